@@ -1,0 +1,199 @@
+"""CPU tier: the oracle (oracle/) against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import squeezedet_pytorch_amd as sqd
+from squeezedet_pytorch_amd import synthetic
+
+TOL = 1e-4   # north_star: class scores / box deltas within 1e-4 fp32
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_anchors_bit_exact(golden_dir):
+    g = load(golden_dir, "anchors.npz")
+    a = oracle.generate_anchors((24, 78), (384, 1248), oracle.KITTI_ANCHOR_SEED)
+    assert a.dtype == np.float64 and np.array_equal(a, g["kitti"])
+    assert np.array_equal(oracle.generate_anchors((4, 6), (64, 96), oracle.KITTI_ANCHOR_SEED), g["small"])
+    # product-side generator agrees too
+    assert np.array_equal(sqd.boxes.generate_anchors((24, 78), (384, 1248), sqd.boxes.KITTI_ANCHORS_SEED), g["kitti"])
+    assert list(a[0]) == [8., 8., 34., 30.] and list(a[-1]) == [1240., 376., 381., 185.]
+
+
+@pytest.mark.parametrize("arch", ["squeezedet", "squeezedetplus"])
+def test_backbone_small(golden_dir, arch):
+    g = load(golden_dir, "backbone_small.npz")
+    cfg = sqd.make_cfg(arch=arch, input_size=(64, 96), device="cpu")
+    sd = synthetic.make_state_dict(arch, seed=1234)
+    x = synthetic.make_images(2, (64, 96), seed=3)
+    cap = {}
+    with torch.no_grad():
+        pred = oracle.backbone_forward(x, sd, arch, capture=cap)
+        ids, sc, bx = oracle.inference_head(pred, cfg.anchors, cfg.input_size)
+    assert pred.shape == (2, cfg.num_anchors, 8)
+    np.testing.assert_allclose(pred.numpy(), g[f"{arch}_pred"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(sc.numpy(), g[f"{arch}_scores"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(bx.numpy(), g[f"{arch}_boxes"], atol=2e-3, rtol=0)   # pixels
+    assert (ids.numpy() == g[f"{arch}_class_ids"]).mean() > 0.999
+    np.testing.assert_allclose(cap["features.3"].numpy()[:, ::8], g[f"{arch}_feat3"], atol=TOL, rtol=0)
+    for i in (0, 2, 3, 5, 14):
+        t = cap[f"features.{i}"].double()
+        ref = g[f"{arch}_feat{i}_sum"]
+        assert abs(t.sum().item() - ref[0]) <= 1e-6 * ref[1] + 1e-3
+        assert abs(t.abs().sum().item() - ref[1]) <= 1e-6 * ref[1] + 1e-3
+
+
+def test_kitti_full_forward(golden_dir):
+    g = load(golden_dir, "kitti_full.npz")
+    cfg = sqd.make_cfg(device="cpu")
+    sd = synthetic.make_state_dict("squeezedet", seed=1234)
+    x = synthetic.make_images(1, (384, 1248), seed=0)
+    cap = {}
+    with torch.no_grad():
+        pred = oracle.backbone_forward(x, sd, capture=cap)
+        ids, sc, bx = oracle.inference_head(pred, cfg.anchors, cfg.input_size)
+    np.testing.assert_allclose(pred[0, ::257].numpy(), g["pred_rows"], atol=TOL, rtol=0)
+    for i in range(15):
+        t = cap[f"features.{i}"].double()
+        assert abs(t.abs().sum().item() - g["layer_sums"][i, 1]) <= 1e-6 * g["layer_sums"][i, 1]
+    top = g["top_idx"]
+    np.testing.assert_allclose(sc[0].numpy()[top], g["top_scores"], atol=TOL, rtol=0)
+    assert np.array_equal(ids[0].numpy()[top], g["top_class_ids"])
+    np.testing.assert_allclose(bx[0].numpy()[top], g["top_boxes"], atol=2e-3, rtol=0)
+
+
+def _decode_pred():
+    rs = np.random.RandomState(11)
+    return torch.from_numpy((rs.standard_normal((2, 16848, 8)) * np.array([2, 2, 2, 2, .4, .4, .4, .4])).astype(np.float32))
+
+
+def test_decode_and_head(golden_dir):
+    g = load(golden_dir, "decode.npz")
+    cfg = sqd.make_cfg(device="cpu")
+    pred = _decode_pred()
+    probs, logp, scores, deltas, boxes = oracle.resolve_predictions(pred, cfg.anchors, cfg.input_size, log_softmax=True)
+    ids, best, bx = oracle.inference_head(pred, cfg.anchors, cfg.input_size)
+    sel = g["sel"]
+    np.testing.assert_allclose(probs.numpy()[:, sel], g["probs"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(logp.numpy()[:, sel], g["logp"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(scores.numpy()[:, sel], g["scores"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(boxes.numpy()[:, sel], g["boxes"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(best.numpy()[:, sel], g["best"], atol=1e-6, rtol=0)
+    assert np.array_equal(ids.numpy()[:, sel], g["class_ids"])
+    assert abs(best.double().sum().item() - g["best_sum"][0]) < 1e-2
+    assert abs(boxes.double().sum().item() - g["box_sum"][0]) < 1e-7 * abs(g["box_sum"][0]) + 1.0
+
+
+def test_filter_matches_reference_control_flow(golden_dir):
+    """Row K: the reference's own Detector.filter (with oracle.nms bound as torchvision.ops.nms)
+    produced these; the oracle's filter_detections must give identical sequences."""
+    g = load(golden_dir, "filter.npz")
+    cfg = sqd.make_cfg(device="cpu")
+    pred = _decode_pred()
+    ids, best, bx = oracle.inference_head(pred, cfg.anchors, cfg.input_size)
+    for b in range(2):
+        d = oracle.filter_detections(ids[b].numpy(), best[b].numpy(), bx[b].numpy())
+        assert np.array_equal(d["class_ids"], g[f"syn{b}_class_ids"])
+        np.testing.assert_array_equal(d["scores"], g[f"syn{b}_scores"])
+        np.testing.assert_array_equal(d["boxes"], g[f"syn{b}_boxes"])
+        # the extra anchor_idx output is consistent with the kept rows
+        np.testing.assert_array_equal(best[b].numpy()[d["anchor_idx"]], d["scores"])
+    assert "allbelow_none" in g.files
+    assert oracle.filter_detections(ids[0].numpy(), best[0].numpy() * 0.2, bx[0].numpy()) is None
+
+
+def test_nms_known_answers():
+    """Hand-derived KATs for the restated NMS (torchvision not available -> unpinned otherwise)."""
+    # A=[0,0,10,10]; B shifted by 4.2 in x: inter=5.8*10=58, union=142 -> IoU 0.40845 (>0.4 -> suppressed)
+    # C shifted by 4.3: inter=57, union=143 -> 0.3986 (kept)
+    boxes = np.array([[0, 0, 10, 10], [4.2, 0, 14.2, 10], [30, 30, 40, 40]], np.float32)
+    assert list(oracle.nms(boxes, np.array([.9, .8, .7], np.float32), 0.4)) == [0, 2]
+    boxes[1] = [4.3, 0, 14.3, 10]
+    assert list(oracle.nms(boxes, np.array([.9, .8, .7], np.float32), 0.4)) == [0, 1, 2]
+    # order follows score, output in descending-score order, chain: B suppressed by A cannot suppress C
+    boxes = np.array([[0, 0, 10, 10], [4, 0, 14, 10], [8, 0, 18, 10]], np.float32)   # IoU(A,B)=.4286 IoU(B,C)=.4286 IoU(A,C)=.111
+    assert list(oracle.nms(boxes, np.array([.5, .9, .7], np.float32), 0.4)) == [1]
+    assert list(oracle.nms(boxes, np.array([.9, .7, .5], np.float32), 0.4)) == [0, 2]
+    # equal scores: stable (input order); degenerate zero-area boxes: IoU = 0/0 = NaN -> not suppressed
+    z = np.array([[5, 5, 5, 5], [5, 5, 5, 5]], np.float32)
+    assert list(oracle.nms(z, np.array([.5, .5], np.float32), 0.4)) == [0, 1]
+    # negative-width box (x2<x1): negative area, inter clamps to 0 -> never suppressed / never suppresses
+    n = np.array([[10, 0, 4, 10], [0, 0, 10, 10]], np.float32)
+    assert list(oracle.nms(n, np.array([.9, .8], np.float32), 0.4)) == [0, 1]
+
+
+def test_filter_known_answers():
+    A = 200
+    scores = np.linspace(0.9, 0.1, A).astype(np.float32)
+    cls = (np.arange(A) % 3).astype(np.int64)
+    boxes = np.zeros((A, 4), np.float32)
+    boxes[:, 0] = np.arange(A) * 20; boxes[:, 2] = boxes[:, 0] + 10; boxes[:, 3] = 10    # disjoint
+    d = oracle.filter_detections(cls, scores, boxes)
+    # top-64 only, class order 0,1,2, each descending, threshold 0.3 applied after
+    assert len(d["scores"]) == 64 and (d["scores"] > 0.3).all()
+    assert list(d["class_ids"]) == sorted(d["class_ids"])
+    for c in range(3):
+        s = d["scores"][d["class_ids"] == c]
+        assert (np.diff(s) < 0).all()
+    assert set(d["anchor_idx"]) == set(range(64))
+    # ties: lower anchor index first
+    s2 = np.full(A, 0.5, np.float32)
+    d2 = oracle.filter_detections(np.zeros(A, np.int64), s2, boxes)
+    assert list(d2["anchor_idx"]) == list(range(64))
+    # score exactly at threshold is dropped (strict >)
+    s3 = np.full(A, 0.3, np.float32)
+    assert oracle.filter_detections(np.zeros(A, np.int64), s3, boxes) is None
+
+
+def test_gt_encoding_and_loss(golden_dir):
+    g = load(golden_dir, "loss.npz")
+    cfg = sqd.make_cfg(device="cpu")
+    gts = []
+    for b in range(2):
+        d, idx = oracle.compute_deltas(g[f"gtboxes{b}"], cfg.anchors)
+        assert np.array_equal(idx, g[f"gtidx{b}"])
+        np.testing.assert_array_equal(d, g[f"gtdeltas{b}"])
+        d2, idx2 = sqd.boxes.compute_deltas(g[f"gtboxes{b}"], cfg.anchors)      # product-side encoder
+        assert np.array_equal(idx2, idx) and np.array_equal(d2, d)
+        gts.append(oracle.encode_gt(g[f"gtcls{b}"], g[f"gtboxes{b}"], cfg.anchors))
+        np.testing.assert_array_equal(gts[-1], sqd.boxes.prepare_annotations(g[f"gtcls{b}"], g[f"gtboxes{b}"], cfg.anchors, 3))
+    gt = torch.from_numpy(np.stack(gts))
+    pred = _decode_pred().requires_grad_(True)
+    loss, st = oracle.multitask_loss(pred, gt, cfg.anchors, cfg.input_size)
+    np.testing.assert_allclose(loss.detach().numpy(), g["loss"], rtol=1e-5)
+    for k in ("class_loss", "score_loss", "bbox_loss"):
+        np.testing.assert_allclose(st[k].detach().numpy(), g[k], rtol=1e-5)
+    loss.mean().backward()
+    gr = pred.grad.numpy()
+    for b in range(2):
+        pos = np.nonzero(gts[b][:, 0])[0]
+        np.testing.assert_allclose(gr[b][pos], g[f"grad_pos{b}"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(gr[:, g["neg"]], g["grad_neg"], rtol=1e-4, atol=1e-9)
+    assert abs(np.abs(gr.astype(np.float64)).sum() - g["grad_abs_sum"][0]) < 1e-4 * g["grad_abs_sum"][0]
+
+
+def test_train_step_small(golden_dir):
+    g = load(golden_dir, "train_step_small.npz")
+    cfg = sqd.make_cfg(input_size=(64, 96), device="cpu")
+    sd = synthetic.make_state_dict("squeezedet", seed=1234)
+    x = synthetic.make_images(2, (64, 96), seed=3)
+    gt = synthetic.make_gt(2, cfg.anchors, (64, 96), seed=2, min_boxes=2, max_boxes=3)
+    new_p, new_m, grads, total, loss_vec, stats = oracle.train_step_reference(sd, None, x, gt, cfg.anchors, cfg.input_size)
+    names = [str(n) for n in g["names"]]
+    assert names == list(sd.keys())
+    np.testing.assert_allclose(loss_vec.numpy(), g["loss_vec"], rtol=1e-4)
+    assert abs(total - g["total_norm"][0]) < 1e-3 * g["total_norm"][0]
+    gn = np.array([float(grads[k].double().norm()) for k in names])
+    np.testing.assert_allclose(gn, g["grad_norms"], rtol=2e-3, atol=1e-6)
+    coef = min(1.0, 5.0 / (total + 1e-6))     # the golden .grad tensors were read after clip_grad_norm_
+    np.testing.assert_allclose(grads["base.convdet.bias"].numpy() * coef, g["convdet_bias_grad"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(grads["base.features.0.weight"].numpy() * coef, g["stem_w_grad"], rtol=1e-2, atol=1e-6)
+    ps = np.array([float(new_p[k].double().abs().sum()) for k in names])
+    np.testing.assert_allclose(ps, g["new_param_abs"], rtol=1e-5)
