@@ -1,0 +1,74 @@
+/* sqd_hip.h -- C ABI of libsqdhip.so: the MI355X (gfx950) SqueezeDet hot path.
+ *
+ * The reference (hazenai/SqueezeDet-PyTorch) is pure Python over torch.nn; it has no FFI of its own.
+ * The seam this library plugs into is the nn.Module surface; every entry point
+ * below names the reference code it replaces.  Conventions:
+ *   - plain pointers to DEVICE memory, explicit sizes, a hipStream_t passed as void*; no torch types;
+ *   - every function only enqueues work on `stream` (never synchronises, never allocates), so it can
+ *     be captured into a hipGraph; the library keeps no mutable global state and is re-entrant;
+ *   - return value: 0 ok, 1 bad argument, 2 unsupported configuration, 3 launch failure;
+ *   - activations are NHWC fp32; a tensor argument is described by (pitch, coff, C): the layer
+ *     touches channels [coff, coff+C) of a buffer whose pixel stride is `pitch` floats.  All channel
+ *     counts / pitches / offsets are multiples of 4 and all base pointers 16-byte aligned.
+ */
+#ifndef SQD_HIP_H
+#define SQD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- tile configurations of the implicit-GEMM convolution -------------------------------------- */
+int sqd_conv_num_cfgs(void);
+/* taps (1 or 9), K-chunk, pixels per workgroup tile, output channels per workgroup slice */
+int sqd_conv_cfg_info(int cfg_id, int* taps, int* kc, int* tile_px, int* bn);
+
+/* Convolution 1x1 or 3x3/pad 1, stride 1, on the fp32 matrix cores, with fused bias / ReLU /
+ * accumulate and an optional ReLU mask applied to the input (x * (xmask > 0)).
+ * Replaces nn.Conv2d + nn.ReLU(inplace) of Fire.squeeze / expand1x1 / expand3x3
+ * (src/model/squeezedet.py:12-14,18-22), torch.cat (:19-22, via y_coff), ConvDet (:73-75,:83) and,
+ * with transposed+flipped weights, their autograd data-gradients (src/engine/trainer.py:47).
+ * w_packed: [ceil(C/kc)][taps][Npad][kc] fp32, zero padded, Npad = ceil(N/bn)*bn (kc, bn from cfg). */
+int sqd_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y, const float* xmask,
+                 int B, int H, int W, int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff,
+                 int relu, int accumulate, int xmask_pitch, int xmask_coff, int cfg_id, void* stream);
+
+/* Stem: Conv2d(3, N, k, stride 2, pad k/2) + ReLU, NCHW image -> NHWC features.
+ * (k,N) = (3,64) squeezedet (src/model/squeezedet.py:34-35) or (7,96) squeezedetplus (:52-53).
+ * w is the checkpoint tensor itself (OIHW). */
+int sqd_stem_conv_relu_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
+                           int B, int Hin, int Win, int N, int ksize, void* stream);
+
+/* nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True) (src/model/squeezedet.py:36,39,42), NHWC.
+ * argmax (uint8, same shape as y, may be NULL) records the window position 0..8 for the backward. */
+int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C,
+                              void* stream);
+int sqd_maxpool3x3s2_ceil_bwd(const float* dy, const unsigned char* argmax, float* dx, int B, int H, int W,
+                              int C, void* stream);
+
+/* Dense decode: PredictionResolver.forward + the argmax/max of SqueezeDet.forward
+ * (src/model/squeezedet.py:109-120,199-202; src/model/modules.py:17-45,66-68).
+ * pred [B][A][num_classes+5], anchors [A][4] (cx,cy,w,h) -> class_ids int64 [B][A], scores [B][A],
+ * boxes [B][A][4] xyxy clamped to the input. */
+int sqd_decode_fwd(const float* pred, const float* anchors, long long* class_ids, float* scores, float* boxes,
+                   int B, int A, int num_classes, int input_h, int input_w, void* stream);
+
+/* Fused decode + Detector.filter for a whole batch (src/engine/detector.py:87-122 + torchvision nms +
+ * the scale division of boxes_postprocess, src/utils/boxes.py:145-147): top keep_top_k (<= 64) by score,
+ * class-wise NMS, score threshold, compacted in class order.  Fixed-capacity outputs [B][keep_top_k];
+ * det_count[b] rows are valid.  det_anchor = anchor index of every kept detection (not returned by the
+ * reference; this is what "box indices bit-exact" is asserted on).  scales [B][2]=(sy,sx) or NULL. */
+int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, int* det_count,
+                   long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
+                   int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
+                   float score_thresh, void* stream);
+
+/* Detector.filter on already decoded dense tensors (class_ids int64 [B][A], scores [B][A], boxes [B][A][4]). */
+int sqd_filter_fwd(const long long* class_ids, const float* scores, const float* boxes, int* det_count,
+                   long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
+                   int num_classes, int keep_top_k, float nms_thresh, float score_thresh, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQD_HIP_H */

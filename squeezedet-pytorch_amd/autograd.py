@@ -1,0 +1,117 @@
+"""Forward / backward executors behind ``torch.autograd.Function`` so that ``SqueezeDetBase`` and
+``Loss`` keep the reference's ``nn.Module`` surface (src/model/squeezedet.py:79-87, :133-174) while
+every FLOP runs in the HIP kernels.
+
+The whole backbone is ONE autograd node: its forward walks the layer table launching
+stem -> pool -> (squeeze, expand1x1, expand3x3)* -> ConvDet on the current stream, keeping NHWC
+activations; its backward walks the table in reverse (dgrad = the same implicit-GEMM kernel with
+transposed/flipped weights and the ReLU mask applied while staging dY; wgrad / bias-grad kernels)
+and returns the gradients of the 64 canonical OIHW parameters.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .synthetic import layer_table
+
+
+def _needs_grad(base):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in base.parameters())
+
+
+def run_backbone_forward(base, image, save=False, drop_mask=None):
+    """Launch the forward plan.  Returns (pred_nhwc [B,H,W,A_per_cell*(C+5)], saved dict | None)."""
+    if not image.is_cuda:
+        raise RuntimeError('SqueezeDetBase runs on the MI355X HIP kernels only: input must be a CUDA/HIP tensor')
+    if image.dtype != torch.float32:
+        raise RuntimeError('SqueezeDetBase expects fp32 input')
+    layers = layer_table(base.arch)
+    feats = base.features
+    B = image.shape[0]
+    saved = {} if save else None
+    stem = feats[0]
+    a = ops.stem_conv_relu(image, stem.weight, stem.bias)
+    if save:
+        saved['image'] = image
+        saved['stem_out'] = a
+    for i in range(2, len(layers)):
+        l = layers[i]
+        if l[0] == 'pool':
+            Bq, H, W, C = a.shape
+            am = torch.empty(Bq, *ops.pool_out_size(H, W), C, device=a.device, dtype=torch.uint8) if save else None
+            y = ops.maxpool(a, argmax=am)
+            if save:
+                saved[f'pool{i}'] = (am, (H, W))
+            a = y
+        else:
+            _, cin, s, e1, e3 = l
+            fire = feats[i]
+            Bq, H, W, C = a.shape
+            assert C == cin, f'layer {i}: expected {cin} channels, got {C}'
+            npix = Bq * H * W
+            sq = torch.empty(Bq, H, W, s, device=a.device, dtype=torch.float32)
+            ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
+            out = torch.empty(Bq, H, W, e1 + e3, device=a.device, dtype=torch.float32)
+            ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, s, e1, npix)), out, 0, relu=True)
+            ops.conv(sq, 0, base.plan(f'{i}.expand3x3', fire.expand3x3, ops.choose_cfg(9, s, e3, npix)), out, e1, relu=True)
+            if save:
+                saved[f'fire{i}'] = (a, sq, out)
+            a = out
+    if drop_mask is not None:
+        a = a * drop_mask                      # elementwise plumbing; mask is NHWC, pre-scaled by 1/(1-p)
+    Bq, H, W, C = a.shape
+    cd = base.convdet
+    pred = torch.empty(Bq, H, W, cd.out_channels, device=a.device, dtype=torch.float32)
+    ops.conv(a, 0, base.plan('convdet', cd, ops.choose_cfg(9, C, cd.out_channels, Bq * H * W)), pred, 0, relu=False)
+    if save:
+        saved['convdet_in'] = a
+        saved['drop_mask'] = drop_mask
+    return pred, saved
+
+
+def _make_drop_mask(base, like_nhwc_shape, device):
+    if base._forced_drop_mask is not None:
+        return base._forced_drop_mask.to(device).permute(0, 2, 3, 1).contiguous()
+    p = base.dropout_prob
+    keep = torch.rand(like_nhwc_shape, device=device) >= p
+    return keep.to(torch.float32) / (1.0 - p)
+
+
+def _feature_shape(base, image):
+    """NHWC shape of the feature map entering ConvDet (needed to draw the dropout mask up front)."""
+    h, w = image.shape[2], image.shape[3]
+    layers = layer_table(base.arch)
+    h, w = ops.stem_out_size(h, w, layers[0][3])
+    c = layers[0][2]
+    for l in layers[2:]:
+        if l[0] == 'pool':
+            h, w = ops.pool_out_size(h, w)
+        else:
+            c = l[3] + l[4]
+    return (image.shape[0], h, w, c)
+
+
+def backbone_apply(base, image):
+    train_drop = base.training and base.dropout is not None
+    drop_mask = _make_drop_mask(base, _feature_shape(base, image), image.device) if train_drop else None
+    if _needs_grad(base):
+        from .backward import BackboneFn
+        params = [p for _, p in base.named_parameters()]
+        pred = BackboneFn.apply(base, image, drop_mask, *params)
+    else:
+        pred, _ = run_backbone_forward(base, image, save=False, drop_mask=drop_mask)
+    B = pred.shape[0]
+    out = pred.view(B, -1, base.num_classes + 5)
+    if out.shape[1] != base.num_anchors:
+        raise RuntimeError(f'input size yields {out.shape[1]} anchors but cfg.num_anchors is {base.num_anchors}')
+    return out
+
+
+def loss_apply(loss_mod, pred, gt):
+    from .backward import LossFn
+    anchors = loss_mod.resolver.anchors_on(pred.device)
+    vec = LossFn.apply(pred, gt, anchors, loss_mod)
+    # vec: [4, B] = (class, pos+neg score, bbox, total) -- reference returns (loss, stats dict), :166-174
+    class_loss, score_loss, bbox_loss, loss = vec[0], vec[1], vec[2], vec[3]
+    return loss, {'loss': loss, 'class_loss': class_loss, 'score_loss': score_loss, 'bbox_loss': bbox_loss}

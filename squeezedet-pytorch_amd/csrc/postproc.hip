@@ -1,0 +1,307 @@
+// Post-processing: per-anchor decode (softmax / sigmoid / anchor box transform) and the fused
+// detection kernel (decode -> top-k by score -> class-wise NMS -> score threshold -> compact).
+//
+// Reference: PredictionResolver.forward src/model/squeezedet.py:109-120, safe_softmax
+// src/model/modules.py:66-68, deltas_to_boxes :27-45, xywh_to_xyxy :17-24, SqueezeDet.forward
+// src/model/squeezedet.py:199-206, Detector.filter src/engine/detector.py:87-122 (+ torchvision nms),
+// boxes_postprocess src/utils/boxes.py:145-147 (the eval-time scale division).
+//
+// pred is [B][A][C+5] fp32 (anchor-major: C class logits, 1 confidence logit, 4 deltas), anchors
+// [A][4] (cx,cy,w,h) fp32.  The reference runs ~15 elementwise launches plus a Python loop with
+// >=10 host syncs per image; here one workgroup per image does everything on chip:
+//   1. every thread scores its anchors (score = max_c softmax_c * sigmoid(conf)); the fp32 score
+//      bit patterns (non-negative floats order like uint32) go to LDS (A*4 bytes),
+//   2. 4-pass 8-bit radix select finds the K-th largest key; candidates above it are gathered,
+//      ties at the threshold are taken in ascending anchor order (the build's documented tie rule),
+//   3. one wave ranks the <=64 candidates (score desc, anchor index asc), decodes their boxes,
+//      builds the 64x64 suppression bit matrix (one 64-bit row per lane) and runs greedy NMS with
+//      a wave-uniform alive mask; survivors are compacted in class order 0..C-1, each class in
+//      descending score, then thresholded -- the exact output order of Detector.filter.
+// Arithmetic mirrors the oracle op for op in fp32 (built with -ffp-contract=off, IEEE division), so
+// that, given identical pred, the kept anchor indices are bit-exact.
+#include "sqd_common.h"
+#include <math.h>
+
+#define SQD_MAX_CLASSES 16
+
+struct BoxF { float x1, y1, x2, y2; };
+
+// score / class of one anchor row.  p points at C+5 floats.
+__device__ __forceinline__ void anchor_score(const float* __restrict__ p, int C, float& score, int& cls) {
+  float l[SQD_MAX_CLASSES];
+  float conf_logit;
+  if (C == 3) {
+    const f32x4 v = *(const f32x4*)p;
+    l[0] = v.x; l[1] = v.y; l[2] = v.z; conf_logit = v.w;
+  } else {
+    for (int c = 0; c < C; ++c) l[c] = p[c];
+    conf_logit = p[C];
+  }
+  float m = l[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, l[c]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) { l[c] = expf(l[c] - m); sum += l[c]; }
+  const float conf = 1.f / (1.f + expf(-conf_logit));
+  float best = -1.f; int bc = 0;
+  for (int c = 0; c < C; ++c) {
+    const float v = (l[c] / sum) * conf;
+    if (v > best) { best = v; bc = c; }
+  }
+  score = best; cls = bc;
+}
+
+__device__ __forceinline__ BoxF anchor_box(const float* __restrict__ d, const float* __restrict__ anc, float wmax, float hmax) {
+  const float ax = anc[0], ay = anc[1], aw = anc[2], ah = anc[3];
+  const float cx = ax + aw * d[0];
+  const float cy = ay + ah * d[1];
+  const float w = aw * expf(d[2]);
+  const float h = ah * expf(d[3]);
+  BoxF b;
+  b.x1 = fminf(fmaxf(cx - 0.5f * (w - 1.f), 0.f), wmax);
+  b.y1 = fminf(fmaxf(cy - 0.5f * (h - 1.f), 0.f), hmax);
+  b.x2 = fminf(fmaxf(cx + 0.5f * (w - 1.f), 0.f), wmax);
+  b.y2 = fminf(fmaxf(cy + 0.5f * (h - 1.f), 0.f), hmax);
+  return b;
+}
+
+// ---- full decode (module surface of SqueezeDet.forward: dense class_ids / scores / boxes) ----
+__global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ pred, const float* __restrict__ anchors,
+                                                     long long* __restrict__ class_ids, float* __restrict__ scores,
+                                                     float* __restrict__ boxes, int B, int A, int C, float wmax, float hmax) {
+  const long long total = (long long)B * A;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const float* p = pred + i * (C + 5);
+    float s; int c;
+    anchor_score(p, C, s, c);
+    const BoxF b = anchor_box(p + C + 1, anchors + 4 * a, wmax, hmax);
+    class_ids[i] = c; scores[i] = s;
+    *(f32x4*)(boxes + 4 * i) = (f32x4){b.x1, b.y1, b.x2, b.y2};
+  }
+}
+
+extern "C" int sqd_decode_fwd(const float* pred, const float* anchors, long long* class_ids, float* scores,
+                              float* boxes, int B, int A, int num_classes, int input_h, int input_w, void* stream) {
+  SQD_CHECK_ARG(pred && anchors && class_ids && scores && boxes && B > 0 && A > 0);
+  SQD_CHECK_ARG(num_classes >= 1 && num_classes <= SQD_MAX_CLASSES);
+  SQD_CHECK_ARG(((uintptr_t)pred & 15) == 0 && ((uintptr_t)boxes & 15) == 0);
+  const long long total = (long long)B * A;
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, anchors, class_ids,
+                     scores, boxes, B, A, num_classes, (float)(input_w - 1), (float)(input_h - 1));
+  return sqd_launch_status();
+}
+
+// ---- fused detection: one workgroup per image ----
+#define DET_THREADS 1024
+#define DET_K 64
+
+struct DetArgs {
+  const float* pred; const float* anchors; const float* scales;   // scales [B][2] = (sy, sx) or null
+  const long long* in_class; const float* in_score; const float* in_box;   // dense inputs (filter mode) or null
+  int* det_count; long long* det_class; float* det_score; float* det_box; int* det_anchor;
+  int B, A, C, K;
+  float wmax, hmax, nms_thresh, score_thresh;
+};
+
+__global__ __launch_bounds__(DET_THREADS) void detect_kernel(DetArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned* keys = (unsigned*)smem_raw;                       // [A]
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_need, s_cnt;
+  __shared__ unsigned wave_tot[DET_THREADS / 64];
+  __shared__ unsigned cand_key[DET_K];
+  __shared__ int cand_idx[DET_K];
+  __shared__ int sorted_pos[DET_K];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, A = a.A, C = a.C, K = a.K;
+  const float* pred = a.pred ? a.pred + (long long)b * A * (C + 5) : nullptr;
+
+  // 1. scores -> keys
+  const bool dense = a.in_score != nullptr;   // Detector.filter(det) mode: start from decoded tensors
+  for (int i = tid; i < A; i += DET_THREADS) {
+    float s; int c;
+    if (dense) s = a.in_score[(long long)b * A + i];
+    else anchor_score(pred + (long long)i * (C + 5), C, s, c);
+    keys[i] = __float_as_uint(s);
+  }
+  if (tid < DET_K) { cand_key[tid] = 0u; cand_idx[tid] = 0x7fffffff - DET_K + tid; }   // distinct sentinels: ranks stay a permutation
+  if (tid == 0) { s_prefix = 0u; s_need = (unsigned)K; s_cnt = 0u; }
+  __syncthreads();
+
+  int ncand;
+  if (A <= K) {
+    // everything is a candidate
+    for (int i = tid; i < A; i += DET_THREADS) { cand_key[i] = keys[i]; cand_idx[i] = i; }
+    ncand = A;
+    __syncthreads();
+  } else {
+    // 2. radix select of the K-th largest key
+    unsigned mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      if (tid < 256) hist[tid] = 0u;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+      for (int i = tid; i < A; i += DET_THREADS) {
+        const unsigned k = keys[i];
+        if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned need = s_need, cum = 0u;
+        int bkt = 255;
+        for (; bkt > 0; --bkt) {
+          if (cum + hist[bkt] >= need) break;
+          cum += hist[bkt];
+        }
+        s_need = need - cum;              // how many keys to take from this bucket (and below-level ties)
+        s_prefix = prefix | ((unsigned)bkt << shift);
+      }
+      mask |= 255u << shift;
+      __syncthreads();
+    }
+    const unsigned tkey = s_prefix;       // K-th largest key
+    const unsigned need = s_need;         // number of keys == tkey to take (>= 1)
+    const unsigned n_gt = (unsigned)K - need;
+    // 3a. keys strictly above the threshold (unordered; ranked later)
+    for (int i = tid; i < A; i += DET_THREADS) {
+      const unsigned k = keys[i];
+      if (k > tkey) { const unsigned pos = atomicAdd(&s_cnt, 1u); cand_key[pos] = k; cand_idx[pos] = i; }
+    }
+    // 3b. ties at the threshold in ascending anchor order: contiguous range per thread + block scan
+    const int chunk = (A + DET_THREADS - 1) / DET_THREADS;
+    const int lo = tid * chunk, hi = min(A, lo + chunk);
+    unsigned c = 0u;
+    for (int i = lo; i < hi; ++i) c += (keys[i] == tkey) ? 1u : 0u;
+    unsigned incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned woff = 0u;
+    for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+    unsigned r = incl - c + woff;
+    for (int i = lo; i < hi && r < need; ++i)
+      if (keys[i] == tkey) { cand_key[n_gt + r] = tkey; cand_idx[n_gt + r] = i; ++r; }
+    ncand = K;
+    __syncthreads();
+  }
+
+  // 4. rank the candidates: score desc, anchor index asc (sentinels: key 0, idx ~INT_MAX -> last)
+  if (tid < DET_K) {
+    const unsigned mykey = cand_key[tid];
+    const int myidx = cand_idx[tid];
+    int rank = 0;
+    for (int j = 0; j < DET_K; ++j) {
+      const unsigned kj = cand_key[j]; const int ij = cand_idx[j];
+      rank += (kj > mykey || (kj == mykey && ij < myidx)) ? 1 : 0;
+    }
+    sorted_pos[rank] = tid;             // ranks are a permutation (indices are distinct)
+  }
+  __syncthreads();
+  if (wave != 0) return;                // 5..7: one wave
+  const int src = sorted_pos[lane];
+  const int idx = cand_idx[src];
+  const bool ok = src < ncand && lane < K;
+  float score = 0.f; int cls = -1;
+  BoxF bx = {0.f, 0.f, 0.f, 0.f};
+  if (ok && dense) {
+    const long long o = (long long)b * A + idx;
+    score = a.in_score[o]; cls = (int)a.in_class[o];
+    const f32x4 v = *(const f32x4*)(a.in_box + 4 * o);
+    bx.x1 = v.x; bx.y1 = v.y; bx.x2 = v.z; bx.y2 = v.w;
+  } else if (ok) {
+    const float* p = pred + (long long)idx * (C + 5);
+    anchor_score(p, C, score, cls);
+    bx = anchor_box(p + C + 1, a.anchors + 4 * idx, a.wmax, a.hmax);
+  }
+  // suppression row: bit j set if j ranks after me, same class, IoU > thresh
+  const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
+  unsigned long long row = 0ull;
+  for (int j = 0; j < DET_K; ++j) {
+    const float jx1 = __shfl(bx.x1, j), jy1 = __shfl(bx.y1, j), jx2 = __shfl(bx.x2, j), jy2 = __shfl(bx.y2, j);
+    const float jarea = __shfl(area, j);
+    const int jcls = __shfl(cls, j);
+    const float w = fmaxf(0.f, fminf(bx.x2, jx2) - fmaxf(bx.x1, jx1));
+    const float h = fmaxf(0.f, fminf(bx.y2, jy2) - fmaxf(bx.y1, jy1));
+    const float inter = w * h;
+    const float ovr = inter / ((area + jarea) - inter);
+    if (j > lane && jcls == cls && cls >= 0 && ovr > a.nms_thresh) row |= 1ull << j;
+  }
+  unsigned long long alive = __ballot(ok);
+  for (int i = 0; i < DET_K; ++i) {
+    const unsigned lo32 = __shfl((unsigned)(row & 0xffffffffull), i);
+    const unsigned hi32 = __shfl((unsigned)(row >> 32), i);
+    if ((alive >> i) & 1ull) alive &= ~(((unsigned long long)hi32 << 32) | lo32);
+  }
+  const bool keep = ((alive >> lane) & 1ull) && score > a.score_thresh;
+  int pos = 0, total = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int c = 0; c < C; ++c) {
+    const unsigned long long m = __ballot(keep && cls == c);
+    if (c < cls) pos += __popcll(m);
+    else if (c == cls) pos += __popcll(m & below);
+    total += __popcll(m);
+  }
+  if (lane == 0) a.det_count[b] = total;
+  if (keep) {
+    float sx = 1.f, sy = 1.f;
+    if (a.scales) { sy = a.scales[2 * b]; sx = a.scales[2 * b + 1]; }
+    const long long o = (long long)b * K + pos;
+    a.det_class[o] = cls;
+    a.det_score[o] = score;
+    a.det_anchor[o] = idx;
+    *(f32x4*)(a.det_box + 4 * o) = (f32x4){bx.x1 / sx, bx.y1 / sy, bx.x2 / sx, bx.y2 / sy};
+  }
+}
+
+static int launch_detect(DetArgs a, hipStream_t stream) {
+  if (a.K < 1 || a.K > DET_K) return SQD_ERR_UNSUPPORTED;                 // one wave holds the NMS bit matrix
+  const size_t lds = (size_t)a.A * sizeof(unsigned);
+  if (lds > 150 * 1024) return SQD_ERR_UNSUPPORTED;                       // A <= 38400 anchors per image
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute((const void*)detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SQD_ERR_LAUNCH;
+  hipLaunchKernelGGL(detect_kernel, dim3((unsigned)a.B), dim3(DET_THREADS), lds, stream, a);
+  return sqd_launch_status();
+}
+
+// Fused decode + Detector.filter for a batch, straight from pred.  Outputs are fixed-capacity
+// [B][K]; rows >= det_count[b] are left untouched.  scales ([B][2] = (sy,sx), may be null) folds
+// boxes_postprocess' division into the store.
+extern "C" int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, int* det_count,
+                              long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
+                              int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
+                              float score_thresh, void* stream) {
+  SQD_CHECK_ARG(pred && anchors && det_count && det_class && det_score && det_box && det_anchor);
+  SQD_CHECK_ARG(B > 0 && A > 0 && num_classes >= 1 && num_classes <= SQD_MAX_CLASSES);
+  SQD_CHECK_ARG(((uintptr_t)pred & 15) == 0 && ((uintptr_t)det_box & 15) == 0);
+  DetArgs a;
+  a.pred = pred; a.anchors = anchors; a.scales = scales; a.in_class = nullptr; a.in_score = nullptr; a.in_box = nullptr;
+  a.det_count = det_count; a.det_class = det_class; a.det_score = det_score; a.det_box = det_box; a.det_anchor = det_anchor;
+  a.B = B; a.A = A; a.C = num_classes; a.K = keep_top_k;
+  a.wmax = (float)(input_w - 1); a.hmax = (float)(input_h - 1);
+  a.nms_thresh = nms_thresh; a.score_thresh = score_thresh;
+  return launch_detect(a, (hipStream_t)stream);
+}
+
+// Detector.filter(det) proper: the same kernel fed with already decoded dense tensors
+// (class_ids int64 [B][A], scores [B][A], boxes [B][A][4]).
+extern "C" int sqd_filter_fwd(const long long* class_ids, const float* scores, const float* boxes, int* det_count,
+                              long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
+                              int num_classes, int keep_top_k, float nms_thresh, float score_thresh, void* stream) {
+  SQD_CHECK_ARG(class_ids && scores && boxes && det_count && det_class && det_score && det_box && det_anchor);
+  SQD_CHECK_ARG(B > 0 && A > 0 && num_classes >= 1 && num_classes <= SQD_MAX_CLASSES);
+  SQD_CHECK_ARG(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)det_box & 15) == 0);
+  DetArgs a;
+  a.pred = nullptr; a.anchors = nullptr; a.scales = nullptr; a.in_class = class_ids; a.in_score = scores; a.in_box = boxes;
+  a.det_count = det_count; a.det_class = det_class; a.det_score = det_score; a.det_box = det_box; a.det_anchor = det_anchor;
+  a.B = B; a.A = A; a.C = num_classes; a.K = keep_top_k;
+  a.wmax = 0.f; a.hmax = 0.f; a.nms_thresh = nms_thresh; a.score_thresh = score_thresh;
+  return launch_detect(a, (hipStream_t)stream);
+}

@@ -1,0 +1,184 @@
+"""``nn.Module`` surface of the reference's ``src/model/squeezedet.py`` -- same class names,
+constructor arguments, ``forward`` signatures, sub-module attribute names and ``state_dict`` keys /
+shapes (OIHW fp32) -- with every forward/backward running on the hand-written gfx950 kernels.
+
+Reference map:
+  Fire                 src/model/squeezedet.py:9-23
+  SqueezeDetBase       :26-97   (features Sequential, dropout, convdet, init_weights)
+  PredictionResolver   :100-120
+  Loss                 :123-174
+  SqueezeDetWithLoss   :177-187
+  SqueezeDet           :190-206
+
+Internally activations are NHWC fp32; the two expand convolutions of a Fire write disjoint channel
+ranges of one buffer (no ``torch.cat``), ConvDet's NHWC output *is* the permuted tensor of :85.
+Canonical parameters stay OIHW ``nn.Parameter``s (optimizer / clip_grad_norm_ / state_dict touch
+them directly); the packed copies the kernels read are a private cache keyed on ``param._version``.
+There is no CPU path: modules raise if the input is not on a GPU or the HIP library is missing.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .synthetic import layer_table, convdet_in_channels
+
+
+class _ConvParams(nn.Module):
+    """Parameter holder with nn.Conv2d's state_dict layout (``weight`` OIHW, ``bias``)."""
+
+    def __init__(self, cin, cout, ksize, stride=1, padding=0):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.kernel_size, self.stride, self.padding = (ksize, ksize), (stride, stride), (padding, padding)
+        self.weight = nn.Parameter(torch.empty(cout, cin, ksize, ksize))
+        self.bias = nn.Parameter(torch.empty(cout))
+
+    def extra_repr(self):
+        return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}'
+
+    def forward(self, x):
+        raise RuntimeError('layers run fused inside SqueezeDetBase.forward (HIP plan); call the parent module')
+
+
+class _Marker(nn.Module):
+    """Placeholder keeping the reference's nn.Sequential indices (ReLU / MaxPool2d slots)."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return self.what
+
+    def forward(self, x):
+        raise RuntimeError('layers run fused inside SqueezeDetBase.forward (HIP plan); call the parent module')
+
+
+class Fire(nn.Module):
+    def __init__(self, inplanes, squeeze_planes, expand1x1_planes, expand3x3_planes):
+        super().__init__()
+        self.squeeze = _ConvParams(inplanes, squeeze_planes, 1)
+        self.expand1x1 = _ConvParams(squeeze_planes, expand1x1_planes, 1)
+        self.expand3x3 = _ConvParams(squeeze_planes, expand3x3_planes, 3, padding=1)
+
+    def forward(self, x):
+        raise RuntimeError('Fire runs fused inside SqueezeDetBase.forward (HIP plan); call the parent module')
+
+
+class SqueezeDetBase(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.num_classes = cfg.num_classes
+        self.num_anchors = cfg.num_anchors
+        self.arch = cfg.arch
+        mods = []
+        for l in layer_table(cfg.arch):                   # raises ValueError('Invalid architecture.')
+            if l[0] == 'conv':
+                mods.append(_ConvParams(l[1], l[2], l[3], stride=l[4], padding=l[5]))
+            elif l[0] == 'relu':
+                mods.append(_Marker('ReLU (fused into the stem kernel)'))
+            elif l[0] == 'pool':
+                mods.append(_Marker('MaxPool2d(kernel_size=3, stride=2, ceil_mode=True)'))
+            else:
+                mods.append(Fire(*l[1:]))
+        self.features = nn.Sequential(*mods)
+        self.dropout_prob = float(cfg.dropout_prob)
+        self.dropout = nn.Dropout(cfg.dropout_prob, inplace=True) if cfg.dropout_prob > 0 else None
+        self.convdet = _ConvParams(convdet_in_channels(cfg.arch), cfg.anchors_per_grid * (cfg.num_classes + 5), 3, padding=1)
+        self._plans = {}
+        self._forced_drop_mask = None       # tests: NCHW mask (already scaled by 1/(1-p)) instead of RNG
+        self.init_weights()
+
+    # ---- reference: init_weights, src/model/squeezedet.py:89-97 ----
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, _ConvParams):
+                nn.init.normal_(m.weight, mean=0.0, std=0.002 if m is self.convdet else 0.005)
+                nn.init.constant_(m.bias, 0)
+
+    # ---- packed-weight cache ----
+    def plan(self, name, mod, cfg_id, direction='fwd'):
+        key = (name, cfg_id, direction)
+        ver = (mod.weight._version, mod.weight.data_ptr(), mod.bias._version, mod.bias.data_ptr())
+        hit = self._plans.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        if direction == 'fwd':
+            p = ops.ConvPlan(mod.weight, mod.bias, cfg_id)
+        else:
+            p = ops.ConvPlan(ops.dgrad_weight(mod.weight.detach()), None, cfg_id)
+        self._plans[key] = (ver, p)
+        return p
+
+    def forward(self, x):
+        from .autograd import backbone_apply
+        return backbone_apply(self, x)
+
+
+class PredictionResolver(nn.Module):
+    def __init__(self, cfg, log_softmax=False):
+        super().__init__()
+        self.log_softmax = log_softmax
+        self.input_size = cfg.input_size
+        self.num_classes = cfg.num_classes
+        self.anchors = torch.from_numpy(np.asarray(cfg.anchors)).unsqueeze(0).float()
+        self.anchors_per_grid = cfg.anchors_per_grid
+        self._dev_anchors = {}
+
+    def anchors_on(self, device):
+        a = self._dev_anchors.get(device)
+        if a is None:
+            a = self.anchors[0].to(device).contiguous()
+            self._dev_anchors[device] = a
+        return a
+
+    def forward(self, pred):
+        """Dense decode on the GPU: returns (class_ids int64 [B,A], scores [B,A], boxes [B,A,4]) -- the three
+        tensors ``SqueezeDet.forward`` derives from the resolver's five outputs (:199-202)."""
+        return ops.decode(pred, self.anchors_on(pred.device), self.input_size, self.num_classes)
+
+
+class SqueezeDet(nn.Module):
+    """ Model for inference """
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.base = SqueezeDetBase(cfg)
+        self.resolver = PredictionResolver(cfg, log_softmax=False)
+
+    def forward(self, batch):
+        pred = self.base(batch['image'])
+        class_ids, scores, boxes = self.resolver(pred)
+        return {'class_ids': class_ids, 'scores': scores, 'boxes': boxes}
+
+
+class Loss(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.resolver = PredictionResolver(cfg, log_softmax=True)
+        self.num_anchors = cfg.num_anchors
+        self.class_loss_weight = cfg.class_loss_weight
+        self.positive_score_loss_weight = cfg.positive_score_loss_weight
+        self.negative_score_loss_weight = cfg.negative_score_loss_weight
+        self.bbox_loss_weight = cfg.bbox_loss_weight
+
+    def forward(self, pred, gt):
+        from .autograd import loss_apply
+        return loss_apply(self, pred, gt)
+
+
+class SqueezeDetWithLoss(nn.Module):
+    """ Model for training """
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.base = SqueezeDetBase(cfg)
+        self.loss = Loss(cfg)
+
+    def forward(self, batch):
+        pred = self.base(batch['image'])
+        loss, loss_stats = self.loss(pred, batch['gt'])
+        return loss, loss_stats

@@ -1,0 +1,229 @@
+"""Thin, shape-checked Python wrappers over the C-ABI kernels (NHWC fp32 device tensors in,
+NHWC fp32 device tensors out).  Every wrapper validates operand shapes against what the kernel
+and its grid assume *before* launching -- an out-of-bounds access on the GPU can take the node down.
+
+All launches go to the caller's current HIP stream; nothing synchronises.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _native as nat
+
+_CFG_TABLE = None
+
+
+def cfg_table():
+    """{cfg_id: (taps, kc, tile_px, bn)} from the compiled library."""
+    global _CFG_TABLE
+    if _CFG_TABLE is None:
+        _CFG_TABLE = {i: (t, k, px, bn) for i, t, k, px, bn in nat.conv_cfgs()}
+    return _CFG_TABLE
+
+
+def choose_cfg(taps, C, N, npix):
+    """Pick a tile configuration for a conv layer: smallest channel-slice width that covers N in
+    the fewest slices without more than ~12% padding, 128-pixel tiles when that still yields
+    >= 4 workgroups per CU, else 64-pixel tiles."""
+    tab = cfg_table()
+    want_kc = 16 if (taps == 9 or C <= 128 and C % 32 != 0 or C < 64) else 32
+    best = None
+    for cid, (t, kc, px, bn) in tab.items():
+        if t != taps:
+            continue
+        slices = -(-N // bn)
+        pad = slices * bn / N
+        tiles = -(-npix // px) * slices
+        cost = pad                                   # wasted MFMA work
+        cost += 0.15 * (kc != want_kc)
+        cost += 0.02 * slices                        # each slice re-reads the activation tile
+        if tiles < 1024 and px > 64:
+            cost += 0.25                             # too few workgroups for 256 CUs
+        if px == 64 and tiles >= 4096:
+            cost += 0.05
+        if best is None or cost < best[0]:
+            best = (cost, cid)
+    if best is None:
+        raise RuntimeError(f'no conv configuration for taps={taps}')
+    return best[1]
+
+
+class ConvPlan:
+    """Packed weights ([C/KC][TAPS][Npad][KC], zero padded) + bias for one conv in one direction."""
+    __slots__ = ('cfg_id', 'taps', 'kc', 'bn', 'C', 'N', 'Npad', 'w', 'bias')
+
+    def __init__(self, w_oihw, bias, cfg_id):
+        taps_cfg, kc, _px, bn = cfg_table()[cfg_id]
+        N, C, kh, kw = w_oihw.shape
+        taps = kh * kw
+        if taps != taps_cfg or kh != kw or taps not in (1, 9):
+            raise ValueError(f'weight {tuple(w_oihw.shape)} does not fit conv cfg {cfg_id} (taps={taps_cfg})')
+        if C % 4 or N % 4:
+            raise ValueError('channel counts must be multiples of 4')
+        self.cfg_id, self.taps, self.kc, self.bn, self.C, self.N = cfg_id, taps, kc, bn, C, N
+        self.Npad = -(-N // bn) * bn
+        cpad = -(-C // kc) * kc
+        w = w_oihw.detach().to(torch.float32).reshape(N, C, taps).permute(0, 2, 1)         # [N, taps, C]
+        wp = torch.zeros(self.Npad, taps, cpad, device=w.device, dtype=torch.float32)
+        wp[:N, :, :C] = w
+        # [Npad, taps, C/KC, KC] -> [C/KC, taps, Npad, KC]
+        self.w = wp.view(self.Npad, taps, cpad // kc, kc).permute(2, 1, 0, 3).contiguous()
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+
+
+def dgrad_weight(w_oihw):
+    """Weights of the convolution that computes dX from dY: swap in/out channels, flip taps."""
+    return w_oihw.permute(1, 0, 2, 3).flip(2, 3)
+
+
+def _check_nhwc(t, name):
+    if t.dim() != 4 or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f'{name} must be a contiguous fp32 CUDA tensor [B,H,W,C], got {tuple(t.shape)} {t.dtype} {t.device}')
+
+
+def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, xmask_coff=0):
+    """y[..., y_coff:y_coff+N] (=|+=) conv(x[..., x_coff:x_coff+C] [* (xmask>0)]) (+bias) (ReLU)."""
+    _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
+    B, H, W, xp = x.shape
+    if tuple(y.shape[:3]) != (B, H, W):
+        raise ValueError(f'conv: x {tuple(x.shape)} and y {tuple(y.shape)} disagree on B,H,W')
+    yp = y.shape[3]
+    if x_coff < 0 or x_coff + plan.C > xp or y_coff < 0 or y_coff + plan.N > yp:
+        raise ValueError('conv: channel window out of range')
+    mp = 0
+    if xmask is not None:
+        _check_nhwc(xmask, 'xmask')
+        if tuple(xmask.shape[:3]) != (B, H, W) or xmask_coff + plan.C > xmask.shape[3]:
+            raise ValueError('conv: xmask geometry mismatch')
+        mp = xmask.shape[3]
+    if B * H * W * max(xp, yp) >= 2 ** 40:
+        raise ValueError('conv: tensor too large')
+    rc = nat.lib().sqd_conv_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(xmask),
+                                B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff,
+                                int(relu), int(accumulate), mp, xmask_coff, plan.cfg_id, nat.stream_handle(x.device))
+    nat.check(rc, 'sqd_conv_fwd')
+    return y
+
+
+def stem_out_size(h, w, ksize):
+    pad = 1 if ksize == 3 else 3
+    return (h + 2 * pad - ksize) // 2 + 1, (w + 2 * pad - ksize) // 2 + 1
+
+
+def stem_conv_relu(image, weight, bias, out=None):
+    """image NCHW [B,3,H,W]; weight OIHW [N,3,k,k] (the checkpoint tensor as is); -> NHWC [B,Ho,Wo,N]."""
+    if image.dim() != 4 or image.shape[1] != 3 or image.dtype != torch.float32 or not image.is_cuda:
+        raise ValueError(f'stem: image must be fp32 CUDA NCHW with 3 channels, got {tuple(image.shape)}')
+    image = image.contiguous()
+    N, ci, k, k2 = weight.shape
+    if ci != 3 or k != k2 or (k, N) not in ((3, 64), (7, 96)):
+        raise ValueError(f'stem: unsupported weight {tuple(weight.shape)}')
+    B, _, H, W = image.shape
+    Ho, Wo = stem_out_size(H, W, k)
+    if out is None:
+        out = torch.empty(B, Ho, Wo, N, device=image.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, Ho, Wo, N):
+        raise ValueError('stem: bad out shape')
+    w = weight.detach().contiguous()
+    b = None if bias is None else bias.detach().contiguous()
+    rc = nat.lib().sqd_stem_conv_relu_fwd(nat.ptr(image), nat.ptr(w), nat.ptr(b), nat.ptr(out), B, H, W, N, k,
+                                          nat.stream_handle(image.device))
+    nat.check(rc, 'sqd_stem_conv_relu_fwd')
+    return out
+
+
+def pool_out_size(h, w):
+    return (h - 3 + 1) // 2 + 1, (w - 3 + 1) // 2 + 1
+
+
+def maxpool(x, out=None, argmax=None):
+    """MaxPool2d(3, 2, ceil_mode=True) on NHWC; ``argmax`` (uint8, same shape as out) is filled if given."""
+    _check_nhwc(x, 'x')
+    B, H, W, C = x.shape
+    if H < 3 or W < 3 or C % 4:
+        raise ValueError('maxpool: need H,W >= 3 and C % 4 == 0')
+    Ho, Wo = pool_out_size(H, W)
+    if out is None:
+        out = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.float32)
+    if tuple(out.shape) != (B, Ho, Wo, C):
+        raise ValueError('maxpool: bad out shape')
+    if argmax is not None and (tuple(argmax.shape) != (B, Ho, Wo, C) or argmax.dtype != torch.uint8):
+        raise ValueError('maxpool: bad argmax tensor')
+    rc = nat.lib().sqd_maxpool3x3s2_ceil_fwd(nat.ptr(x), nat.ptr(out), nat.ptr(argmax), B, H, W, C, nat.stream_handle(x.device))
+    nat.check(rc, 'sqd_maxpool3x3s2_ceil_fwd')
+    return out
+
+
+def maxpool_bwd(dy, argmax, in_hw, out=None):
+    _check_nhwc(dy, 'dy')
+    B, Ho, Wo, C = dy.shape
+    H, W = in_hw
+    if pool_out_size(H, W) != (Ho, Wo) or tuple(argmax.shape) != (B, Ho, Wo, C) or argmax.dtype != torch.uint8:
+        raise ValueError('maxpool_bwd: geometry mismatch')
+    if out is None:
+        out = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
+    rc = nat.lib().sqd_maxpool3x3s2_ceil_bwd(nat.ptr(dy), nat.ptr(argmax), nat.ptr(out), B, H, W, C, nat.stream_handle(dy.device))
+    nat.check(rc, 'sqd_maxpool3x3s2_ceil_bwd')
+    return out
+
+
+def decode(pred, anchors, input_size, num_classes):
+    """pred [B,A,C+5], anchors [A,4] fp32 -> class_ids int64 [B,A], scores [B,A], boxes [B,A,4]."""
+    if pred.dim() != 3 or pred.shape[2] != num_classes + 5 or pred.dtype != torch.float32 or not pred.is_cuda:
+        raise ValueError(f'decode: bad pred {tuple(pred.shape)}')
+    pred = pred.contiguous()
+    B, A, _ = pred.shape
+    if tuple(anchors.shape) != (A, 4) or anchors.dtype != torch.float32 or anchors.device != pred.device:
+        raise ValueError('decode: anchors must be fp32 [A,4] on the same device')
+    ids = torch.empty(B, A, device=pred.device, dtype=torch.int64)
+    scores = torch.empty(B, A, device=pred.device, dtype=torch.float32)
+    boxes = torch.empty(B, A, 4, device=pred.device, dtype=torch.float32)
+    rc = nat.lib().sqd_decode_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(ids), nat.ptr(scores), nat.ptr(boxes),
+                                  B, A, num_classes, int(input_size[0]), int(input_size[1]), nat.stream_handle(pred.device))
+    nat.check(rc, 'sqd_decode_fwd')
+    return ids, scores, boxes
+
+
+def _det_buffers(B, K, device):
+    return (torch.zeros(B, device=device, dtype=torch.int32), torch.zeros(B, K, device=device, dtype=torch.int64),
+            torch.zeros(B, K, device=device, dtype=torch.float32), torch.zeros(B, K, 4, device=device, dtype=torch.float32),
+            torch.zeros(B, K, device=device, dtype=torch.int32))
+
+
+def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3, scales=None, out=None):
+    """Fused decode + top-k + class-wise NMS + threshold for a batch.
+    Returns (count int32 [B], class_ids int64 [B,K], scores [B,K], boxes [B,K,4], anchor_idx int32 [B,K])."""
+    if pred.dim() != 3 or pred.shape[2] != num_classes + 5 or pred.dtype != torch.float32 or not pred.is_cuda:
+        raise ValueError(f'detect: bad pred {tuple(pred.shape)}')
+    pred = pred.contiguous()
+    B, A, _ = pred.shape
+    if tuple(anchors.shape) != (A, 4) or anchors.dtype != torch.float32 or anchors.device != pred.device:
+        raise ValueError('detect: anchors must be fp32 [A,4] on the same device')
+    if scales is not None and (tuple(scales.shape) != (B, 2) or scales.dtype != torch.float32 or scales.device != pred.device):
+        raise ValueError('detect: scales must be fp32 [B,2] (sy, sx)')
+    bufs = out if out is not None else _det_buffers(B, keep_top_k, pred.device)
+    cnt, cls, sc, bx, idx = bufs
+    rc = nat.lib().sqd_detect_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(cnt), nat.ptr(cls),
+                                  nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes, int(input_size[0]),
+                                  int(input_size[1]), int(keep_top_k), float(nms_thresh), float(score_thresh),
+                                  nat.stream_handle(pred.device))
+    nat.check(rc, 'sqd_detect_fwd')
+    return bufs
+
+
+def filter_dense(class_ids, scores, boxes, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3):
+    """``Detector.filter`` on already decoded dense tensors ([B,A] / [B,A,4])."""
+    if scores.dim() != 2 or class_ids.shape != scores.shape or tuple(boxes.shape) != tuple(scores.shape) + (4,):
+        raise ValueError('filter: shape mismatch')
+    if class_ids.dtype != torch.int64 or scores.dtype != torch.float32 or boxes.dtype != torch.float32 or not scores.is_cuda:
+        raise ValueError('filter: dtype/device mismatch')
+    B, A = scores.shape
+    bufs = _det_buffers(B, keep_top_k, scores.device)
+    cnt, cls, sc, bx, idx = bufs
+    rc = nat.lib().sqd_filter_fwd(nat.ptr(class_ids.contiguous()), nat.ptr(scores.contiguous()), nat.ptr(boxes.contiguous()),
+                                  nat.ptr(cnt), nat.ptr(cls), nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes,
+                                  int(keep_top_k), float(nms_thresh), float(score_thresh), nat.stream_handle(scores.device))
+    nat.check(rc, 'sqd_filter_fwd')
+    return bufs

@@ -1,0 +1,119 @@
+"""GPU tier, kernel level: each HIP kernel against a plain fp32 CPU reference of the same op
+(torch.nn.functional on CPU = the arithmetic the reference delegates to), through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _ops():
+    from squeezedet_pytorch_amd import ops
+    return ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def _tol(ref):
+    # fp32 summation-order noise scales with the magnitude of the sums
+    return TOL * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("taps,C,N,B,H,W", [
+    (1, 64, 16, 2, 12, 20), (1, 128, 32, 1, 9, 13), (1, 256, 48, 2, 7, 11), (1, 512, 64, 1, 6, 10),
+    (1, 768, 96, 1, 5, 9), (1, 16, 64, 2, 12, 20), (1, 48, 192, 1, 7, 11), (1, 96, 384, 1, 6, 7),
+    (9, 16, 64, 2, 12, 20), (9, 32, 128, 1, 9, 33), (9, 48, 192, 1, 24, 78), (9, 96, 384, 1, 5, 17),
+    (9, 768, 72, 1, 6, 18), (9, 16, 64, 1, 3, 3), (1, 100, 20, 1, 4, 5),
+])
+def test_conv_fwd_all_cfgs(taps, C, N, B, H, W):
+    ops = _ops()
+    k = 3 if taps == 9 else 1
+    x = _rand(B, C, H, W, seed=1)
+    w = _rand(N, C, k, k, seed=2, scale=(2.0 / (C * taps)) ** 0.5)
+    b = _rand(N, seed=3, scale=0.1)
+    ref = _nhwc(F.relu(F.conv2d(x, w, b, padding=k // 2)))
+    xg = _nhwc(x).cuda()
+    cfgs = [cid for cid, (t, kc, px, bn) in ops.cfg_table().items() if t == taps]
+    assert cfgs
+    for cid in cfgs:
+        plan = ops.ConvPlan(w.cuda(), b.cuda(), cid)
+        y = torch.full((B, H, W, N), float('nan'), device='cuda')
+        ops.conv(xg, 0, plan, y, 0, relu=True)
+        err = (y.cpu() - ref).abs().max().item()
+        assert err <= _tol(ref), f'cfg {cid}: max err {err}'
+    # automatic choice is one of them
+    assert ops.choose_cfg(taps, C, N, B * H * W) in cfgs
+
+
+def test_conv_channel_windows_accumulate_mask():
+    ops = _ops()
+    B, H, W = 2, 10, 19
+    C, N = 32, 64
+    xfull = _rand(B, 48, H, W, seed=4)                 # read channels [8, 40)
+    w = _rand(N, C, 3, 3, seed=5, scale=0.1)
+    mask_src = _rand(B, 48, H, W, seed=6)
+    x = xfull[:, 8:40]
+    xm = x * (mask_src[:, 8:40] > 0)
+    ref = F.conv2d(xm, w, None, padding=1)
+    y0 = _rand(B, 96, H, W, seed=7)                    # write channels [16, 80) of a 96-wide buffer, accumulate
+    exp = y0.clone()
+    exp[:, 16:80] += ref
+    plan = ops.ConvPlan(w.cuda(), None, ops.choose_cfg(9, C, N, B * H * W))
+    y = _nhwc(y0).cuda()
+    ops.conv(_nhwc(xfull).cuda(), 8, plan, y, 16, relu=False, accumulate=True, xmask=_nhwc(mask_src).cuda(), xmask_coff=8)
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert (got - exp).abs().max().item() <= _tol(exp)
+    # untouched channels are bit-identical
+    assert torch.equal(got[:, :16], y0[:, :16]) and torch.equal(got[:, 80:], y0[:, 80:])
+
+
+def test_conv_dgrad_weights_equal_autograd():
+    ops = _ops()
+    B, C, N, H, W = 1, 16, 64, 9, 21
+    x = _rand(B, C, H, W, seed=8).requires_grad_(True)
+    w = _rand(N, C, 3, 3, seed=9, scale=0.1)
+    y = F.conv2d(x, w, None, padding=1)
+    dy = _rand(B, N, H, W, seed=10)
+    y.backward(dy)
+    plan = ops.ConvPlan(ops.dgrad_weight(w.cuda()), None, ops.choose_cfg(9, N, C, B * H * W))
+    dx = torch.empty(B, H, W, C, device='cuda')
+    ops.conv(_nhwc(dy).cuda(), 0, plan, dx, 0)
+    ref = _nhwc(x.grad)
+    assert (dx.cpu() - ref).abs().max().item() <= _tol(ref)
+
+
+@pytest.mark.parametrize("k,N,H,W", [(3, 64, 64, 96), (3, 64, 33, 47), (7, 96, 64, 96), (7, 96, 30, 50)])
+def test_stem(k, N, H, W):
+    ops = _ops()
+    x = _rand(2, 3, H, W, seed=11)
+    w = _rand(N, 3, k, k, seed=12, scale=(2.0 / (3 * k * k)) ** 0.5)
+    b = _rand(N, seed=13, scale=0.1)
+    ref = _nhwc(F.relu(F.conv2d(x, w, b, stride=2, padding=1 if k == 3 else 3)))
+    y = ops.stem_conv_relu(x.cuda(), w.cuda(), b.cuda())
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert (y.cpu() - ref).abs().max().item() <= _tol(ref)
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 32, 48), (128, 17, 23), (256, 12, 39), (64, 3, 3), (8, 4, 4)])
+def test_maxpool_fwd_bwd(C, H, W):
+    ops = _ops()
+    x = _rand(2, C, H, W, seed=14).requires_grad_(True)
+    ref = F.max_pool2d(x, 3, 2, ceil_mode=True)
+    dy = _rand(*ref.shape, seed=15)
+    ref.backward(dy)
+    xg = _nhwc(x.detach()).cuda()
+    am = torch.empty(*_nhwc(ref.detach()).shape, dtype=torch.uint8, device='cuda')
+    y = ops.maxpool(xg, argmax=am)
+    assert torch.equal(y.cpu(), _nhwc(ref.detach()))            # max is exact
+    dx = ops.maxpool_bwd(_nhwc(dy).cuda(), am, (H, W))
+    assert (dx.cpu() - _nhwc(x.grad)).abs().max().item() <= 1e-6
