@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Benchmark of the SqueezeDet hot path on MI355X (contract: see the task brief / DESIGN.md).
+
+A *step* is one pass of the inference hot path over one batch of 20 synthetic 1248x384 images that
+are already resident in HBM: stem -> pools -> 10 Fire modules -> ConvDet (HIP kernels) -> fused
+decode / top-64 / class-wise NMS / threshold kernel.  ``value`` = images/sec over all ranks.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--no-cpu-baseline]
+
+For N > 1 launch with ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``:
+one process per GPU, batches sharded by rank, no data-path collective for inference (replicas), an
+RCCL gradient all-reduce per step for training.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (spec)
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FWD_GFLOP_PER_IMAGE = 10.566       # SURVEY.md section 8d / BASELINE.md section 3 (2*MAC, convs only)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=20, help='images per GPU per step')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
+    ap.add_argument('--arch', default='squeezedet')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='(unused: the timed region is eager so kernels can be bracketed)')
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, batch, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference, kind='port') timed on the host cores on a
+    bounded sample of the same workload: whole inference path for `batch` images."""
+    import oracle
+    from squeezedet_pytorch_amd import synthetic
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    x = synthetic.make_images(batch, cfg.input_size, seed=0)
+
+    def one():
+        with torch.no_grad():
+            pred = oracle.backbone_forward(x, sd, cfg.arch)
+            ids, sc, bx = oracle.inference_head(pred, cfg.anchors, cfg.input_size, cfg.num_classes)
+        for b in range(batch):
+            oracle.filter_detections(ids[b].numpy(), sc[b].numpy(), bx[b].numpy(), cfg.keep_top_k, cfg.nms_thresh,
+                                     cfg.score_thresh, cfg.num_classes)
+    t0 = time.time(); one(); warm = time.time() - t0
+    n, t_acc = 0, 0.0
+    while n < 3 or (t_acc + warm < seconds_budget and n < 10):
+        t0 = time.time(); one(); t_acc += time.time() - t0; n += 1
+        if t_acc + warm > seconds_budget:
+            break
+    return {'value': round(batch * n / t_acc, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} timed passes (1 warm-up) of the oracle CPU path (torch CPU fp32 backbone + numpy decode/top-k/NMS) '
+                      f'on the same bs={batch} 1248x384 synthetic batch, {threads} threads of {cores} host CPUs'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd import ops, synthetic
+    from squeezedet_pytorch_amd.detector import Detector
+    from squeezedet_pytorch_amd.model import SqueezeDet
+
+    cfg = sqd.make_cfg(arch=args.arch, device=dev)
+    sd = synthetic.make_state_dict(args.arch, seed=1234)
+    B = args.batch
+    x = synthetic.make_images(B, cfg.input_size, seed=rank).to(dev)
+
+    if args.mode == 'train':
+        from squeezedet_pytorch_amd.trainer import make_train_step
+        step, describe = make_train_step(cfg, sd, x, rank, world, dist)
+    else:
+        model = SqueezeDet(cfg)
+        model.load_state_dict(sd)
+        det = Detector(model, cfg)
+        out_bufs = ops._det_buffers(B, cfg.keep_top_k, dev)
+
+        def step():
+            return det.detect_device(x, out=out_bufs)
+        describe = 'SqueezeDet KITTI 1248x384 bs=20 inference on 1 MI355X (Fire+ConvDet HIP kernels, fused NMS)'
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up; the first warm-up steps also find the dominant kernel ----
+    timer_all = ops.KernelTimer()
+    ops.set_timer(timer_all)
+    nprof = max(2, min(args.warmup, 3))
+    for _ in range(nprof):
+        step()
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    summ = timer_all.summary()
+    dominant = max(summ.items(), key=lambda kv: kv[1]['ms'])[0] if summ else None
+    for _ in range(max(0, args.warmup - 3)):
+        step()
+
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
+    timer = ops.KernelTimer(select={dominant}) if dominant else None
+    ops.set_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        value = total_images / elapsed
+        roof = None
+        if timer is not None:
+            d = timer.summary()[dominant]
+            avg_s = d['ms'] / d['launches'] / 1e3
+            flops_per_launch = d['flops'] / d['launches']
+            bytes_per_launch = d['bytes'] / d['launches']
+            ai = flops_per_launch / max(bytes_per_launch, 1.0)
+            if ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):    # ridge point 19.7 flop/B
+                ach = flops_per_launch / avg_s / 1e12
+                roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None}
+            else:
+                ach = bytes_per_launch / avg_s / 1e9
+                roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
+            roof.update({'kernel': dominant, 'launches_per_step': d['launches'] // args.steps,
+                         'avg_launch_us': round(avg_s * 1e6, 2),
+                         'algorithmic_per_launch': {'gflop': round(flops_per_launch / 1e9, 3), 'mbytes': round(bytes_per_launch / 1e6, 3)},
+                         'share_of_step': round(d['ms'] / 1e3 / elapsed, 3)})
+        whole = {'tflops': round(value * FWD_GFLOP_PER_IMAGE / 1e3, 2),
+                 'frac_of_fp32_mfma_peak': round(value / world * FWD_GFLOP_PER_IMAGE / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)} \
+            if args.arch == 'squeezedet' and args.mode == 'infer' else None
+        kernels = {k: {'ms_per_step': round(v['ms'] / nprof, 4),
+                       'launches_per_step': v['launches'] // nprof,
+                       'tflops': round(v['flops'] / (v['ms'] / 1e3) / 1e12, 2) if v['ms'] > 0 else 0,
+                       'gbs': round(v['bytes'] / (v['ms'] / 1e3) / 1e9, 1) if v['ms'] > 0 else 0}
+                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
+        cpu = None
+        if not args.no_cpu_baseline and args.mode == 'infer':
+            cpu = cpu_baseline(cfg, sd, B)
+        line = {
+            'metric': 'images/sec SqueezeDet 1248x384 bs=20 ' + ('inference' if args.mode == 'infer' else 'training'),
+            'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': describe, 'arch': args.arch, 'images_per_gpu_per_step': B, 'global_batch': B * world,
+                       'input': '3x384x1248 fp32 NCHW, HBM resident', 'weights': 'synthetic Kaiming-scale, seed 1234',
+                       'parallelism': f'replicas x{world}' if args.mode == 'infer' else f'dp{world}'},
+            'roofline': roof, 'cpu_baseline': cpu, 'whole_network': whole, 'kernels_warmup_profile': kernels,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -15,6 +15,54 @@ from . import _native as nat
 _CFG_TABLE = None
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event bracket (bench.py / profiling only).  ``select`` limits the
+    bracketing to kernels whose name is in the set (None = all).  Events are recorded on the stream
+    the kernels are launched on (torch's current stream)."""
+
+    def __init__(self, select=None):
+        self.select = select
+        self.records = []          # (name, tag, flops, bytes, start_event, end_event)
+
+    def wants(self, name):
+        return self.select is None or name in self.select
+
+    def summary(self):
+        """{name: dict(launches, ms, flops, bytes)} -- call after a synchronize."""
+        out = {}
+        for name, tag, fl, by, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, tags={}))
+            ms = e0.elapsed_time(e1)
+            d['launches'] += 1; d['ms'] += ms; d['flops'] += fl; d['bytes'] += by
+            t = d['tags'].setdefault(tag, [0, 0.0]); t[0] += 1; t[1] += ms
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+class _Bracket:
+    __slots__ = ('rec',)
+
+    def __init__(self, name, tag, flops, nbytes):
+        t = _timer
+        self.rec = None
+        if t is not None and t.wants(name):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            self.rec = (name, tag, flops, nbytes, e0, e1)
+            e0.record()
+
+    def done(self):
+        if self.rec is not None:
+            self.rec[5].record()
+            _timer.records.append(self.rec)
+
+
 def cfg_table():
     """{cfg_id: (taps, kc, tile_px, bn)} from the compiled library."""
     global _CFG_TABLE
@@ -100,10 +148,18 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
         mp = xmask.shape[3]
     if B * H * W * max(xp, yp) >= 2 ** 40:
         raise ValueError('conv: tensor too large')
+    br = None
+    if _timer is not None:
+        npix = B * H * W
+        br = _Bracket(f'conv_igemm<{plan.taps},{plan.kc},{cfg_table()[plan.cfg_id][2] // 64},{plan.bn // 16}>',
+                      f'{plan.taps}tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * plan.taps,
+                      4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * plan.taps))
     rc = nat.lib().sqd_conv_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(xmask),
                                 B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff,
                                 int(relu), int(accumulate), mp, xmask_coff, plan.cfg_id, nat.stream_handle(x.device))
     nat.check(rc, 'sqd_conv_fwd')
+    if br is not None:
+        br.done()
     return y
 
 
@@ -128,9 +184,13 @@ def stem_conv_relu(image, weight, bias, out=None):
         raise ValueError('stem: bad out shape')
     w = weight.detach().contiguous()
     b = None if bias is None else bias.detach().contiguous()
+    br = _Bracket(f'stem_conv<{k}>', f'stem {H}x{W}', 2.0 * B * Ho * Wo * N * 3 * k * k,
+                  4.0 * (B * 3 * H * W + B * Ho * Wo * N)) if _timer is not None else None
     rc = nat.lib().sqd_stem_conv_relu_fwd(nat.ptr(image), nat.ptr(w), nat.ptr(b), nat.ptr(out), B, H, W, N, k,
                                           nat.stream_handle(image.device))
     nat.check(rc, 'sqd_stem_conv_relu_fwd')
+    if br is not None:
+        br.done()
     return out
 
 
@@ -151,8 +211,11 @@ def maxpool(x, out=None, argmax=None):
         raise ValueError('maxpool: bad out shape')
     if argmax is not None and (tuple(argmax.shape) != (B, Ho, Wo, C) or argmax.dtype != torch.uint8):
         raise ValueError('maxpool: bad argmax tensor')
+    br = _Bracket('maxpool_fwd', f'pool C{C} {H}x{W}', 0.0, 4.0 * B * C * (H * W + Ho * Wo)) if _timer is not None else None
     rc = nat.lib().sqd_maxpool3x3s2_ceil_fwd(nat.ptr(x), nat.ptr(out), nat.ptr(argmax), B, H, W, C, nat.stream_handle(x.device))
     nat.check(rc, 'sqd_maxpool3x3s2_ceil_fwd')
+    if br is not None:
+        br.done()
     return out
 
 
@@ -205,11 +268,14 @@ def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4
         raise ValueError('detect: scales must be fp32 [B,2] (sy, sx)')
     bufs = out if out is not None else _det_buffers(B, keep_top_k, pred.device)
     cnt, cls, sc, bx, idx = bufs
+    br = _Bracket('detect', f'detect A{A}', 0.0, 4.0 * B * A * (num_classes + 5)) if _timer is not None else None
     rc = nat.lib().sqd_detect_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(cnt), nat.ptr(cls),
                                   nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes, int(input_size[0]),
                                   int(input_size[1]), int(keep_top_k), float(nms_thresh), float(score_thresh),
                                   nat.stream_handle(pred.device))
     nat.check(rc, 'sqd_detect_fwd')
+    if br is not None:
+        br.done()
     return bufs
 
 
