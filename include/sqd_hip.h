@@ -29,9 +29,31 @@ int sqd_conv_cfg_info(int cfg_id, int* taps, int* kc, int* tile_px, int* bn);
  * (src/model/squeezedet.py:12-14,18-22), torch.cat (:19-22, via y_coff), ConvDet (:73-75,:83) and,
  * with transposed+flipped weights, their autograd data-gradients (src/engine/trainer.py:47).
  * w_packed: [ceil(C/kc)][taps][Npad][kc] fp32, zero padded, Npad = ceil(N/bn)*bn (kc, bn from cfg). */
+/* Epilogue order: acc (+bias) (+= y if accumulate) (*= ymul) (zero where ymask <= 0) (ReLU) -> y.
+ * ymask / ymul address the same pixels as y with their own (pitch, coff); they serve the backward pass
+ * (ReLU mask of the layer that produced this gradient's forward activation; dropout mask). */
 int sqd_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y, const float* xmask,
-                 int B, int H, int W, int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff,
-                 int relu, int accumulate, int xmask_pitch, int xmask_coff, int cfg_id, void* stream);
+                 const float* ymask, const float* ymul, int B, int H, int W, int C, int x_pitch, int x_coff,
+                 int N, int Npad, int y_pitch, int y_coff, int relu, int accumulate, int xmask_pitch,
+                 int xmask_coff, int ymask_pitch, int ymask_coff, int ymul_pitch, int ymul_coff, int cfg_id,
+                 void* stream);
+
+/* Canonical OIHW parameter [No][Ci][k][k] -> packed layout of sqd_conv_fwd for the forward conv
+ * (dgrad=0: N=No, C=Ci) or for its data-gradient conv (dgrad=1: N=Ci, C=No, taps flipped). */
+int sqd_pack_conv_weight(const float* w_oihw, float* w_packed, int No, int Ci, int taps, int kc, int Npad,
+                         int dgrad, void* stream);
+
+/* Weight + bias gradient of a 1x1 / 3x3 conv (autograd of nn.Conv2d, src/engine/trainer.py:47).
+ * dy window [dy_coff, dy_coff+N) must already carry its ReLU mask; slab = workspace of
+ * S*(N*taps*C + N) floats (S pixel-splits, summed in fixed order => bitwise reproducible);
+ * dw is OIHW [N][C][k][k], db [N] (may be NULL). */
+int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
+                   int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int taps, int S,
+                   void* stream);
+
+/* Stem weight + bias gradient (the image needs no data gradient).  slab: S*(N*3*k*k + N) floats. */
+int sqd_stem_wgrad(const float* dy_nhwc, const float* img_nchw, float* slab, float* dw_oihw, float* db,
+                   int B, int Hin, int Win, int N, int ksize, int S, void* stream);
 
 /* Stem: Conv2d(3, N, k, stride 2, pad k/2) + ReLU, NCHW image -> NHWC features.
  * (k,N) = (3,64) squeezedet (src/model/squeezedet.py:34-35) or (7,96) squeezedetplus (:52-53).
@@ -43,8 +65,9 @@ int sqd_stem_conv_relu_fwd(const float* x_nchw, const float* w_oihw, const float
  * argmax (uint8, same shape as y, may be NULL) records the window position 0..8 for the backward. */
 int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C,
                               void* stream);
-int sqd_maxpool3x3s2_ceil_bwd(const float* dy, const unsigned char* argmax, float* dx, int B, int H, int W,
-                              int C, void* stream);
+/* relu_src (may be NULL): the pool's forward input when that was a ReLU output; its mask is folded in. */
+int sqd_maxpool3x3s2_ceil_bwd(const float* dy, const unsigned char* argmax, float* dx, const float* relu_src,
+                              int B, int H, int W, int C, void* stream);
 
 /* Dense decode: PredictionResolver.forward + the argmax/max of SqueezeDet.forward
  * (src/model/squeezedet.py:109-120,199-202; src/model/modules.py:17-45,66-68).
@@ -67,6 +90,18 @@ int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales,
 int sqd_filter_fwd(const long long* class_ids, const float* scores, const float* boxes, int* det_count,
                    long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
                    int num_classes, int keep_top_k, float nms_thresh, float score_thresh, void* stream);
+
+/* Multi-task loss (Loss.forward, src/model/squeezedet.py:133-174; compute_overlaps, modules.py:48-63).
+ * pred [B][A][C+5], gt [B][A][C+9] = (mask, x1,y1,x2,y2, dx,dy,dw,dh, onehot[C]), anchors [A][4].
+ * workspace: B*16*5 floats.  losses: [4][B] = (class, score = pos+neg, bbox, total); nobj: [B]. */
+int sqd_loss_fwd(const float* pred, const float* gt, const float* anchors, float* workspace, float* losses,
+                 float* nobj, int B, int A, int num_classes, int input_h, int input_w, float w_class,
+                 float w_pos, float w_neg, float w_bbox, void* stream);
+/* Analytic backward incl. the un-detached IoU path.  coef [3][B]: upstream gradient of (class, score, bbox)
+ * per image (the gradient of `total` already added to each).  dpred [B][A][C+5]. */
+int sqd_loss_bwd(const float* pred, const float* gt, const float* anchors, const float* nobj, const float* coef,
+                 float* dpred, int B, int A, int num_classes, int input_h, int input_w, float w_class,
+                 float w_pos, float w_neg, float w_bbox, void* stream);
 
 #ifdef __cplusplus
 }

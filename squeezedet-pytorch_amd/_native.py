@@ -26,25 +26,21 @@ c_f = ctypes.c_float
 _SIGNATURES = {
     'sqd_conv_num_cfgs': [],
     'sqd_conv_cfg_info': [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
-    'sqd_conv_fwd': [c_p, c_p, c_p, c_p, c_p] + [c_i] * 15 + [c_p],
+    'sqd_conv_fwd': [c_p] * 7 + [c_i] * 19 + [c_p],
+    'sqd_pack_conv_weight': [c_p, c_p] + [c_i] * 6 + [c_p],
+    'sqd_conv_wgrad': [c_p] * 5 + [c_i] * 11 + [c_p],
+    'sqd_stem_wgrad': [c_p] * 5 + [c_i] * 6 + [c_p],
     'sqd_stem_conv_relu_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_fwd': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    'sqd_maxpool3x3s2_ceil_bwd': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    'sqd_maxpool3x3s2_ceil_bwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_decode_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_detect_fwd': [c_p] * 8 + [c_i] * 6 + [c_f, c_f, c_p],
     'sqd_filter_fwd': [c_p] * 8 + [c_i] * 4 + [c_f, c_f, c_p],
+    'sqd_loss_fwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],
+    'sqd_loss_bwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],
 }
 # symbols added by later build stages; bound when present in the library
-_OPTIONAL = {
-    'sqd_loss_fwd_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p],
-    'sqd_conv_wgrad': [c_p, c_p, c_p, c_p, c_p] + [c_i] * 14 + [c_p],
-    'sqd_stem_wgrad': [c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_p],
-    'sqd_pack_conv_weight': [c_p, c_p] + [c_i] * 7 + [c_p],
-    'sqd_bias_grad': [c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
-    'sqd_sgd_clip_step': [c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_p],
-    'sqd_sumsq_partials': [c_p, c_p, c_i, c_p],
-    'sqd_scale_mask': [c_p, c_p, c_p, ctypes.c_longlong, c_p],
-}
+_OPTIONAL = {}
 
 _ERRORS = {1: 'bad argument', 2: 'unsupported configuration', 3: 'kernel launch failed'}
 

@@ -1,0 +1,102 @@
+"""Backward executors: ``BackboneFn`` (one autograd node for stem..ConvDet) and ``LossFn``.
+
+Reference behaviour reproduced: autograd through ``SqueezeDetBase.forward`` (src/model/squeezedet.py:79-87)
+and ``Loss.forward`` (:133-174) as triggered by ``loss.backward()`` in src/engine/trainer.py:47.
+
+Gradient flow convention: every gradient tensor materialised in HBM already carries the ReLU mask of
+the activation it belongs to -- the kernel that *produces* it applies the mask in its epilogue
+(``ymask``), so the (up to four) consumers of that gradient read it once each without the mask tensor.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .autograd import run_backbone_forward
+from .synthetic import layer_table
+
+
+def run_backbone_backward(base, saved, dpred):
+    """dpred: NHWC [B,H,W,anchors_per_grid*(C+5)].  Returns {param_name (relative to base): grad}."""
+    layers = layer_table(base.arch)
+    feats = base.features
+    grads = {}
+    dpred = dpred.contiguous()
+    B, H, W, ncd = dpred.shape
+    cd = base.convdet
+    a_in = saved['convdet_in']
+    cin_cd = a_in.shape[3]
+    npix = B * H * W
+    grads['convdet.weight'], grads['convdet.bias'] = ops.conv_wgrad(dpred, 0, ncd, a_in, 0, cin_cd, 9)
+    last = len(layers) - 1
+    assert layers[last][0] == 'fire'
+    out_last = saved[f'fire{last}'][2]
+    dA = torch.empty_like(out_last)
+    ops.conv(dpred, 0, base.plan('convdet', cd, ops.choose_cfg(9, ncd, cin_cd, npix), 'dgrad'), dA, 0,
+             ymul=saved['drop_mask'], ymask=out_last)
+    for i in range(last, 1, -1):
+        l = layers[i]
+        if l[0] == 'pool':
+            am, (Hi, Wi) = saved[f'pool{i}']
+            prev = layers[i - 1][0]
+            relu_src = saved[f'fire{i - 1}'][2] if prev == 'fire' else saved['stem_out']
+            dA = ops.maxpool_bwd(dA, am, (Hi, Wi), relu_src=relu_src)
+            continue
+        _, cin, s, e1, e3 = l
+        fire = feats[i]
+        x_in, sq, out = saved[f'fire{i}']
+        Bq, Hq, Wq, _ = out.shape
+        npix = Bq * Hq * Wq
+        pre = f'features.{i}.'
+        grads[pre + 'expand1x1.weight'], grads[pre + 'expand1x1.bias'] = ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1)
+        grads[pre + 'expand3x3.weight'], grads[pre + 'expand3x3.bias'] = ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9)
+        dSq = torch.empty_like(sq)
+        ops.conv(dA, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, e1, s, npix), 'dgrad'), dSq, 0)
+        ops.conv(dA, e1, base.plan(f'{i}.expand3x3', fire.expand3x3, ops.choose_cfg(9, e3, s, npix), 'dgrad'), dSq, 0,
+                 accumulate=True, ymask=sq)
+        grads[pre + 'squeeze.weight'], grads[pre + 'squeeze.bias'] = ops.conv_wgrad(dSq, 0, s, x_in, 0, cin, 1)
+        dIn = torch.empty_like(x_in)
+        prev_is_fire = layers[i - 1][0] == 'fire'
+        ops.conv(dSq, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, s, cin, npix), 'dgrad'), dIn, 0,
+                 ymask=x_in if prev_is_fire else None)
+        dA = dIn
+    stem = feats[0]
+    grads['features.0.weight'], grads['features.0.bias'] = ops.stem_wgrad(dA, saved['image'].contiguous(), stem.out_channels,
+                                                                           stem.kernel_size[0])
+    return grads
+
+
+class BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, base, image, drop_mask, *params):
+        pred, saved = run_backbone_forward(base, image.detach(), save=True, drop_mask=drop_mask)
+        ctx.base = base
+        ctx.saved = saved
+        ctx.names = [n for n, _ in base.named_parameters()]
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        grads = run_backbone_backward(ctx.base, ctx.saved, dpred)
+        ctx.saved = None
+        return (None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+class LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, anchors, loss_mod):
+        res = loss_mod.resolver
+        weights = (loss_mod.class_loss_weight, loss_mod.positive_score_loss_weight,
+                   loss_mod.negative_score_loss_weight, loss_mod.bbox_loss_weight)
+        losses, nobj = ops.loss_fwd(pred.detach(), gt, anchors, res.input_size, res.num_classes, weights)
+        ctx.save_for_backward(pred.detach(), gt, anchors, nobj)
+        ctx.meta = (res.input_size, res.num_classes, weights)
+        return losses                      # [4,B] = (class, score, bbox, total)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, anchors, nobj = ctx.saved_tensors
+        input_size, num_classes, weights = ctx.meta
+        coef = (g[:3] + g[3:4]).contiguous()       # gradient of `total` reaches all three components
+        dpred = ops.loss_bwd(pred, gt, anchors, nobj, coef, input_size, num_classes, weights)
+        return dpred, None, None, None

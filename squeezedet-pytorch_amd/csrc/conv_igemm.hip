@@ -35,6 +35,8 @@ struct ConvArgs {
   int relu, accumulate;
   int tiles_x, tiles_y;
   int xmask_pitch, xmask_coff;
+  const float* ymask; const float* ymul;      // epilogue: zero where ymask <= 0 (ReLU backward), multiply by ymul (dropout)
+  int ymask_pitch, ymask_coff, ymul_pitch, ymul_coff;
   long long total_px;
 };
 
@@ -158,6 +160,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       if (a.bias) v += *(const f32x4*)(a.bias + n);
       float* dst = a.y + gp * a.y_pitch + a.y_coff + n;
       if (a.accumulate) v += *(const f32x4*)dst;
+      if (a.ymul) v *= *(const f32x4*)(a.ymul + gp * a.ymul_pitch + a.ymul_coff + n);
+      if (a.ymask) {
+        const f32x4 m = *(const f32x4*)(a.ymask + gp * a.ymask_pitch + a.ymask_coff + n);
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+      }
       if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       *(f32x4*)dst = v;
     }
@@ -211,6 +218,7 @@ static const ConvCfg kConvCfgs[] = {
     {9, 16, 2, 6},  // 15 3x3, 8x16 px x 96 ch
     {9, 16, 1, 6},  // 16 3x3, 4x16 px x 96 ch
     {9, 16, 2, 3},  // 17 3x3, 8x16 px x 48 ch
+    {9, 16, 2, 1},  // 18 3x3, 8x16 px x 16 ch (dgrad into a 16-channel squeeze)
 };
 static const int kNumConvCfgs = (int)(sizeof(kConvCfgs) / sizeof(kConvCfgs[0]));
 
@@ -227,9 +235,10 @@ extern "C" int sqd_conv_cfg_info(int cfg_id, int* taps, int* kc, int* tile_px, i
 }
 
 extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
-                            const float* xmask, int B, int H, int W, int C, int x_pitch, int x_coff,
-                            int N, int Npad, int y_pitch, int y_coff, int relu, int accumulate,
-                            int xmask_pitch, int xmask_coff, int cfg_id, void* stream) {
+                            const float* xmask, const float* ymask, const float* ymul, int B, int H, int W, int C,
+                            int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
+                            int accumulate, int xmask_pitch, int xmask_coff, int ymask_pitch, int ymask_coff,
+                            int ymul_pitch, int ymul_coff, int cfg_id, void* stream) {
   SQD_CHECK_ARG(x && w_packed && y);
   SQD_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && N > 0);
   SQD_CHECK_ARG(cfg_id >= 0 && cfg_id < kNumConvCfgs);
@@ -239,7 +248,10 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   SQD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)w_packed & 15) == 0);
   SQD_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0);
   if (xmask) SQD_CHECK_ARG((xmask_pitch & 3) == 0 && (xmask_coff & 3) == 0 && xmask_coff + C <= xmask_pitch && ((uintptr_t)xmask & 15) == 0);
+  if (ymask) SQD_CHECK_ARG((ymask_pitch & 3) == 0 && (ymask_coff & 3) == 0 && ymask_coff + N <= ymask_pitch && ((uintptr_t)ymask & 15) == 0);
+  if (ymul) SQD_CHECK_ARG((ymul_pitch & 3) == 0 && (ymul_coff & 3) == 0 && ymul_coff + N <= ymul_pitch && ((uintptr_t)ymul & 15) == 0);
   ConvArgs a;
+  a.ymask = ymask; a.ymul = ymul; a.ymask_pitch = ymask_pitch; a.ymask_coff = ymask_coff; a.ymul_pitch = ymul_pitch; a.ymul_coff = ymul_coff;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.xmask = xmask;
   a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff;
@@ -268,6 +280,7 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   SQD_CONV_CASE(9, 16, 2, 6)
   SQD_CONV_CASE(9, 16, 1, 6)
   SQD_CONV_CASE(9, 16, 2, 3)
+  SQD_CONV_CASE(9, 16, 2, 1)
 #undef SQD_CONV_CASE
   return SQD_ERR_UNSUPPORTED;
 }

@@ -190,8 +190,8 @@ extern "C" int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char
 // Backward: dx[b,iy,ix,c] = sum over the (at most 4) windows covering (iy,ix) whose argmax is this
 // element.  Gather form (one thread per input element, no atomics, deterministic).
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ amax,
-                                                          float* __restrict__ dx, int B, int H, int W, int C,
-                                                          int Ho, int Wo) {
+                                                          float* __restrict__ dx, const float* __restrict__ relu_src,
+                                                          int B, int H, int W, int C, int Ho, int Wo) {
   const int cv = C >> 2;
   const long long total = (long long)B * H * W * cv;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -214,16 +214,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         if ((int)((am >> 16) & 255) == t) acc.z += g.z;
         if ((int)(am >> 24) == t) acc.w += g.w;
       }
-    *(f32x4*)(dx + (((long long)b * H + iy) * W + ix) * C + 4 * c4) = acc;
+    const long long xo = (((long long)b * H + iy) * W + ix) * C + 4 * c4;
+    if (relu_src) {      // the pooled tensor was a ReLU output: fold its backward mask into this store
+      const f32x4 m = *(const f32x4*)(relu_src + xo);
+      acc.x = m.x > 0.f ? acc.x : 0.f; acc.y = m.y > 0.f ? acc.y : 0.f; acc.z = m.z > 0.f ? acc.z : 0.f; acc.w = m.w > 0.f ? acc.w : 0.f;
+    }
+    *(f32x4*)(dx + xo) = acc;
   }
 }
 
-extern "C" int sqd_maxpool3x3s2_ceil_bwd(const float* dy, const unsigned char* argmax, float* dx, int B, int H,
-                                         int W, int C, void* stream) {
+extern "C" int sqd_maxpool3x3s2_ceil_bwd(const float* dy, const unsigned char* argmax, float* dx, const float* relu_src,
+                                         int B, int H, int W, int C, void* stream) {
   SQD_CHECK_ARG(dy && argmax && dx && B > 0 && H >= 3 && W >= 3 && C > 0 && (C & 3) == 0);
   const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
   const long long total = (long long)B * H * W * (C >> 2);
   const int blocks = (int)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, B, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, relu_src, B, H, W, C, Ho, Wo);
   return sqd_launch_status();
 }

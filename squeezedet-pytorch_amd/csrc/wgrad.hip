@@ -1,0 +1,418 @@
+// Weight / bias gradients of the convolutions (the reference gets them from autograd through
+// nn.Conv2d, src/engine/trainer.py:47), the deterministic slab reduction, and the weight packer.
+//
+// dW[n][c][tap] = sum over pixels p of dY[p][n] * X[p + offset(tap)][c]      (dY already ReLU-masked)
+// db[n]         = sum over pixels p of dY[p][n]
+//
+// This is a GEMM whose reduction axis is the pixel axis (B*H*W up to 599,040), so it is split over
+// workgroups: each workgroup owns an output tile (TN*16 out-channels x TC*16 in-channels x all taps),
+// walks a strided subset of the pixel blocks accumulating in MFMA registers, and writes ONE partial
+// slab; a second kernel sums the slabs in fixed order (bitwise reproducible -- no float atomics)
+// and emits the gradient in the checkpoint's OIHW layout.  MFMA operand A = dY^T (row = out-channel,
+// k = pixel), operand B = X (k = pixel, column = in-channel); both are read from pixel-major LDS
+// tiles whose pitch is = 16 (mod 32) floats so the two k-groups of a 32-lane half hit disjoint banks.
+// The bias gradient rides along as extra tiles with B = 1.
+#include "sqd_common.h"
+
+struct WgradArgs {
+  const float* dy; const float* x; float* slab;
+  int B, H, W;
+  int N, dy_pitch, dy_coff;
+  int C, x_pitch, x_coff;
+  int tiles_x, tiles_y, nblocks, n_groups;
+  long long total_px;
+  long long slab_stride;
+};
+
+template <int TAPS, int TN, int TC, int TH>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int PB = TH * 16;                                 // pixels per block
+  constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16);           // dY tile pitch  (= 16 mod 32)
+  constexpr int PC = TC * 16 + ((TC & 1) ? 0 : 16);           // X tile pitch   (= 16 mod 32)
+  constexpr int XPIX = (TAPS == 9) ? (TH + 2) * 18 : PB;
+  constexpr int TILES = TN * TC * TAPS;
+  constexpr int NACC = (TILES + 3) / 4;
+  constexpr int BACC = (TN + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dyT = smem;                 // [PB][PN]
+  float* xT = smem + PB * PN;        // [XPIX][PC]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int ng = blockIdx.y % a.n_groups, cg = blockIdx.y / a.n_groups;
+  const int n0 = ng * TN * 16, c0 = cg * TC * 16;
+  const bool do_bias = (cg == 0);
+
+  f32x4 acc[NACC], bacc[BACC];
+  int aoff[NACC], boff[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int t = wave + 4 * i;
+    if (t >= TILES) t = TILES - 1;                             // harmless duplicate, never stored
+    const int ct = t % TC, tap = (t / TC) % TAPS, nt = t / (TC * TAPS);
+    aoff[i] = nt * 16 + lr;
+    boff[i] = ((TAPS == 9) ? ((tap / 3) * 18 + tap % 3) : 0) * PC + ct * 16 + lr;
+  }
+#pragma unroll
+  for (int i = 0; i < BACC; ++i) bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bool first = true;
+  for (int pb = blockIdx.x; pb < a.nblocks; pb += gridDim.x) {
+    int b = 0, y0 = 0, x0 = 0;
+    long long p0 = 0;
+    if (TAPS == 9) {
+      int t = pb;
+      const int tx = t % a.tiles_x; t /= a.tiles_x;
+      const int ty = t % a.tiles_y; b = t / a.tiles_y;
+      y0 = ty * TH; x0 = tx * 16;
+    } else {
+      p0 = (long long)pb * PB;
+    }
+    if (!first) __syncthreads();
+    first = false;
+    // stage dY tile (zero outside the image / beyond N)
+    for (int idx = tid; idx < PB * TN * 4; idx += 256) {
+      const int pix = idx / (TN * 4), v = idx - pix * (TN * 4);
+      const int n = n0 + 4 * v;
+      long long gp; bool ok = n < a.N;
+      if (TAPS == 9) {
+        const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
+        ok = ok && iy < a.H && ix < a.W;
+        gp = ((long long)b * a.H + iy) * a.W + ix;
+      } else {
+        gp = p0 + pix; ok = ok && gp < a.total_px;
+      }
+      f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ok) val = *(const f32x4*)(a.dy + gp * a.dy_pitch + a.dy_coff + n);
+      *(f32x4*)(dyT + pix * PN + 4 * v) = val;
+    }
+    // stage X tile (3x3: with a 1-pixel halo)
+    for (int idx = tid; idx < XPIX * TC * 4; idx += 256) {
+      const int pix = idx / (TC * 4), v = idx - pix * (TC * 4);
+      const int c = c0 + 4 * v;
+      long long gp; bool ok = c < a.C;
+      if (TAPS == 9) {
+        const int r = pix / 18, col = pix - r * 18;
+        const int iy = y0 + r - 1, ix = x0 + col - 1;
+        ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        gp = ((long long)b * a.H + iy) * a.W + ix;
+      } else {
+        gp = p0 + pix; ok = ok && gp < a.total_px;
+      }
+      f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ok) val = *(const f32x4*)(a.x + gp * a.x_pitch + a.x_coff + c);
+      *(f32x4*)(xT + pix * PC + 4 * v) = val;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < TH * 4; ++s) {
+      const int r = s >> 2, cq = s & 3;
+      const int pixA = r * 16 + cq * 4 + kq;
+      const int pixB = (TAPS == 9) ? r * 18 + cq * 4 + kq : pixA;
+      const float* ap = dyT + pixA * PN;
+      const float* bp = xT + pixB * PC;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = mfma16(ap[aoff[i]], bp[boff[i]], acc[i]);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < BACC; ++i) {
+          const int bt = (wave + 4 * i < TN) ? wave + 4 * i : 0;
+          bacc[i] = mfma16(ap[bt * 16 + lr], 1.0f, bacc[i]);
+        }
+      }
+    }
+  }
+
+  // one slab per blockIdx.x; layout [n][tap][c] then [N] bias sums
+  float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int t = wave + 4 * i;
+    if (t >= TILES) continue;
+    const int ct = t % TC, tap = (t / TC) % TAPS, nt = t / (TC * TAPS);
+    const int c = c0 + ct * 16 + lr;
+    if (c >= a.C) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + nt * 16 + 4 * kq + r;
+      if (n < a.N) slab[((long long)n * TAPS + tap) * a.C + c] = acc[i][r];
+    }
+  }
+  if (do_bias && lr == 0) {
+#pragma unroll
+    for (int i = 0; i < BACC; ++i) {
+      const int bt = wave + 4 * i;
+      if (bt >= TN) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + bt * 16 + 4 * kq + r;
+        if (n < a.N) slab[(long long)a.N * TAPS * a.C + n] = bacc[i][r];
+      }
+    }
+  }
+}
+
+// dw (OIHW: [N][C][TAPS]) and db ([N]) = fixed-order sum of S slabs
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           float* __restrict__ db, int S, long long slab_stride,
+                                                           int N, int C, int TAPS) {
+  const long long nw = (long long)N * TAPS * C;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nw + N) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += slab[(long long)k * slab_stride + idx];
+  if (idx < nw) {
+    const int c = (int)(idx % C); const long long t = idx / C;
+    const int tap = (int)(t % TAPS); const int n = (int)(t / TAPS);
+    dw[((long long)n * C + c) * TAPS + tap] = s;
+  } else if (db) {
+    db[idx - nw] = s;
+  }
+}
+
+template <int TAPS, int TN, int TC, int TH>
+static int launch_wgrad(WgradArgs a, int S, hipStream_t stream) {
+  constexpr int PB = TH * 16;
+  constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16), PC = TC * 16 + ((TC & 1) ? 0 : 16);
+  constexpr int XPIX = (TAPS == 9) ? (TH + 2) * 18 : PB;
+  constexpr size_t lds = (size_t)(PB * PN + XPIX * PC) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "wgrad LDS budget");
+  if (TAPS == 9) {
+    a.tiles_x = sqd_cdiv(a.W, 16); a.tiles_y = sqd_cdiv(a.H, TH);
+    a.nblocks = a.B * a.tiles_x * a.tiles_y;
+  } else {
+    a.tiles_x = a.tiles_y = 0;
+    a.nblocks = (int)((a.total_px + PB - 1) / PB);
+  }
+  a.n_groups = sqd_cdiv(a.N, TN * 16);
+  const int c_groups = sqd_cdiv(a.C, TC * 16);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, TN, TC, TH>), dim3((unsigned)S, (unsigned)(a.n_groups * c_groups)), dim3(256), lds,
+                     stream, a);
+  return sqd_launch_status();
+}
+
+// dy: [B][H][W][dy_pitch] window [dy_coff, dy_coff+N) (ReLU mask already applied); x: input window
+// [x_coff, x_coff+C); slab: workspace of S * (N*taps*C + N) floats; dw: [N][C][k][k]; db: [N] or NULL.
+extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
+                              int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int taps, int S,
+                              void* stream) {
+  SQD_CHECK_ARG(dy && x && slab && dw && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535);
+  SQD_CHECK_ARG((N & 3) == 0 && (C & 3) == 0 && (dy_pitch & 3) == 0 && (dy_coff & 3) == 0 && (x_pitch & 3) == 0 && (x_coff & 3) == 0);
+  SQD_CHECK_ARG(dy_coff + N <= dy_pitch && x_coff + C <= x_pitch);
+  SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0);
+  SQD_CHECK_ARG(taps == 1 || taps == 9);
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.slab = slab; a.B = B; a.H = H; a.W = W;
+  a.N = N; a.dy_pitch = dy_pitch; a.dy_coff = dy_coff; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.total_px = (long long)B * H * W;
+  a.slab_stride = (long long)N * taps * C + N;
+  hipStream_t s = (hipStream_t)stream;
+  const int tn = N >= 64 ? 4 : sqd_cdiv(N, 16);
+  const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
+  int rc = SQD_ERR_UNSUPPORTED;
+  if (taps == 9) {
+    if (N > 64 && N <= 80) rc = launch_wgrad<9, 5, 1, 8>(a, S, s);      // ConvDet (N = 72)
+    else rc = launch_wgrad<9, 4, 1, 8>(a, S, s);
+  } else {
+#define SQD_WG_CASE(TNv, TCv) if (tn == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, 4>(a, S, s);
+    SQD_WG_CASE(1, 1) SQD_WG_CASE(1, 2) SQD_WG_CASE(1, 3) SQD_WG_CASE(1, 4)
+    SQD_WG_CASE(2, 1) SQD_WG_CASE(2, 2) SQD_WG_CASE(2, 3) SQD_WG_CASE(2, 4)
+    SQD_WG_CASE(3, 1) SQD_WG_CASE(3, 2) SQD_WG_CASE(3, 3) SQD_WG_CASE(3, 4)
+    SQD_WG_CASE(4, 1) SQD_WG_CASE(4, 2) SQD_WG_CASE(4, 3) SQD_WG_CASE(4, 4)
+#undef SQD_WG_CASE
+  }
+  if (rc != SQD_OK) return rc;
+  const long long outs = a.slab_stride;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, s, slab, dw, db, S, a.slab_stride,
+                     N, C, taps);
+  return sqd_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem weight gradient: dW0[n][ci][ky][kx] = sum_p dY[p][n] * img[ci][2*py+ky-pad][2*px+kx-pad]
+// (no data gradient: the image needs none).  Same split-K slab scheme; slab layout [n][K] + [N].
+// ---------------------------------------------------------------------------------------------
+struct StemWgradArgs {
+  const float* dy; const float* img; float* slab;
+  int B, Hin, Win, Ho, Wo, N;
+  int tiles_x, tiles_y, nblocks;
+  long long slab_stride;
+};
+
+template <int KS, int PAD, int TN>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
+  constexpr int TH = 8;
+  constexpr int K = 3 * KS * KS, KT = (K + 15) / 16;          // k-tiles of 16 im2col columns
+  constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16);
+  constexpr int IH = 2 * (TH - 1) + KS, IW = 2 * 15 + KS, IWP = IW | 1;
+  constexpr int NIN = 3 * IH * IWP;
+  constexpr int TILES = TN * KT, NACC = (TILES + 3) / 4, BACC = (TN + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dyT = smem;                   // [128][PN]
+  float* inT = smem + 128 * PN;        // [3][IH][IWP] + zero slot
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, kq = lane >> 4;
+
+  f32x4 acc[NACC], bacc[BACC];
+  int aoff[NACC], boff[NACC];
+  bool bok[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int t = wave + 4 * i;
+    if (t >= TILES) t = TILES - 1;
+    const int kt = t % KT, nt = t / KT;
+    const int k = kt * 16 + lr;                                 // this lane's im2col column
+    const int ci = k / (KS * KS), rem = k - ci * (KS * KS), ky = rem / KS, kx = rem - ky * KS;
+    aoff[i] = nt * 16 + lr;
+    bok[i] = k < K;
+    boff[i] = bok[i] ? (ci * IH + ky) * IWP + kx : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < BACC; ++i) bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bool first = true;
+  for (int pb = blockIdx.x; pb < a.nblocks; pb += gridDim.x) {
+    int t = pb;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16;
+    if (!first) __syncthreads();
+    first = false;
+    for (int idx = tid; idx < 128 * TN * 4; idx += 256) {
+      const int pix = idx / (TN * 4), v = idx - pix * (TN * 4);
+      const int oy = y0 + (pix >> 4), ox = x0 + (pix & 15), n = 4 * v;
+      f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (oy < a.Ho && ox < a.Wo && n < a.N) val = *(const f32x4*)(a.dy + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.N + n);
+      *(f32x4*)(dyT + pix * PN + 4 * v) = val;
+    }
+    for (int idx = tid; idx < 3 * IH * IW; idx += 256) {
+      const int c = idx % IW; int r = idx / IW; const int ci = r / IH; r -= ci * IH;
+      const int iy = 2 * y0 - PAD + r, ix = 2 * x0 - PAD + c;
+      float v = 0.f;
+      if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) v = a.img[(((long long)b * 3 + ci) * a.Hin + iy) * a.Win + ix];
+      inT[(ci * IH + r) * IWP + c] = v;
+    }
+    if (tid == 0) inT[NIN] = 0.f;
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < TH * 4; ++s) {
+      const int r = s >> 2, cq = s & 3;
+      const int col = cq * 4 + kq;
+      const float* ap = dyT + (r * 16 + col) * PN;
+      const int pbase = (2 * r) * IWP + 2 * col;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = mfma16(ap[aoff[i]], inT[bok[i] ? pbase + boff[i] : NIN], acc[i]);
+#pragma unroll
+      for (int i = 0; i < BACC; ++i) {
+        const int bt = (wave + 4 * i < TN) ? wave + 4 * i : 0;
+        bacc[i] = mfma16(ap[bt * 16 + lr], 1.0f, bacc[i]);
+      }
+    }
+  }
+  float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int t = wave + 4 * i;
+    if (t >= TILES) continue;
+    const int kt = t % KT, nt = t / KT;
+    const int k = kt * 16 + lr;
+    if (k >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nt * 16 + 4 * kq + r;
+      if (n < a.N) slab[(long long)n * K + k] = acc[i][r];
+    }
+  }
+  if (lr == 0) {
+#pragma unroll
+    for (int i = 0; i < BACC; ++i) {
+      const int bt = wave + 4 * i;
+      if (bt >= TN) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = bt * 16 + 4 * kq + r;
+        if (n < a.N) slab[(long long)a.N * K + n] = bacc[i][r];
+      }
+    }
+  }
+}
+
+template <int KS, int PAD, int TN>
+static int launch_stem_wgrad(StemWgradArgs a, int S, hipStream_t s) {
+  constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16);
+  constexpr int IH = 14 + KS, IW = 30 + KS, IWP = IW | 1;
+  constexpr size_t lds = (size_t)(128 * PN + 3 * IH * IWP + 1) * sizeof(float);
+  a.tiles_x = sqd_cdiv(a.Wo, 16); a.tiles_y = sqd_cdiv(a.Ho, 8);
+  a.nblocks = a.B * a.tiles_x * a.tiles_y;
+  auto kern = stem_wgrad_kernel<KS, PAD, TN>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SQD_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(256), lds, s, a);
+  return sqd_launch_status();
+}
+
+// dy: NHWC [B][Ho][Wo][N] (ReLU-masked); img: NCHW [B][3][Hin][Win]; slab: S*(N*3*k*k + N) floats;
+// dw: OIHW [N][3][k][k]; db: [N].
+extern "C" int sqd_stem_wgrad(const float* dy, const float* img, float* slab, float* dw, float* db, int B, int Hin,
+                              int Win, int N, int ksize, int S, void* stream) {
+  SQD_CHECK_ARG(dy && img && slab && dw && B > 0 && Hin > 0 && Win > 0 && S > 0 && S <= 65535);
+  SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0);
+  StemWgradArgs a;
+  a.dy = dy; a.img = img; a.slab = slab; a.B = B; a.Hin = Hin; a.Win = Win; a.N = N;
+  const int K = 3 * ksize * ksize;
+  a.slab_stride = (long long)N * K + N;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = SQD_ERR_UNSUPPORTED;
+  if (ksize == 3 && N == 64) {
+    a.Ho = (Hin + 2 - 3) / 2 + 1; a.Wo = (Win + 2 - 3) / 2 + 1;
+    rc = launch_stem_wgrad<3, 1, 4>(a, S, s);
+  } else if (ksize == 7 && N == 96) {
+    a.Ho = (Hin + 6 - 7) / 2 + 1; a.Wo = (Win + 6 - 7) / 2 + 1;
+    rc = launch_stem_wgrad<7, 3, 6>(a, S, s);
+  }
+  if (rc != SQD_OK) return rc;
+  // slab layout [n][K] is already OIHW-flat: reduce with C := K, TAPS := 1
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.slab_stride + 255) / 256)), dim3(256), 0, s, slab, dw, db, S,
+                     a.slab_stride, N, K, 1);
+  return sqd_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packer: canonical OIHW parameter -> [ceil(C/kc)][taps][Npad][kc] (zero padded), forward
+// orientation or the data-gradient orientation (in/out channels swapped, taps flipped).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int No, int Ci,
+                                                          int taps, int kc, int Npad, int nchunks, int dgrad) {
+  // forward: N = No (out ch), C = Ci;  dgrad: N = Ci, C = No, tap flipped
+  const int N = dgrad ? Ci : No, C = dgrad ? No : Ci;
+  const long long total = (long long)nchunks * taps * Npad * kc;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int kk = (int)(idx % kc); long long t = idx / kc;
+    const int n = (int)(t % Npad); t /= Npad;
+    const int tap = (int)(t % taps); const int cc = (int)(t / taps);
+    const int c = cc * kc + kk;
+    float v = 0.f;
+    if (n < N && c < C) {
+      if (!dgrad) v = w[((long long)n * Ci + c) * taps + tap];
+      else v = w[((long long)c * Ci + n) * taps + (taps - 1 - tap)];
+    }
+    out[idx] = v;
+  }
+}
+
+// w: OIHW [No][Ci][k][k]; out: packed for a conv with (N,C) = (No,Ci) (dgrad=0) or (Ci,No) (dgrad=1).
+extern "C" int sqd_pack_conv_weight(const float* w, float* out, int No, int Ci, int taps, int kc, int Npad, int dgrad,
+                                    void* stream) {
+  SQD_CHECK_ARG(w && out && No > 0 && Ci > 0 && (taps == 1 || taps == 9) && kc > 0 && Npad > 0);
+  const int N = dgrad ? Ci : No, C = dgrad ? No : Ci;
+  SQD_CHECK_ARG(Npad >= N);
+  const int nchunks = sqd_cdiv(C, kc);
+  const long long total = (long long)nchunks * taps * Npad * kc;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, No, Ci, taps, kc, Npad,
+                     nchunks, dgrad);
+  return sqd_launch_status();
+}

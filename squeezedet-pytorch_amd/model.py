@@ -106,10 +106,7 @@ class SqueezeDetBase(nn.Module):
         hit = self._plans.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
-        if direction == 'fwd':
-            p = ops.ConvPlan(mod.weight, mod.bias, cfg_id)
-        else:
-            p = ops.ConvPlan(ops.dgrad_weight(mod.weight.detach()), None, cfg_id)
+        p = ops.ConvPlan(mod.weight, mod.bias, cfg_id, dgrad=(direction != 'fwd'))
         self._plans[key] = (ver, p)
         return p
 

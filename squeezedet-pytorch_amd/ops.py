@@ -99,31 +99,36 @@ def choose_cfg(taps, C, N, npix):
 
 
 class ConvPlan:
-    """Packed weights ([C/KC][TAPS][Npad][KC], zero padded) + bias for one conv in one direction."""
+    """Packed weights ([C/KC][TAPS][Npad][KC], zero padded) + bias for one conv in one direction.
+    ``dgrad=True`` packs the data-gradient orientation of the same OIHW parameter (in/out channels
+    swapped, taps flipped).  Packing is one HIP kernel launch on the current stream."""
     __slots__ = ('cfg_id', 'taps', 'kc', 'bn', 'C', 'N', 'Npad', 'w', 'bias')
 
-    def __init__(self, w_oihw, bias, cfg_id):
+    def __init__(self, w_oihw, bias, cfg_id, dgrad=False):
         taps_cfg, kc, _px, bn = cfg_table()[cfg_id]
-        N, C, kh, kw = w_oihw.shape
+        No, Ci, kh, kw = w_oihw.shape
         taps = kh * kw
         if taps != taps_cfg or kh != kw or taps not in (1, 9):
             raise ValueError(f'weight {tuple(w_oihw.shape)} does not fit conv cfg {cfg_id} (taps={taps_cfg})')
+        N, C = (Ci, No) if dgrad else (No, Ci)
         if C % 4 or N % 4:
             raise ValueError('channel counts must be multiples of 4')
+        if not w_oihw.is_cuda or w_oihw.dtype != torch.float32:
+            raise ValueError('weights must be fp32 CUDA tensors')
         self.cfg_id, self.taps, self.kc, self.bn, self.C, self.N = cfg_id, taps, kc, bn, C, N
         self.Npad = -(-N // bn) * bn
-        cpad = -(-C // kc) * kc
-        w = w_oihw.detach().to(torch.float32).reshape(N, C, taps).permute(0, 2, 1)         # [N, taps, C]
-        wp = torch.zeros(self.Npad, taps, cpad, device=w.device, dtype=torch.float32)
-        wp[:N, :, :C] = w
-        # [Npad, taps, C/KC, KC] -> [C/KC, taps, Npad, KC]
-        self.w = wp.view(self.Npad, taps, cpad // kc, kc).permute(2, 1, 0, 3).contiguous()
-        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        nchunks = -(-C // kc)
+        src = w_oihw.detach().contiguous()
+        self.w = torch.empty(nchunks, taps, self.Npad, kc, device=src.device, dtype=torch.float32)
+        rc = nat.lib().sqd_pack_conv_weight(nat.ptr(src), nat.ptr(self.w), No, Ci, taps, kc, self.Npad, int(dgrad),
+                                            nat.stream_handle(src.device))
+        nat.check(rc, 'sqd_pack_conv_weight')
+        self.bias = None if (bias is None or dgrad) else bias.detach().contiguous()
 
 
 def dgrad_weight(w_oihw):
     """Weights of the convolution that computes dX from dY: swap in/out channels, flip taps."""
-    return w_oihw.permute(1, 0, 2, 3).flip(2, 3)
+    return w_oihw.permute(1, 0, 2, 3).flip(2, 3).contiguous()
 
 
 def _check_nhwc(t, name):
@@ -131,7 +136,8 @@ def _check_nhwc(t, name):
         raise ValueError(f'{name} must be a contiguous fp32 CUDA tensor [B,H,W,C], got {tuple(t.shape)} {t.dtype} {t.device}')
 
 
-def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, xmask_coff=0):
+def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, xmask_coff=0, ymask=None, ymask_coff=0,
+         ymul=None, ymul_coff=0):
     """y[..., y_coff:y_coff+N] (=|+=) conv(x[..., x_coff:x_coff+C] [* (xmask>0)]) (+bias) (ReLU)."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
     B, H, W, xp = x.shape
@@ -146,6 +152,17 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
         if tuple(xmask.shape[:3]) != (B, H, W) or xmask_coff + plan.C > xmask.shape[3]:
             raise ValueError('conv: xmask geometry mismatch')
         mp = xmask.shape[3]
+    ymp = ylp = 0
+    if ymask is not None:
+        _check_nhwc(ymask, 'ymask')
+        if tuple(ymask.shape[:3]) != (B, H, W) or ymask_coff + plan.N > ymask.shape[3]:
+            raise ValueError('conv: ymask geometry mismatch')
+        ymp = ymask.shape[3]
+    if ymul is not None:
+        _check_nhwc(ymul, 'ymul')
+        if tuple(ymul.shape[:3]) != (B, H, W) or ymul_coff + plan.N > ymul.shape[3]:
+            raise ValueError('conv: ymul geometry mismatch')
+        ylp = ymul.shape[3]
     if B * H * W * max(xp, yp) >= 2 ** 40:
         raise ValueError('conv: tensor too large')
     br = None
@@ -155,8 +172,9 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
                       f'{plan.taps}tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * plan.taps,
                       4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * plan.taps))
     rc = nat.lib().sqd_conv_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(xmask),
-                                B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff,
-                                int(relu), int(accumulate), mp, xmask_coff, plan.cfg_id, nat.stream_handle(x.device))
+                                nat.ptr(ymask), nat.ptr(ymul), B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff,
+                                int(relu), int(accumulate), mp, xmask_coff, ymp, ymask_coff, ylp, ymul_coff,
+                                plan.cfg_id, nat.stream_handle(x.device))
     nat.check(rc, 'sqd_conv_fwd')
     if br is not None:
         br.done()
@@ -219,7 +237,7 @@ def maxpool(x, out=None, argmax=None):
     return out
 
 
-def maxpool_bwd(dy, argmax, in_hw, out=None):
+def maxpool_bwd(dy, argmax, in_hw, out=None, relu_src=None):
     _check_nhwc(dy, 'dy')
     B, Ho, Wo, C = dy.shape
     H, W = in_hw
@@ -227,7 +245,13 @@ def maxpool_bwd(dy, argmax, in_hw, out=None):
         raise ValueError('maxpool_bwd: geometry mismatch')
     if out is None:
         out = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
-    rc = nat.lib().sqd_maxpool3x3s2_ceil_bwd(nat.ptr(dy), nat.ptr(argmax), nat.ptr(out), B, H, W, C, nat.stream_handle(dy.device))
+    if relu_src is not None and (tuple(relu_src.shape) != (B, H, W, C) or not relu_src.is_contiguous()):
+        raise ValueError('maxpool_bwd: relu_src must match the pool input')
+    br = _Bracket('maxpool_bwd', f'poolbwd C{C} {H}x{W}', 0.0, 4.0 * B * C * (H * W * 2 + Ho * Wo * 1.25)) if _timer is not None else None
+    rc = nat.lib().sqd_maxpool3x3s2_ceil_bwd(nat.ptr(dy), nat.ptr(argmax), nat.ptr(out), nat.ptr(relu_src), B, H, W, C,
+                                             nat.stream_handle(dy.device))
+    if br is not None:
+        br.done()
     nat.check(rc, 'sqd_maxpool3x3s2_ceil_bwd')
     return out
 
@@ -293,3 +317,114 @@ def filter_dense(class_ids, scores, boxes, num_classes, keep_top_k=64, nms_thres
                                   int(keep_top_k), float(nms_thresh), float(score_thresh), nat.stream_handle(scores.device))
     nat.check(rc, 'sqd_filter_fwd')
     return bufs
+
+
+# ---------------------------------------------------------------------------------------------
+# training-side ops
+# ---------------------------------------------------------------------------------------------
+_TARGET_WGS = 1536
+
+
+def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps):
+    """(dW OIHW [N,C,k,k], db [N]) from dy[..., dy_coff:dy_coff+N] (already ReLU-masked) and
+    x[..., x_coff:x_coff+C]."""
+    _check_nhwc(dy, 'dy'); _check_nhwc(x, 'x')
+    B, H, W, dyp = dy.shape
+    if tuple(x.shape[:3]) != (B, H, W):
+        raise ValueError('wgrad: dy and x disagree on B,H,W')
+    xp = x.shape[3]
+    if dy_coff + N > dyp or x_coff + C > xp or N % 4 or C % 4 or taps not in (1, 9):
+        raise ValueError('wgrad: channel window out of range')
+    k = 3 if taps == 9 else 1
+    if taps == 9:
+        tn = 5 if 64 < N <= 80 else 4
+        groups = -(-N // (tn * 16)) * -(-C // 16)
+        nblocks = B * -(-H // 8) * -(-W // 16)
+    else:
+        tn = 4 if N >= 64 else -(-N // 16)
+        tc = 4 if C >= 64 else -(-C // 16)
+        groups = -(-N // (tn * 16)) * -(-C // (tc * 16))
+        nblocks = -(-(B * H * W) // 64)
+    S = max(1, min(nblocks, _TARGET_WGS // groups, 256))
+    stride = N * taps * C + N
+    slab = torch.empty(S * stride, device=dy.device, dtype=torch.float32)
+    dw = torch.empty(N, C, k, k, device=dy.device, dtype=torch.float32)
+    db = torch.empty(N, device=dy.device, dtype=torch.float32)
+    br = _Bracket(f'conv_wgrad<{taps}>', f'wgrad {taps}tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * taps,
+                  4.0 * (B * H * W * (C + N) + 2 * S * stride)) if _timer is not None else None
+    rc = nat.lib().sqd_conv_wgrad(nat.ptr(dy), nat.ptr(x), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, dyp, dy_coff,
+                                  C, xp, x_coff, taps, S, nat.stream_handle(dy.device))
+    nat.check(rc, 'sqd_conv_wgrad')
+    if br is not None:
+        br.done()
+    return dw, db
+
+
+def stem_wgrad(dy, image, N, ksize):
+    """(dW [N,3,k,k], db [N]) of the stem from dy NHWC [B,Ho,Wo,N] (ReLU-masked) and the NCHW image."""
+    _check_nhwc(dy, 'dy')
+    B, Ho, Wo, n = dy.shape
+    if n != N or image.dim() != 4 or image.shape[0] != B or image.shape[1] != 3 or not image.is_contiguous():
+        raise ValueError('stem_wgrad: geometry mismatch')
+    H, W = image.shape[2], image.shape[3]
+    if stem_out_size(H, W, ksize) != (Ho, Wo) or (ksize, N) not in ((3, 64), (7, 96)):
+        raise ValueError('stem_wgrad: unsupported geometry')
+    nblocks = B * -(-Ho // 8) * -(-Wo // 16)
+    S = max(1, min(nblocks, 1024))
+    K = 3 * ksize * ksize
+    slab = torch.empty(S * (N * K + N), device=dy.device, dtype=torch.float32)
+    dw = torch.empty(N, 3, ksize, ksize, device=dy.device, dtype=torch.float32)
+    db = torch.empty(N, device=dy.device, dtype=torch.float32)
+    br = _Bracket(f'stem_wgrad<{ksize}>', f'stem wgrad {H}x{W}', 2.0 * B * Ho * Wo * N * K,
+                  4.0 * (B * Ho * Wo * N + B * 3 * H * W)) if _timer is not None else None
+    rc = nat.lib().sqd_stem_wgrad(nat.ptr(dy), nat.ptr(image), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, ksize, S,
+                                  nat.stream_handle(dy.device))
+    nat.check(rc, 'sqd_stem_wgrad')
+    if br is not None:
+        br.done()
+    return dw, db
+
+
+def _check_loss_args(pred, gt, anchors, num_classes):
+    if pred.dim() != 3 or pred.shape[2] != num_classes + 5 or pred.dtype != torch.float32 or not pred.is_cuda:
+        raise ValueError(f'loss: bad pred {tuple(pred.shape)}')
+    B, A, _ = pred.shape
+    if tuple(gt.shape) != (B, A, num_classes + 9) or gt.dtype != torch.float32 or gt.device != pred.device:
+        raise ValueError(f'loss: gt must be fp32 [B,A,C+9] on the same device, got {tuple(gt.shape)}')
+    if tuple(anchors.shape) != (A, 4) or anchors.dtype != torch.float32 or anchors.device != pred.device:
+        raise ValueError('loss: anchors must be fp32 [A,4] on the same device')
+    return B, A
+
+
+def loss_fwd(pred, gt, anchors, input_size, num_classes, weights):
+    """-> (losses [4,B] = class, score, bbox, total; nobj [B])."""
+    B, A = _check_loss_args(pred, gt, anchors, num_classes)
+    pred, gt, anchors = pred.contiguous(), gt.contiguous(), anchors.contiguous()
+    ws = torch.empty(B * 16 * 5, device=pred.device, dtype=torch.float32)
+    losses = torch.empty(4, B, device=pred.device, dtype=torch.float32)
+    nobj = torch.empty(B, device=pred.device, dtype=torch.float32)
+    br = _Bracket('loss_fwd', f'loss A{A}', 0.0, 4.0 * B * A * (2 * num_classes + 14)) if _timer is not None else None
+    rc = nat.lib().sqd_loss_fwd(nat.ptr(pred), nat.ptr(gt), nat.ptr(anchors), nat.ptr(ws), nat.ptr(losses), nat.ptr(nobj), B, A,
+                                num_classes, int(input_size[0]), int(input_size[1]), *[float(w) for w in weights],
+                                nat.stream_handle(pred.device))
+    nat.check(rc, 'sqd_loss_fwd')
+    if br is not None:
+        br.done()
+    return losses, nobj
+
+
+def loss_bwd(pred, gt, anchors, nobj, coef, input_size, num_classes, weights):
+    """coef [3,B] -> dpred [B,A,C+5]."""
+    B, A = _check_loss_args(pred, gt, anchors, num_classes)
+    if tuple(coef.shape) != (3, B) or tuple(nobj.shape) != (B,):
+        raise ValueError('loss_bwd: coef must be [3,B], nobj [B]')
+    pred, gt, anchors, coef = pred.contiguous(), gt.contiguous(), anchors.contiguous(), coef.contiguous().float()
+    dpred = torch.empty_like(pred)
+    br = _Bracket('loss_bwd', f'lossbwd A{A}', 0.0, 4.0 * B * A * (3 * num_classes + 19)) if _timer is not None else None
+    rc = nat.lib().sqd_loss_bwd(nat.ptr(pred), nat.ptr(gt), nat.ptr(anchors), nat.ptr(nobj), nat.ptr(coef), nat.ptr(dpred), B, A,
+                                num_classes, int(input_size[0]), int(input_size[1]), *[float(w) for w in weights],
+                                nat.stream_handle(pred.device))
+    nat.check(rc, 'sqd_loss_bwd')
+    if br is not None:
+        br.done()
+    return dpred

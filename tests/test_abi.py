@@ -36,7 +36,7 @@ def test_library_builds_and_exports_header_symbols():
     from squeezedet_pytorch_amd import _native as nat
     lib = nat.lib()
     protos = _header_protos()
-    assert len(protos) >= 9
+    assert len(protos) >= 14
     for name in protos:
         assert hasattr(lib, name), f"{name} declared in include/sqd_hip.h but not exported"
 
@@ -73,7 +73,7 @@ def test_status_codes_without_gpu():
     assert t.value in (1, 9) and k.value in (16, 32) and px.value in (64, 128) and bn.value % 16 == 0
     assert lib.sqd_conv_cfg_info(n, None, None, None, None) == 1           # bad cfg id
     null = ctypes.c_void_p(0)
-    assert lib.sqd_conv_fwd(null, null, null, null, null, 1, 1, 1, 4, 4, 0, 4, 16, 4, 0, 0, 0, 0, 0, 0, null) == 1
+    assert lib.sqd_conv_fwd(null, null, null, null, null, null, null, 1, 1, 1, 4, 4, 0, 4, 16, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, null) == 1
     assert lib.sqd_detect_fwd(null, null, null, null, null, null, null, null, 1, 1, 3, 1, 1, 64, 0.4, 0.3, null) == 1
 
 

@@ -1,0 +1,71 @@
+"""CPU tier, N>1 path: world_size-2 gloo processes exercise the gradient all-reduce / sharding logic
+of trainer.py (the HIP kernels themselves cannot run here; per-shard gradients come from the oracle).
+Checks the reference semantic: loss.mean() over the GLOBAL batch (src/engine/trainer.py:43)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd import synthetic
+    from squeezedet_pytorch_amd.trainer import allreduce_gradients, shard_sizes
+    size = (64, 96)
+    cfg = sqd.make_cfg(input_size=size, device='cpu')
+    sd = synthetic.make_state_dict('squeezedet', seed=1234)
+    B = 4
+    x = synthetic.make_images(B, size, seed=3)
+    gt = synthetic.make_gt(B, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3)
+    sizes = shard_sizes(B, world)
+    lo = sum(sizes[:rank]); hi = lo + sizes[rank]
+    # local step exactly as Trainer.run_epoch does it: local mean, backward, all-reduce SUM, /W
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred = oracle.backbone_forward(x[lo:hi], params)
+    loss_vec, _ = oracle.multitask_loss(pred, gt[lo:hi], cfg.anchors, size)
+    loss_vec.mean().backward()
+    plist = list(params.values())
+    flat = allreduce_gradients(plist, world)
+    assert flat.numel() == 2082120
+    torch.save({k: v.grad for k, v in params.items()}, os.path.join(out_dir, f'g{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gloo_world2_gradient_allreduce_equals_global_mean(tmp_path):
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    import oracle
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd import synthetic
+    size = (64, 96)
+    cfg = sqd.make_cfg(input_size=size, device='cpu')
+    sd = synthetic.make_state_dict('squeezedet', seed=1234)
+    x = synthetic.make_images(4, size, seed=3)
+    gt = synthetic.make_gt(4, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3)
+    _, _, grads, total, _, _ = oracle.train_step_reference(sd, None, x, gt, cfg.anchors, size)
+    g0 = torch.load(os.path.join(tmp_path, 'g0.pt'))
+    g1 = torch.load(os.path.join(tmp_path, 'g1.pt'))
+    for k in grads:
+        assert torch.equal(g0[k], g1[k]), f'{k}: ranks disagree after all-reduce'
+        ref = grads[k]
+        assert (g0[k] - ref).abs().max().item() <= 1e-4 * max(float(ref.abs().max()), 1e-3), k
+
+
+def test_shard_sizes():
+    from squeezedet_pytorch_amd.trainer import shard_sizes
+    assert shard_sizes(160, 8) == [20] * 8
+    assert shard_sizes(20, 1) == [20]
+    assert shard_sizes(22, 4) == [6, 6, 5, 5] and sum(shard_sizes(23, 8)) == 23
