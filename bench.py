@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
     ap.add_argument('--arch', default='squeezedet')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='(unused: the timed region is eager so kernels can be bracketed)')
+    ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
     return ap.parse_args()
 
 
@@ -114,29 +114,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up; the first warm-up steps also find the dominant kernel ----
-    timer_all = ops.KernelTimer()
-    ops.set_timer(timer_all)
-    nprof = max(2, min(args.warmup, 3))
-    for _ in range(nprof):
+    # ---- warm-up (eager), then capture one step into a hipGraph for the timed region ----
+    for _ in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
-    ops.set_timer(None)
-    summ = timer_all.summary()
-    dominant = max(summ.items(), key=lambda kv: kv[1]['ms'])[0] if summ else None
-    for _ in range(max(0, args.warmup - 3)):
-        step()
+    graph = None
+    if args.mode == 'infer' and not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()                                   # allocations of the capture stream's pool
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay(); graph.replay()
+        torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
 
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
-    timer = ops.KernelTimer(select={dominant}) if dominant else None
-    ops.set_timer(timer)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     barrier()
     elapsed = time.perf_counter() - t0
+
+    # ---- per-kernel HIP-event pass, inside the same process right after the timed region: every kernel of
+    # `nprof` eager steps is bracketed on its launch stream.  Two un-bracketed steps are enqueued first so the
+    # host runs ahead of the GPU and no bracket absorbs a launch gap (brackets are only exact when the GPU is
+    # the bottleneck; checked against rocprofv3 --kernel-trace, profiles/). ----
+    nprof = 3
+    timer = ops.KernelTimer()
+    run(); run()
+    ops.set_timer(timer)
+    for _ in range(nprof):
+        step()
     ops.set_timer(None)
+    torch.cuda.synchronize()
+    summ = timer.summary()
+    dominant = max(summ.items(), key=lambda kv: kv[1]['ms'])[0] if summ else None
 
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -147,8 +165,8 @@ def main():
         total_images = B * world * args.steps
         value = total_images / elapsed
         roof = None
-        if timer is not None:
-            d = timer.summary()[dominant]
+        if dominant is not None:
+            d = summ[dominant]
             avg_s = d['ms'] / d['launches'] / 1e3
             flops_per_launch = d['flops'] / d['launches']
             bytes_per_launch = d['bytes'] / d['launches']
@@ -161,10 +179,11 @@ def main():
                 ach = bytes_per_launch / avg_s / 1e9
                 roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
-            roof.update({'kernel': dominant, 'launches_per_step': d['launches'] // args.steps,
+            roof.update({'kernel': dominant, 'launches_per_step': d['launches'] // nprof,
                          'avg_launch_us': round(avg_s * 1e6, 2),
                          'algorithmic_per_launch': {'gflop': round(flops_per_launch / 1e9, 3), 'mbytes': round(bytes_per_launch / 1e6, 3)},
-                         'share_of_step': round(d['ms'] / 1e3 / elapsed, 3)})
+                         'share_of_step': round(d['ms'] / nprof / (elapsed / args.steps * 1e3), 3),
+                         'how': f'HIP events around every launch of {nprof} eager steps enqueued behind the timed region'})
         whole = {'tflops': round(value * FWD_GFLOP_PER_IMAGE / 1e3, 2),
                  'frac_of_fp32_mfma_peak': round(value / world * FWD_GFLOP_PER_IMAGE / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)} \
             if args.arch == 'squeezedet' and args.mode == 'infer' else None
@@ -184,7 +203,8 @@ def main():
             'config': {'workload': describe, 'arch': args.arch, 'images_per_gpu_per_step': B, 'global_batch': B * world,
                        'input': '3x384x1248 fp32 NCHW, HBM resident', 'weights': 'synthetic Kaiming-scale, seed 1234',
                        'parallelism': f'replicas x{world}' if args.mode == 'infer' else f'dp{world}'},
-            'roofline': roof, 'cpu_baseline': cpu, 'whole_network': whole, 'kernels_warmup_profile': kernels,
+            'roofline': roof, 'cpu_baseline': cpu, 'whole_network': whole, 'timed_with': 'hipGraph replay' if graph is not None else 'eager launches',
+            'kernels_event_profile': kernels,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -9,18 +9,21 @@
 //
 // Layout: activations NHWC fp32 ([B][H][W][pitch], a layer reads/writes a channel window
 // [coff, coff+C) of a buffer whose pixel pitch may be larger: that is how concat is eliminated).
-// Weights are pre-packed by the host as [C/KC][TAPS][Npad][KC] (zero padded) so that one K-chunk
-// of one output-channel slice is a contiguous run.
+// Weights are pre-packed (pack_weight_kernel) as [C/KC][KC/4][TAPS][Npad][4] (zero padded): the LDS
+// image of one K-chunk of one output-channel slice is a set of contiguous runs.
 //
 // Work decomposition: one 256-thread workgroup (4 waves, one per SIMD) computes a tile of
 // TH x 16 pixels (3x3: a TH-row x 16-column patch of one image with a 1-pixel halo; 1x1: TH*16
 // consecutive pixels of the flattened B*H*W axis) times BN = 16*NT output channels.  The K loop
 // walks channel chunks of KC; per chunk the activation tile and the weight slice for all taps are
-// staged in LDS, then every wave issues v_mfma_f32_16x16x4_f32 over (tap, k).  MFMA operand A is
+// staged in LDS, then every wave issues v_mfma_f32_16x16x4_f32 over (tap, k).  Workgroups are
+// PERSISTENT: the grid is one resident wave of workgroups (CUs x occupancy), each walks a strided
+// list of pixel tiles, and the global loads of the next stage (next K chunk or next tile) are issued
+// into registers before the MFMAs of the current stage and written to LDS after them, so HBM/L2
+// latency hides under compute; when the whole K fits one chunk the weight slice stays in LDS.  MFMA operand A is
 // the weight tile (row = output channel), operand B the activation tile (column = pixel), so each
 // lane ends up holding 4 consecutive output channels of one pixel: the epilogue is one 16-byte
-// store per lane and tile.  LDS rows are padded to KC+4 floats (4*odd) which makes the
-// ds_read_b64 operand fetches bank-conflict free (16 rows x 2 k-pairs per 32-lane half).
+// store per lane and tile.
 //
 // Numerics: fp32 operands, fp32 accumulate; the MFMA is bit-for-bit a k-ordered fmaf chain, so
 // results differ from the reference's MKL-DNN/cuDNN summation order only by fp32 rounding
@@ -33,56 +36,62 @@ struct ConvArgs {
   int C, x_pitch, x_coff;
   int N, Npad, y_pitch, y_coff;
   int relu, accumulate;
-  int tiles_x, tiles_y;
+  int tiles_x, tiles_y, ntiles;
   int xmask_pitch, xmask_coff;
   const float* ymask; const float* ymul;      // epilogue: zero where ymask <= 0 (ReLU backward), multiply by ymul (dropout)
   int ymask_pitch, ymask_coff, ymul_pitch, ymul_coff;
   long long total_px;
 };
 
-template <int TAPS, int KC, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+// LDS tiles are "k-quad major": [KC/4][rows][4 floats].  A lane's MFMA operands for 4 consecutive
+// k (one ds_read_b128) sit in plane 4*s + (lane>>4); with the row count a multiple of 16 the four
+// 16-lane groups of a ds_read_b128 each cover 16 distinct 16-byte slots of the 256-byte bank row
+// (MI355X_MICROARCH.md LDS table), i.e. conflict-free at the full 256 B/clk.  Staging stores walk rows
+// fastest (8 consecutive lanes = 8 consecutive 16-byte slots of one plane): conflict-free too.
+template <int TAPS, int KC, int MT, int NT, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   constexpr int WM = 4;                 // waves along pixels; every wave covers all BN channels
   constexpr int TH = MT * WM;           // tile rows of 16 pixels
   constexpr int BN = 16 * NT;
-  constexpr int KP = KC + 4;            // LDS row pitch in floats = 4 * odd
   constexpr int NPIX = (TAPS == 9) ? (TH + 2) * 18 : TH * 16;
-  constexpr int KV = KC / 4;
-  static_assert(((KP / 4) & 1) == 1, "LDS pitch must be 4*odd floats");
+  constexpr int NPIXP = (NPIX + 15) & ~15;
+  constexpr int WROWS = TAPS * BN;      // multiple of 16
+  constexpr int KV = KC / 4;            // planes
+  constexpr int A_IT = (NPIX * KV + 255) / 256;          // float4 prefetch registers per thread
+  constexpr int W_IT = (WROWS * KV + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* actT = smem;                   // [NPIX][KP]
-  float* wT = smem + NPIX * KP;         // [TAPS][BN][KP]
+  float* actT = smem;                   // [KV][NPIXP][4]
+  float* wT = smem + KV * NPIXP * 4;    // [KV][WROWS][4]
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * BN;
-
-  int b = 0, y0 = 0, x0 = 0;
-  long long p0 = 0;
-  if (TAPS == 9) {
-    int t = blockIdx.x;
-    const int tx = t % a.tiles_x; t /= a.tiles_x;
-    const int ty = t % a.tiles_y; b = t / a.tiles_y;
-    y0 = ty * TH; x0 = tx * 16;
-  } else {
-    p0 = (long long)blockIdx.x * (TH * 16);
-  }
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   const int nchunks = (a.C + KC - 1) / KC;
-  for (int cc = 0; cc < nchunks; ++cc) {
+  const bool w_stationary = (nchunks == 1);   // whole K fits one chunk: weights stay in LDS across tiles
+  const int ntiles = a.ntiles;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+
+  f32x4 ra[A_IT], rw[W_IT];
+
+  // ---- global -> registers (zero outside the image / beyond C) ----
+  auto load_act = [&](int t, int cc) {
+    int b = 0, y0 = 0, x0 = 0;
+    long long p0 = 0;
+    if (TAPS == 9) {
+      const int tx = t % a.tiles_x; t /= a.tiles_x;
+      const int ty = t % a.tiles_y; b = t / a.tiles_y;
+      y0 = ty * TH; x0 = tx * 16;
+    } else {
+      p0 = (long long)t * (TH * 16);
+    }
     const int c0 = cc * KC;
-    if (cc) __syncthreads();
-    // ---- stage the activation tile (zero outside the image / beyond C) ----
-    for (int idx = tid; idx < NPIX * KV; idx += 256) {
-      const int pix = idx / KV, v = idx - pix * KV;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int v = idx / NPIX, pix = idx - v * NPIX;
       const int c = c0 + 4 * v;
-      bool ok = c < a.C;
+      bool ok = (idx < NPIX * KV) && c < a.C;
       long long gp;
       if (TAPS == 9) {
         const int r = pix / 18, col = pix - r * 18;
@@ -102,97 +111,188 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
           val.z = m.z > 0.f ? val.z : 0.f; val.w = m.w > 0.f ? val.w : 0.f;
         }
       }
-      *(f32x4*)(actT + pix * KP + 4 * v) = val;
+      ra[it] = val;
     }
-    // ---- stage the weight slice [TAPS][BN][KC] of this chunk ----
-    const float* wc = a.w + ((long long)cc * TAPS * a.Npad + n0) * KC;
-    for (int idx = tid; idx < TAPS * BN * KV; idx += 256) {
-      const int tn = idx / KV, v = idx - tn * KV;
+  };
+  // packed weights: [chunk][plane v][tap][Npad][4]
+  auto load_w = [&](int cc) {
+    const float* wc = a.w + (long long)cc * KV * TAPS * a.Npad * 4;
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int v = idx / WROWS, tn = idx - v * WROWS;
       const int tap = tn / BN, n = tn - tap * BN;
-      *(f32x4*)(wT + tn * KP + 4 * v) = *(const f32x4*)(wc + ((long long)tap * a.Npad + n) * KC + 4 * v);
+      f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (idx < WROWS * KV) val = *(const f32x4*)(wc + (((long long)v * TAPS + tap) * a.Npad + n0 + n) * 4);
+      rw[it] = val;
     }
-    __syncthreads();
-    // ---- MFMA over (tap, k) ----
+  };
+  // ---- registers -> LDS ----
+  auto store_act = [&]() {
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+    for (int it = 0; it < A_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int v = idx / NPIX, pix = idx - v * NPIX;
+      if (idx < NPIX * KV) *(f32x4*)(actT + (v * NPIXP + pix) * 4) = ra[it];
+    }
+  };
+  auto store_w = [&]() {
 #pragma unroll
-      for (int k8 = 0; k8 < KC / 8; ++k8) {
-        f32x2 bf[MT], af[NT];
+    for (int it = 0; it < W_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < WROWS * KV) *(f32x4*)(wT + idx * 4) = rw[it];      // idx = v*WROWS + tn
+    }
+  };
+
+  f32x4 acc[MT][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int row = (TAPS == 9) ? ((wm * MT + i) + dy) * 18 + lr + dx : (wm * MT + i) * 16 + lr;
-          bf[i] = *(const f32x2*)(actT + row * KP + k8 * 8 + 2 * g);
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: first stage
+  load_act(tile, 0);
+  load_w(0);
+  store_act();
+  store_w();
+  __syncthreads();
+
+  for (;;) {
+    for (int cc = 0; cc < nchunks; ++cc) {
+      // ---- prefetch the next stage (next K chunk, or chunk 0 of this workgroup's next tile) ----
+      int ncc = cc + 1, ntile = tile;
+      if (ncc == nchunks) { ncc = 0; ntile = tile + (int)gridDim.x; }
+      const bool has_next = ntile < ntiles;
+      const bool next_w = has_next && !w_stationary;
+      if (has_next) load_act(ntile, ncc);
+      if (next_w) load_w(ncc);
+
+      // ---- MFMA over (tap, k) of the staged chunk ----
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+        for (int s = 0; s < KC / 16; ++s) {
+          f32x4 bf[MT], af[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int row = (TAPS == 9) ? ((wm * MT + i) + dy) * 18 + lr + dx : (wm * MT + i) * 16 + lr;
+            bf[i] = *(const f32x4*)(actT + ((4 * s + g) * NPIXP + row) * 4);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            af[j] = *(const f32x4*)(wT + ((4 * s + g) * WROWS + tap * BN + j * 16 + lr) * 4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(af[j][t], bf[i][t], acc[i][j]);
+        }
+      }
+
+      // ---- epilogue after the last chunk: lane holds channels n0+16j+4g..+3 of pixel (row i, col lr) ----
+      if (cc == nchunks - 1) {
+        int b = 0, y0 = 0, x0 = 0;
+        long long p0 = 0;
+        if (TAPS == 9) {
+          int t = tile;
+          const int tx = t % a.tiles_x; t /= a.tiles_x;
+          const int ty = t % a.tiles_y; b = t / a.tiles_y;
+          y0 = ty * TH; x0 = tx * 16;
+        } else {
+          p0 = (long long)tile * (TH * 16);
         }
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          af[j] = *(const f32x2*)(wT + (tap * BN + j * 16 + lr) * KP + k8 * 8 + 2 * g);
+        for (int i = 0; i < MT; ++i) {
+          long long gp; bool valid;
+          if (TAPS == 9) {
+            const int iy = y0 + wm * MT + i, ix = x0 + lr;
+            valid = iy < a.H && ix < a.W;
+            gp = ((long long)b * a.H + iy) * a.W + ix;
+          } else {
+            gp = p0 + (wm * MT + i) * 16 + lr;
+            valid = gp < a.total_px;
+          }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(af[j].x, bf[i].x, acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(af[j].y, bf[i].y, acc[i][j]);
+          for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + 4 * g;
+            f32x4 v = acc[i][j];
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!valid || n >= a.N) continue;
+            if (a.bias) v += *(const f32x4*)(a.bias + n);
+            float* dst = a.y + gp * a.y_pitch + a.y_coff + n;
+            if (a.accumulate) v += *(const f32x4*)dst;
+            if (a.ymul) v *= *(const f32x4*)(a.ymul + gp * a.ymul_pitch + a.ymul_coff + n);
+            if (a.ymask) {
+              const f32x4 m = *(const f32x4*)(a.ymask + gp * a.ymask_pitch + a.ymask_coff + n);
+              v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *(f32x4*)dst = v;
+          }
+        }
       }
-    }
-  }
 
-  // ---- epilogue: lane holds channels n0 + 16j + 4g .. +3 of pixel (row i, column lr) ----
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    long long gp; bool valid;
-    if (TAPS == 9) {
-      const int iy = y0 + wm * MT + i, ix = x0 + lr;
-      valid = iy < a.H && ix < a.W;
-      gp = ((long long)b * a.H + iy) * a.W + ix;
-    } else {
-      gp = p0 + (wm * MT + i) * 16 + lr;
-      valid = gp < a.total_px;
+      // ---- hand the prefetched stage over through LDS ----
+      __syncthreads();                       // every wave is done reading the current stage
+      if (has_next) store_act();
+      if (next_w) store_w();
+      __syncthreads();
     }
-    if (!valid) continue;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + 4 * g;
-      if (n >= a.N) continue;
-      f32x4 v = acc[i][j];
-      if (a.bias) v += *(const f32x4*)(a.bias + n);
-      float* dst = a.y + gp * a.y_pitch + a.y_coff + n;
-      if (a.accumulate) v += *(const f32x4*)dst;
-      if (a.ymul) v *= *(const f32x4*)(a.ymul + gp * a.ymul_pitch + a.ymul_coff + n);
-      if (a.ymask) {
-        const f32x4 m = *(const f32x4*)(a.ymask + gp * a.ymask_pitch + a.ymask_coff + n);
-        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-      }
-      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      *(f32x4*)dst = v;
-    }
+    tile += (int)gridDim.x;
+    if (tile >= ntiles) break;
   }
+}
+
+static int sqd_num_cus() {
+  static int cus = 0;                        // immutable per-process cache
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
 }
 
 template <int TAPS, int KC, int MT, int NT>
 static int launch_conv(ConvArgs a, hipStream_t stream) {
-  constexpr int TH = MT * 4, BN = 16 * NT, KP = KC + 4;
+  constexpr int TH = MT * 4, BN = 16 * NT;
   constexpr int NPIX = (TAPS == 9) ? (TH + 2) * 18 : TH * 16;
-  constexpr size_t lds = (size_t)(NPIX + TAPS * BN) * KP * sizeof(float);
+  constexpr int NPIXP = (NPIX + 15) & ~15;
+  constexpr size_t lds = (size_t)(NPIXP + TAPS * BN) * KC * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  dim3 grid;
+  // waves/SIMD the register allocator must leave room for (= workgroups per CU): capped by what LDS admits
+  // and by what each instantiation reaches without spilling (checked with -Rpass-analysis)
+  constexpr int LDSW = (int)((160 * 1024) / lds);
+  constexpr int REGW = (TAPS == 9) ? ((MT * NT <= 8 && NT <= 4) ? 2 : 1)
+                                   : ((MT * NT <= 2) ? 4 : ((MT * NT <= 4 && KC == 32) || (KC == 16 && MT * NT <= 8) ? 3 : 2));
+  constexpr int MINW = LDSW < REGW ? (LDSW < 1 ? 1 : LDSW) : REGW;
+  auto kern = conv_igemm_kernel<TAPS, KC, MT, NT, MINW>;
+  static int wgs_per_cu = 0;                 // occupancy of this instantiation (immutable once computed)
+  if (wgs_per_cu == 0) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SQD_ERR_LAUNCH;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    wgs_per_cu = nb > 4 ? 4 : nb;
+  }
   if (TAPS == 9) {
     a.tiles_x = sqd_cdiv(a.W, 16); a.tiles_y = sqd_cdiv(a.H, TH);
-    grid.x = (unsigned)(a.B * a.tiles_x * a.tiles_y);
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
   } else {
     a.tiles_x = a.tiles_y = 0;
-    grid.x = (unsigned)((a.total_px + TH * 16 - 1) / (TH * 16));
+    a.ntiles = (int)((a.total_px + TH * 16 - 1) / (TH * 16));
   }
-  grid.y = (unsigned)sqd_cdiv(a.N, BN);
-  if ((int)grid.y * BN > a.Npad) return SQD_ERR_BAD_ARG;   // packed weights too short for this slice width
-  auto kern = conv_igemm_kernel<TAPS, KC, MT, NT>;
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+  const int nslices = sqd_cdiv(a.N, BN);
+  if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;     // packed weights too short for this slice width
+  // persistent grid: at most one resident wave of workgroups, pixel tiles dealt evenly
+  const int slots = sqd_num_cus() * wgs_per_cu;
+  int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
+  const int per_wg = sqd_cdiv(a.ntiles, gx_max);
+  const int gx = sqd_cdiv(a.ntiles, per_wg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(256), lds, stream, a);
   return sqd_launch_status();
 }
 
@@ -219,6 +319,24 @@ static const ConvCfg kConvCfgs[] = {
     {9, 16, 1, 6},  // 16 3x3, 4x16 px x 96 ch
     {9, 16, 2, 3},  // 17 3x3, 8x16 px x 48 ch
     {9, 16, 2, 1},  // 18 3x3, 8x16 px x 16 ch (dgrad into a 16-channel squeeze)
+    {9, 16, 1, 1},  // 19 3x3, 4x16 px x 16 ch
+    {9, 16, 1, 2},  // 20 3x3, 4x16 px x 32 ch
+    {9, 16, 1, 3},  // 21 3x3, 4x16 px x 48 ch
+    {9, 16, 4, 1},  // 22 3x3, 16x16 px x 16 ch
+    {9, 16, 4, 2},  // 23 3x3, 16x16 px x 32 ch
+    {1, 16, 1, 2},  // 24 1x1 small C, 64 px x 32 ch
+    {1, 16, 2, 2},  // 25 1x1 small C, 128 px x 32 ch
+    {1, 16, 4, 2},  // 26 1x1 small C, 256 px x 32 ch
+    {1, 16, 4, 4},  // 27 1x1 small C, 256 px x 64 ch
+    {1, 32, 1, 1},  // 28 1x1, 64 px x 16 ch
+    {1, 32, 1, 2},  // 29 1x1, 64 px x 32 ch
+    {1, 32, 4, 1},  // 30 1x1, 256 px x 16 ch
+    {1, 32, 4, 2},  // 31 1x1, 256 px x 32 ch
+    {1, 64, 1, 2},  // 32 1x1, KC=64, 64 px x 32 ch
+    {1, 64, 1, 3},  // 33 1x1, KC=64, 64 px x 48 ch
+    {1, 64, 1, 4},  // 34 1x1, KC=64, 64 px x 64 ch
+    {1, 64, 2, 1},  // 35 1x1, KC=64, 128 px x 16 ch
+    {1, 64, 2, 2},  // 36 1x1, KC=64, 128 px x 32 ch
 };
 static const int kNumConvCfgs = (int)(sizeof(kConvCfgs) / sizeof(kConvCfgs[0]));
 
@@ -255,7 +373,7 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.xmask = xmask;
   a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff;
-  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0;
+  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0;
   a.xmask_pitch = xmask_pitch; a.xmask_coff = xmask_coff;
   a.total_px = (long long)B * H * W;
   hipStream_t s = (hipStream_t)stream;
@@ -281,6 +399,24 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   SQD_CONV_CASE(9, 16, 1, 6)
   SQD_CONV_CASE(9, 16, 2, 3)
   SQD_CONV_CASE(9, 16, 2, 1)
+  SQD_CONV_CASE(9, 16, 1, 1)
+  SQD_CONV_CASE(9, 16, 1, 2)
+  SQD_CONV_CASE(9, 16, 1, 3)
+  SQD_CONV_CASE(9, 16, 4, 1)
+  SQD_CONV_CASE(9, 16, 4, 2)
+  SQD_CONV_CASE(1, 16, 1, 2)
+  SQD_CONV_CASE(1, 16, 2, 2)
+  SQD_CONV_CASE(1, 16, 4, 2)
+  SQD_CONV_CASE(1, 16, 4, 4)
+  SQD_CONV_CASE(1, 32, 1, 1)
+  SQD_CONV_CASE(1, 32, 1, 2)
+  SQD_CONV_CASE(1, 32, 4, 1)
+  SQD_CONV_CASE(1, 32, 4, 2)
+  SQD_CONV_CASE(1, 64, 1, 2)
+  SQD_CONV_CASE(1, 64, 1, 3)
+  SQD_CONV_CASE(1, 64, 1, 4)
+  SQD_CONV_CASE(1, 64, 2, 1)
+  SQD_CONV_CASE(1, 64, 2, 2)
 #undef SQD_CONV_CASE
   return SQD_ERR_UNSUPPORTED;
 }

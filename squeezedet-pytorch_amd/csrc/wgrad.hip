@@ -381,25 +381,28 @@ extern "C" int sqd_stem_wgrad(const float* dy, const float* img, float* slab, fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight packer: canonical OIHW parameter -> [ceil(C/kc)][taps][Npad][kc] (zero padded), forward
+// Weight packer: canonical OIHW parameter -> [ceil(C/kc)][kc/4][taps][Npad][4] (zero padded), forward
 // orientation or the data-gradient orientation (in/out channels swapped, taps flipped).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int No, int Ci,
                                                           int taps, int kc, int Npad, int nchunks, int dgrad) {
   // forward: N = No (out ch), C = Ci;  dgrad: N = Ci, C = No, tap flipped
+  // out[chunk][plane v][tap][n][e]  with channel c = chunk*kc + 4*v + e
   const int N = dgrad ? Ci : No, C = dgrad ? No : Ci;
-  const long long total = (long long)nchunks * taps * Npad * kc;
+  const int kv = kc >> 2;
+  const long long total = (long long)nchunks * kv * taps * Npad * 4;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int kk = (int)(idx % kc); long long t = idx / kc;
+    const int e = (int)(idx & 3); long long t = idx >> 2;
     const int n = (int)(t % Npad); t /= Npad;
-    const int tap = (int)(t % taps); const int cc = (int)(t / taps);
-    const int c = cc * kc + kk;
-    float v = 0.f;
+    const int tap = (int)(t % taps); t /= taps;
+    const int v = (int)(t % kv); const int cc = (int)(t / kv);
+    const int c = cc * kc + 4 * v + e;
+    float val = 0.f;
     if (n < N && c < C) {
-      if (!dgrad) v = w[((long long)n * Ci + c) * taps + tap];
-      else v = w[((long long)c * Ci + n) * taps + (taps - 1 - tap)];
+      if (!dgrad) val = w[((long long)n * Ci + c) * taps + tap];
+      else val = w[((long long)c * Ci + n) * taps + (taps - 1 - tap)];
     }
-    out[idx] = v;
+    out[idx] = val;
   }
 }
 

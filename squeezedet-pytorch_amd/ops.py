@@ -55,6 +55,9 @@ class _Bracket:
         if t is not None and t.wants(name):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             self.rec = (name, tag, flops, nbytes, e0, e1)
+            # a start marker that directly follows a kernel is time-stamped while that kernel still runs
+            # (measured: +40..80 us vs rocprofv3); a preceding fence marker makes it wait for the stream
+            torch.cuda.Event(enable_timing=True).record()
             e0.record()
 
     def done(self):
@@ -71,11 +74,31 @@ def cfg_table():
     return _CFG_TABLE
 
 
+_TUNING = None
+
+
+def _tuning():
+    """Measured per-shape table written by tools/tune_conv.py on an MI355X ({} if absent)."""
+    global _TUNING
+    if _TUNING is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning.json')
+        try:
+            with open(path) as f:
+                _TUNING = {k: int(v['cfg']) for k, v in json.load(f).items()}
+        except (OSError, ValueError, KeyError):
+            _TUNING = {}
+    return _TUNING
+
+
 def choose_cfg(taps, C, N, npix):
-    """Pick a tile configuration for a conv layer: smallest channel-slice width that covers N in
-    the fewest slices without more than ~12% padding, 128-pixel tiles when that still yields
-    >= 4 workgroups per CU, else 64-pixel tiles."""
+    """Tile configuration for a conv layer: the measured table if it has this shape, else a heuristic
+    (least channel padding, 128-pixel tiles when that still yields >= 4 workgroups per CU)."""
     tab = cfg_table()
+    hit = _tuning().get(f'{taps}:{C}:{N}:{npix}')
+    if hit is not None and hit in tab and tab[hit][0] == taps:
+        return hit
     want_kc = 16 if (taps == 9 or C <= 128 and C % 32 != 0 or C < 64) else 32
     best = None
     for cid, (t, kc, px, bn) in tab.items():

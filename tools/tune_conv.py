@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Measure every compiled conv tile configuration on every conv shape of the network (forward and
+data-gradient orientation) on the current GPU and write the fastest per shape to
+squeezedet-pytorch_amd/tuning.json (consulted by ops.choose_cfg).  Run on the GPU box:
+
+    python tools/tune_conv.py [--arch squeezedet] [--batch 20] [--size 384 1248]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import squeezedet_pytorch_amd as sqd  # noqa: E402
+from squeezedet_pytorch_amd import ops  # noqa: E402
+from squeezedet_pytorch_amd.synthetic import layer_table, convdet_in_channels  # noqa: E402
+
+
+def shapes(arch, B, H, W):
+    """[(taps, C, N, h, w)] of every conv launched by forward + backward at this input size."""
+    out = set()
+    layers = layer_table(arch)
+    h, w = ops.stem_out_size(H, W, layers[0][3])
+    for l in layers[2:]:
+        if l[0] == 'pool':
+            h, w = ops.pool_out_size(h, w)
+            continue
+        _, cin, s, e1, e3 = l
+        out.add((1, cin, s, h, w)); out.add((1, s, e1, h, w)); out.add((9, s, e3, h, w))
+        out.add((1, s, cin, h, w)); out.add((1, e1, s, h, w)); out.add((9, e3, s, h, w))      # dgrads
+    ncd = 9 * 8
+    c = convdet_in_channels(arch)
+    out.add((9, c, ncd, h, w)); out.add((9, ncd, c, h, w))
+    return sorted(out)
+
+
+def time_cfg(taps, C, N, B, h, w, cid, reps=10):
+    k = 3 if taps == 9 else 1
+    wt = torch.randn(N, C, k, k, device='cuda') * 0.05
+    bias = torch.randn(N, device='cuda')
+    plan = ops.ConvPlan(wt, bias, cid)
+    x = torch.randn(B, h, w, C, device='cuda')
+    y = torch.empty(B, h, w, N, device='cuda')
+    for _ in range(2):
+        ops.conv(x, 0, plan, y, 0, relu=True)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv(x, 0, plan, y, 0, relu=True)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3      # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--arch', default='squeezedet')
+    ap.add_argument('--batch', type=int, default=20)
+    ap.add_argument('--size', type=int, nargs=2, default=[384, 1248])
+    ap.add_argument('--out', default=os.path.join(ROOT, 'squeezedet-pytorch_amd', 'tuning.json'))
+    args = ap.parse_args()
+    B = args.batch
+    table = {}
+    if os.path.exists(args.out):
+        table = json.load(open(args.out))
+    tab = ops.cfg_table()
+    for taps, C, N, h, w in shapes(args.arch, B, *args.size):
+        res = []
+        for cid, (t, kc, px, bn) in tab.items():
+            if t != taps:
+                continue
+            if -(-N // bn) * bn > 2 * N and bn > 16:        # more than 2x channel padding: skip
+                continue
+            try:
+                res.append((time_cfg(taps, C, N, B, h, w, cid), cid))
+            except Exception as e:  # noqa: BLE001
+                print('skip', (taps, C, N, h, w), cid, e)
+        res.sort()
+        best_us, best = res[0]
+        gf = 2.0 * B * h * w * N * C * taps / 1e9
+        key = f'{taps}:{C}:{N}:{B * h * w}'
+        table[key] = {'cfg': best, 'us': round(best_us, 1), 'tflops': round(gf / best_us * 1e-3 * 1e3 / 1e3 * 1e3, 1) if False else round(gf / (best_us * 1e-6) / 1e3, 1),
+                      'all': {str(c): round(u, 1) for u, c in res}}
+        print(f'{key:24s} best cfg {best:2d} {tab[best]}  {best_us:8.1f} us  {gf / (best_us * 1e-6) / 1e3:6.1f} TF/s   '
+              + ' '.join(f'{c}:{u:.0f}' for u, c in res[:5]), flush=True)
+    json.dump(table, open(args.out, 'w'), indent=1, sort_keys=True)
+    print('wrote', args.out)
+
+
+if __name__ == '__main__':
+    main()
