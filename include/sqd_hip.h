@@ -61,6 +61,11 @@ int sqd_stem_wgrad(const float* dy_nhwc, const float* img_nchw, float* slab, flo
 int sqd_stem_conv_relu_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
                            int B, int Hin, int Win, int N, int ksize, void* stream);
 
+/* Fused features[0..2]: conv + ReLU + MaxPool2d(3,2,ceil_mode=True) (src/model/squeezedet.py:34-36 / :52-54)
+ * without materialising the conv output.  y: NHWC [B][Hp][Wp][N]; argmax (uint8, may be NULL) as below. */
+int sqd_stem_conv_relu_pool_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
+                                unsigned char* argmax, int B, int Hin, int Win, int N, int ksize, void* stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True) (src/model/squeezedet.py:36,39,42), NHWC.
  * argmax (uint8, same shape as y, may be NULL) records the window position 0..8 for the backward. */
 int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C,

@@ -31,6 +31,7 @@ _SIGNATURES = {
     'sqd_conv_wgrad': [c_p] * 5 + [c_i] * 11 + [c_p],
     'sqd_stem_wgrad': [c_p] * 5 + [c_i] * 6 + [c_p],
     'sqd_stem_conv_relu_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    'sqd_stem_conv_relu_pool_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_fwd': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_bwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_decode_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],

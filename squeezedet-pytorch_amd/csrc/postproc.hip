@@ -144,9 +144,25 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(DetArgs a) {
       if (tid < 256) hist[tid] = 0u;
       __syncthreads();
       const unsigned prefix = s_prefix;
-      for (int i = tid; i < A; i += DET_THREADS) {
-        const unsigned k = keys[i];
-        if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+      // scores cluster in very few exponent bins: in the two leading passes aggregate equal bins inside a
+      // wave (one atomic per distinct bin) instead of serialising up to 64 same-address LDS atomics
+      for (int i0 = 0; i0 < A; i0 += DET_THREADS) {
+        const int i = i0 + tid;
+        const unsigned k = (i < A) ? keys[i] : 0u;
+        const bool act = (i < A) && ((k & mask) == prefix);
+        const unsigned bin = (k >> shift) & 255u;
+        if (pass < 2) {
+          unsigned long long todo = __ballot(act);
+          while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned lb = __shfl(bin, leader);
+            const unsigned long long same = __ballot(act && bin == lb);
+            if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+            todo &= ~same;
+          }
+        } else if (act) {
+          atomicAdd(&hist[bin], 1u);
+        }
       }
       __syncthreads();
       if (tid == 0) {

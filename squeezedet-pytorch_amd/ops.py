@@ -235,6 +235,34 @@ def stem_conv_relu(image, weight, bias, out=None):
     return out
 
 
+def stem_pool(image, weight, bias, argmax=None):
+    """Fused conv(3->N,k,s2)+ReLU+MaxPool(3,2,ceil): NCHW image -> NHWC pooled features [B,Hp,Wp,N]."""
+    if image.dim() != 4 or image.shape[1] != 3 or image.dtype != torch.float32 or not image.is_cuda:
+        raise ValueError(f'stem_pool: image must be fp32 CUDA NCHW with 3 channels, got {tuple(image.shape)}')
+    image = image.contiguous()
+    N, ci, k, k2 = weight.shape
+    if ci != 3 or k != k2 or (k, N) not in ((3, 64), (7, 96)):
+        raise ValueError(f'stem_pool: unsupported weight {tuple(weight.shape)}')
+    B, _, H, W = image.shape
+    Ho, Wo = stem_out_size(H, W, k)
+    if Ho < 3 or Wo < 3:
+        raise ValueError('stem_pool: input too small')
+    Hp, Wp = pool_out_size(Ho, Wo)
+    out = torch.empty(B, Hp, Wp, N, device=image.device, dtype=torch.float32)
+    if argmax is not None and (tuple(argmax.shape) != (B, Hp, Wp, N) or argmax.dtype != torch.uint8):
+        raise ValueError('stem_pool: bad argmax tensor')
+    w = weight.detach().contiguous()
+    b = None if bias is None else bias.detach().contiguous()
+    br = _Bracket(f'stem_pool<{k}>', f'stem+pool {H}x{W}', 2.0 * B * Ho * Wo * N * 3 * k * k,
+                  4.0 * (B * 3 * H * W + B * Hp * Wp * N)) if _timer is not None else None
+    rc = nat.lib().sqd_stem_conv_relu_pool_fwd(nat.ptr(image), nat.ptr(w), nat.ptr(b), nat.ptr(out), nat.ptr(argmax), B, H, W, N, k,
+                                               nat.stream_handle(image.device))
+    nat.check(rc, 'sqd_stem_conv_relu_pool_fwd')
+    if br is not None:
+        br.done()
+    return out
+
+
 def pool_out_size(h, w):
     return (h - 3 + 1) // 2 + 1, (w - 3 + 1) // 2 + 1
 

@@ -117,3 +117,23 @@ def test_maxpool_fwd_bwd(C, H, W):
     assert torch.equal(y.cpu(), _nhwc(ref.detach()))            # max is exact
     dx = ops.maxpool_bwd(_nhwc(dy).cuda(), am, (H, W))
     assert (dx.cpu() - _nhwc(x.grad)).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("k,N,H,W", [(3, 64, 64, 96), (3, 64, 50, 70), (3, 64, 37, 45), (7, 96, 64, 96), (7, 96, 30, 50)])
+def test_fused_stem_pool(k, N, H, W):
+    ops = _ops()
+    x = _rand(2, 3, H, W, seed=21)
+    w = _rand(N, 3, k, k, seed=22, scale=(2.0 / (3 * k * k)) ** 0.5)
+    b = _rand(N, seed=23, scale=0.1)
+    conv = F.relu(F.conv2d(x, w, b, stride=2, padding=1 if k == 3 else 3))
+    ref, ridx = F.max_pool2d(conv, 3, 2, ceil_mode=True, return_indices=True)
+    am = torch.empty(*_nhwc(ref).shape, dtype=torch.uint8, device='cuda')
+    y = ops.stem_pool(x.cuda(), w.cuda(), b.cuda(), argmax=am)
+    assert tuple(y.shape) == tuple(_nhwc(ref).shape)
+    assert (y.cpu() - _nhwc(ref)).abs().max().item() <= _tol(ref)
+    # argmax consistent with the separate kernels (same window code 0..8)
+    y2 = ops.stem_conv_relu(x.cuda(), w.cuda(), b.cuda())
+    am2 = torch.empty_like(am)
+    p2 = ops.maxpool(y2, argmax=am2)
+    assert torch.equal(p2, y)
+    assert (am == am2).float().mean().item() > 0.999
