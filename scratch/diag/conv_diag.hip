@@ -384,7 +384,11 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#ifndef DIAG_NOSTORE
         *(f32x4*)dst = v;
+#else
+        if (v.x == 123.456f) *(f32x4*)dst = v;
+#endif
       }
     }
   };
@@ -395,7 +399,11 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
       if (pending >= 0) { flush(pending); pending = -1; }
       int ncc = cc + 1, ntile = tile;
       if (ncc == nchunks) { ncc = 0; ntile = tile + (int)gridDim.x; }
+#ifdef DIAG_NODMA
+      const bool has_next = false;
+#else
       const bool has_next = ntile < ntiles;
+#endif
       const bool next_w = has_next && !w_stationary;
       const TilePos ntp = tile_pos(has_next ? ntile : tile);
       const float* actT = actB + sbuf * ASLOTS * 4;

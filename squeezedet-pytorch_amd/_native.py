@@ -26,6 +26,7 @@ c_f = ctypes.c_float
 _SIGNATURES = {
     'sqd_conv_num_cfgs': [],
     'sqd_conv_cfg_info': [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
+    'sqd_conv_cfg_is_dma': [c_i],
     'sqd_conv_fwd': [c_p] * 7 + [c_i] * 19 + [c_p],
     'sqd_pack_conv_weight': [c_p, c_p] + [c_i] * 6 + [c_p],
     'sqd_conv_wgrad': [c_p] * 5 + [c_i] * 11 + [c_p],
@@ -103,11 +104,11 @@ def stream_handle(device=None):
 
 
 def conv_cfgs():
-    """[(cfg_id, taps, kc, tile_px, bn)] as compiled into the library."""
+    """[(cfg_id, taps, kc, tile_px, bn, is_dma)] as compiled into the library."""
     l = lib()
     out = []
     for i in range(l.sqd_conv_num_cfgs()):
         t, k, px, bn = c_i(), c_i(), c_i(), c_i()
         check(l.sqd_conv_cfg_info(i, ctypes.byref(t), ctypes.byref(k), ctypes.byref(px), ctypes.byref(bn)), 'sqd_conv_cfg_info')
-        out.append((i, t.value, k.value, px.value, bn.value))
+        out.append((i, t.value, k.value, px.value, bn.value, l.sqd_conv_cfg_is_dma(i)))
     return out

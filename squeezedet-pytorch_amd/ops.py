@@ -70,8 +70,18 @@ def cfg_table():
     """{cfg_id: (taps, kc, tile_px, bn)} from the compiled library."""
     global _CFG_TABLE
     if _CFG_TABLE is None:
-        _CFG_TABLE = {i: (t, k, px, bn) for i, t, k, px, bn in nat.conv_cfgs()}
+        rows = nat.conv_cfgs()
+        _CFG_TABLE = {i: (t, k, px, bn) for i, t, k, px, bn, _ in rows}
+        _CFG_DMA.update({i: bool(d) for i, _, _, _, _, d in rows})
     return _CFG_TABLE
+
+
+_CFG_DMA = {}
+
+
+def cfg_is_dma(cfg_id):
+    cfg_table()
+    return _CFG_DMA[cfg_id]
 
 
 _TUNING = None
@@ -102,7 +112,7 @@ def choose_cfg(taps, C, N, npix):
     want_kc = 16 if (taps == 9 or C <= 128 and C % 32 != 0 or C < 64) else 32
     best = None
     for cid, (t, kc, px, bn) in tab.items():
-        if t != taps:
+        if t != taps or _CFG_DMA.get(cid, False):
             continue
         slices = -(-N // bn)
         pad = slices * bn / N
@@ -171,6 +181,8 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
         raise ValueError('conv: channel window out of range')
     mp = 0
     if xmask is not None:
+        if cfg_is_dma(plan.cfg_id):
+            raise ValueError('conv: xmask needs a register-staged configuration')
         _check_nhwc(xmask, 'xmask')
         if tuple(xmask.shape[:3]) != (B, H, W) or xmask_coff + plan.C > xmask.shape[3]:
             raise ValueError('conv: xmask geometry mismatch')

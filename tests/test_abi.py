@@ -71,6 +71,7 @@ def test_status_codes_without_gpu():
     t, k, px, bn = (ctypes.c_int() for _ in range(4))
     assert lib.sqd_conv_cfg_info(0, ctypes.byref(t), ctypes.byref(k), ctypes.byref(px), ctypes.byref(bn)) == 0
     assert t.value in (1, 9) and k.value in (16, 32, 64) and px.value in (64, 128, 256) and bn.value % 16 == 0
+    assert lib.sqd_conv_cfg_is_dma(0) == 0 and lib.sqd_conv_cfg_is_dma(n) == -1
     assert lib.sqd_conv_cfg_info(n, None, None, None, None) == 1           # bad cfg id
     null = ctypes.c_void_p(0)
     assert lib.sqd_conv_fwd(null, null, null, null, null, null, null, 1, 1, 1, 4, 4, 0, 4, 16, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, null) == 1

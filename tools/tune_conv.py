@@ -68,6 +68,7 @@ def main():
     if os.path.exists(args.out):
         table = json.load(open(args.out))
     tab = ops.cfg_table()
+    print('configs:', {c: tab[c] + (ops.cfg_is_dma(c),) for c in tab})
     for taps, C, N, h, w in shapes(args.arch, B, *args.size):
         res = []
         for cid, (t, kc, px, bn) in tab.items():
