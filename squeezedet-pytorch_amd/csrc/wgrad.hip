@@ -24,18 +24,34 @@ struct WgradArgs {
   long long slab_stride;
 };
 
+// LDS tiles are pixel-major rows of exactly TN*16 (dY) / TC*16 (X) floats, filled by LDS-DMA
+// (global_load_lds_dwordx4: 64 consecutive 16-byte slots per wave instruction, arbitrary per-lane source,
+// out-of-range sources read a zero page) into a double buffer: the next pixel block streams in during the
+// MFMAs of the current one, one barrier per block.  When a row is a multiple of 32 floats the 16-byte
+// slot index is XOR-ed with 4*(pixel&1) so the two k-groups of a 32-lane half (adjacent pixels, same
+// channel) land in different banks for the ds_read_b32 operand fetches; other row lengths are = 16 (mod 32)
+// floats and need no swizzle.  With TN a multiple of 4 every wave owns whole out-channel tiles and its
+// dY operand is fetched once per k-step for all taps / in-channel tiles.
+__device__ __attribute__((aligned(16))) float sqd_wg_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
+
 template <int TAPS, int TN, int TC, int TH>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int PB = TH * 16;                                 // pixels per block
-  constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16);           // dY tile pitch  (= 16 mod 32)
-  constexpr int PC = TC * 16 + ((TC & 1) ? 0 : 16);           // X tile pitch   (= 16 mod 32)
+  constexpr int RN = TN * 4, RC = TC * 4;                     // 16-byte slots per row
+  constexpr bool SWN = (RN % 8) == 0, SWC = (RC % 8) == 0;    // row = multiple of 32 floats -> swizzle
   constexpr int XPIX = (TAPS == 9) ? (TH + 2) * 18 : PB;
+  constexpr int DSLOTS = (PB * RN + 255) & ~255, XSLOTS = (XPIX * RC + 255) & ~255;
+  constexpr int D_IT = DSLOTS / 256, X_IT = XSLOTS / 256;
+  constexpr bool SHARED = (TN % 4) == 0;                      // wave w owns n-tiles w, w+4, ...
+  constexpr int NU = SHARED ? TN / 4 : 1;
   constexpr int TILES = TN * TC * TAPS;
-  constexpr int NACC = (TILES + 3) / 4;
+  constexpr int NACC = SHARED ? NU * TC * TAPS : (TILES + 3) / 4;
   constexpr int BACC = (TN + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* dyT = smem;                 // [PB][PN]
-  float* xT = smem + PB * PN;        // [XPIX][PC]
+  // layout: dy[0], dy[1], x[0], x[1]
+  float* const dyB = smem;
+  float* const xB = smem + 2 * DSLOTS * 4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, kq = lane >> 4;
@@ -43,22 +59,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int n0 = ng * TN * 16, c0 = cg * TC * 16;
   const bool do_bias = (cg == 0);
 
-  f32x4 acc[NACC], bacc[BACC];
-  int aoff[NACC], boff[NACC];
+  // block-independent decode of this lane's DMA slots
+  int d_pix[D_IT], d_ch[D_IT], x_pix[X_IT], x_ch[X_IT];
 #pragma unroll
-  for (int i = 0; i < NACC; ++i) {
-    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int t = wave + 4 * i;
-    if (t >= TILES) t = TILES - 1;                             // harmless duplicate, never stored
-    const int ct = t % TC, tap = (t / TC) % TAPS, nt = t / (TC * TAPS);
-    aoff[i] = nt * 16 + lr;
-    boff[i] = ((TAPS == 9) ? ((tap / 3) * 18 + tap % 3) : 0) * PC + ct * 16 + lr;
+  for (int it = 0; it < D_IT; ++it) {
+    const int slot = it * 256 + tid;
+    const int pix = slot / RN, qp = slot - pix * RN;
+    const int q = SWN ? (qp ^ ((pix & 1) << 2)) : qp;
+    d_pix[it] = (pix < PB) ? pix : -1;
+    d_ch[it] = n0 + 4 * q;
   }
 #pragma unroll
-  for (int i = 0; i < BACC; ++i) bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < X_IT; ++it) {
+    const int slot = it * 256 + tid;
+    const int pix = slot / RC, qp = slot - pix * RC;
+    const int q = SWC ? (qp ^ ((pix & 1) << 2)) : qp;
+    x_pix[it] = (pix < XPIX) ? pix : -1;
+    x_ch[it] = c0 + 4 * q;
+  }
 
-  bool first = true;
-  for (int pb = blockIdx.x; pb < a.nblocks; pb += gridDim.x) {
+  auto dma_block = [&](int pb, int buf) {
     int b = 0, y0 = 0, x0 = 0;
     long long p0 = 0;
     if (TAPS == 9) {
@@ -69,13 +89,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     } else {
       p0 = (long long)pb * PB;
     }
-    if (!first) __syncthreads();
-    first = false;
-    // stage dY tile (zero outside the image / beyond N)
-    for (int idx = tid; idx < PB * TN * 4; idx += 256) {
-      const int pix = idx / (TN * 4), v = idx - pix * (TN * 4);
-      const int n = n0 + 4 * v;
-      long long gp; bool ok = n < a.N;
+#pragma unroll
+    for (int it = 0; it < D_IT; ++it) {
+      const int pix = d_pix[it];
+      bool ok = pix >= 0 && d_ch[it] < a.N;
+      long long gp;
       if (TAPS == 9) {
         const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
         ok = ok && iy < a.H && ix < a.W;
@@ -83,15 +101,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       } else {
         gp = p0 + pix; ok = ok && gp < a.total_px;
       }
-      f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (ok) val = *(const f32x4*)(a.dy + gp * a.dy_pitch + a.dy_coff + n);
-      *(f32x4*)(dyT + pix * PN + 4 * v) = val;
+      const float* src = ok ? a.dy + gp * a.dy_pitch + a.dy_coff + d_ch[it] : sqd_wg_zero_page;
+      __builtin_amdgcn_global_load_lds(src, (wg_lds_ptr_t)(dyB + (buf * DSLOTS + it * 256 + wave * 64) * 4), 16, 0, 0);
     }
-    // stage X tile (3x3: with a 1-pixel halo)
-    for (int idx = tid; idx < XPIX * TC * 4; idx += 256) {
-      const int pix = idx / (TC * 4), v = idx - pix * (TC * 4);
-      const int c = c0 + 4 * v;
-      long long gp; bool ok = c < a.C;
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int pix = x_pix[it];
+      bool ok = pix >= 0 && x_ch[it] < a.C;
+      long long gp;
       if (TAPS == 9) {
         const int r = pix / 18, col = pix - r * 18;
         const int iy = y0 + r - 1, ix = x0 + col - 1;
@@ -100,37 +117,91 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       } else {
         gp = p0 + pix; ok = ok && gp < a.total_px;
       }
-      f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (ok) val = *(const f32x4*)(a.x + gp * a.x_pitch + a.x_coff + c);
-      *(f32x4*)(xT + pix * PC + 4 * v) = val;
+      const float* src = ok ? a.x + gp * a.x_pitch + a.x_coff + x_ch[it] : sqd_wg_zero_page;
+      __builtin_amdgcn_global_load_lds(src, (wg_lds_ptr_t)(xB + (buf * XSLOTS + it * 256 + wave * 64) * 4), 16, 0, 0);
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int s = 0; s < TH * 4; ++s) {
-      const int r = s >> 2, cq = s & 3;
-      const int pixA = r * 16 + cq * 4 + kq;
-      const int pixB = (TAPS == 9) ? r * 18 + cq * 4 + kq : pixA;
-      const float* ap = dyT + pixA * PN;
-      const float* bp = xT + pixB * PC;
+  };
+
+  f32x4 acc[NACC], bacc[BACC];
+  // Per-lane LDS float offsets, computed ONCE: in every k-step the pixel index is (compile-time part) + kq
+  // (+ the tap shift), and because row strides / tap shifts (18*dy + dx) / 4*cq are even except dx, the
+  // swizzle parity is (kq + dx) & 1 -- constant per lane and tile.  The unrolled loop then addresses LDS as
+  // lane_offset + immediate with no VALU arithmetic per MFMA.
+  const int swA = SWN ? ((kq & 1) << 4) : 0;
+  int al[NACC], bl[NACC], abias[BACC];
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) acc[i] = mfma16(ap[aoff[i]], bp[boff[i]], acc[i]);
+  for (int i = 0; i < NACC; ++i) {
+    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int nt, ct, tap;
+    if (SHARED) {
+      const int u = i / (TC * TAPS), rem = i - u * (TC * TAPS);
+      nt = wave + 4 * u; tap = rem / TC; ct = rem - tap * TC;
+    } else {
+      int t = wave + 4 * i;
+      if (t >= TILES) t = TILES - 1;                           // harmless duplicate, never stored
+      ct = t % TC; tap = (t / TC) % TAPS; nt = t / (TC * TAPS);
+    }
+    const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+    const int swB = SWC ? (((kq + dx) & 1) << 4) : 0;
+    al[i] = kq * (RN * 4) + ((nt * 16 + lr) ^ swA);
+    bl[i] = (kq + dy * 18 + dx) * (RC * 4) + ((ct * 16 + lr) ^ swB);
+  }
+#pragma unroll
+  for (int i = 0; i < BACC; ++i) {
+    bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int bt = (wave + 4 * i < TN) ? wave + 4 * i : 0;
+    abias[i] = kq * (RN * 4) + ((bt * 16 + lr) ^ swA);
+  }
+
+  int pb = blockIdx.x, buf = 0;
+  if (pb < a.nblocks) dma_block(pb, 0);
+  for (; pb < a.nblocks; pb += (int)gridDim.x) {
+    __syncthreads();                   // vmcnt(0) + barrier: this block's tiles landed, previous compute finished
+    const int nxt = pb + (int)gridDim.x;
+    if (nxt < a.nblocks) dma_block(nxt, buf ^ 1);
+    const float* dyT = dyB + buf * DSLOTS * 4;
+    const float* xT = xB + buf * XSLOTS * 4;
+#pragma unroll
+    for (int s = 0; s < TH * 4; ++s) {
+      constexpr int dummy = 0; (void)dummy;
+      const int r = s >> 2, cq = s & 3;
+      const int immA = (r * 16 + cq * 4) * (RN * 4);           // compile-time after unrolling
+      const int immB = ((TAPS == 9) ? (r * 18 + cq * 4) : (r * 16 + cq * 4)) * (RC * 4);
+      if (SHARED) {
+        float av[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) av[u] = dyT[al[u * TC * TAPS] + immA];
+#pragma unroll
+        for (int j = 0; j < TC * TAPS; ++j) {
+          const float bv = xT[bl[j] + immB];
+#pragma unroll
+          for (int u = 0; u < NU; ++u) acc[u * TC * TAPS + j] = mfma16(av[u], bv, acc[u * TC * TAPS + j]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = mfma16(dyT[al[i] + immA], xT[bl[i] + immB], acc[i]);
+      }
       if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < BACC; ++i) {
-          const int bt = (wave + 4 * i < TN) ? wave + 4 * i : 0;
-          bacc[i] = mfma16(ap[bt * 16 + lr], 1.0f, bacc[i]);
-        }
+        for (int i = 0; i < BACC; ++i) bacc[i] = mfma16(dyT[abias[i] + immA], 1.0f, bacc[i]);
       }
     }
+    buf ^= 1;
   }
 
   // one slab per blockIdx.x; layout [n][tap][c] then [N] bias sums
   float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
-    const int t = wave + 4 * i;
-    if (t >= TILES) continue;
-    const int ct = t % TC, tap = (t / TC) % TAPS, nt = t / (TC * TAPS);
+    int nt, ct, tap;
+    if (SHARED) {
+      const int u = i / (TC * TAPS), rem = i - u * (TC * TAPS);
+      nt = wave + 4 * u; tap = rem / TC; ct = rem - tap * TC;
+    } else {
+      const int t = wave + 4 * i;
+      if (t >= TILES) continue;
+      ct = t % TC; tap = (t / TC) % TAPS; nt = t / (TC * TAPS);
+    }
     const int c = c0 + ct * 16 + lr;
     if (c >= a.C) continue;
 #pragma unroll
@@ -153,31 +224,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// dw (OIHW: [N][C][TAPS]) and db ([N]) = fixed-order sum of S slabs
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                           float* __restrict__ db, int S, long long slab_stride,
-                                                           int N, int C, int TAPS) {
+// dw (OIHW: [N][C][TAPS]) and db ([N]) = fixed-order sum of S slabs.  A block reduces 32 consecutive
+// outputs; its 8 thread groups each sum the slabs k = g, g+8, ... in ascending order, then the 8 partials
+// are combined in a fixed order through LDS -- parallel over slabs yet bitwise reproducible.
+#define WGR_OUT 32
+#define WGR_PARTS 8
+__global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                           float* __restrict__ db, int S, long long slab_stride,
+                                                                           int N, int C, int TAPS) {
+  __shared__ float red[WGR_PARTS][WGR_OUT];
   const long long nw = (long long)N * TAPS * C;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nw + N) return;
+  const int o = threadIdx.x & (WGR_OUT - 1), part = threadIdx.x / WGR_OUT;
+  const long long idx = (long long)blockIdx.x * WGR_OUT + o;
+  const bool live = idx < nw + N;
   float s = 0.f;
-  for (int k = 0; k < S; ++k) s += slab[(long long)k * slab_stride + idx];
+  if (live) {
+#pragma unroll 8
+    for (int k = part; k < S; k += WGR_PARTS) s += slab[(long long)k * slab_stride + idx];
+  }
+  red[part][o] = s;
+  __syncthreads();
+  if (part != 0 || !live) return;
+  float t = red[0][o];
+#pragma unroll
+  for (int p = 1; p < WGR_PARTS; ++p) t += red[p][o];
   if (idx < nw) {
-    const int c = (int)(idx % C); const long long t = idx / C;
-    const int tap = (int)(t % TAPS); const int n = (int)(t / TAPS);
-    dw[((long long)n * C + c) * TAPS + tap] = s;
+    const int c = (int)(idx % C); const long long q = idx / C;
+    const int tap = (int)(q % TAPS); const int n = (int)(q / TAPS);
+    dw[((long long)n * C + c) * TAPS + tap] = t;
   } else if (db) {
-    db[idx - nw] = s;
+    db[idx - nw] = t;
   }
 }
 
 template <int TAPS, int TN, int TC, int TH>
 static int launch_wgrad(WgradArgs a, int S, hipStream_t stream) {
   constexpr int PB = TH * 16;
-  constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16), PC = TC * 16 + ((TC & 1) ? 0 : 16);
   constexpr int XPIX = (TAPS == 9) ? (TH + 2) * 18 : PB;
-  constexpr size_t lds = (size_t)(PB * PN + XPIX * PC) * sizeof(float);
-  static_assert(lds <= 64 * 1024, "wgrad LDS budget");
+  constexpr int DSLOTS = (PB * TN * 4 + 255) & ~255, XSLOTS = (XPIX * TC * 4 + 255) & ~255;
+  constexpr size_t lds = (size_t)(2 * DSLOTS + 2 * XSLOTS) * 16;
+  static_assert(lds <= 160 * 1024, "wgrad LDS budget");
+  auto kern = conv_wgrad_kernel<TAPS, TN, TC, TH>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SQD_ERR_LAUNCH;
   if (TAPS == 9) {
     a.tiles_x = sqd_cdiv(a.W, 16); a.tiles_y = sqd_cdiv(a.H, TH);
     a.nblocks = a.B * a.tiles_x * a.tiles_y;
@@ -187,8 +277,7 @@ static int launch_wgrad(WgradArgs a, int S, hipStream_t stream) {
   }
   a.n_groups = sqd_cdiv(a.N, TN * 16);
   const int c_groups = sqd_cdiv(a.C, TC * 16);
-  hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, TN, TC, TH>), dim3((unsigned)S, (unsigned)(a.n_groups * c_groups)), dim3(256), lds,
-                     stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)S, (unsigned)(a.n_groups * c_groups)), dim3(256), lds, stream, a);
   return sqd_launch_status();
 }
 
@@ -209,13 +298,17 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
   a.slab_stride = (long long)N * taps * C + N;
   hipStream_t s = (hipStream_t)stream;
   const int tn = N >= 64 ? 4 : sqd_cdiv(N, 16);
-  const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
   int rc = SQD_ERR_UNSUPPORTED;
   if (taps == 9) {
-    if (N > 64 && N <= 80) rc = launch_wgrad<9, 5, 1, 8>(a, S, s);      // ConvDet (N = 72)
-    else rc = launch_wgrad<9, 4, 1, 8>(a, S, s);
+    if (N > 64 && N <= 80) rc = launch_wgrad<9, 5, 1, 4>(a, S, s);      // ConvDet (N = 72)
+    else if (C % 32 == 0 && tn == 4) rc = launch_wgrad<9, 4, 2, 4>(a, S, s);
+    else if (tn == 4) rc = launch_wgrad<9, 4, 1, 4>(a, S, s);
+    else if (tn == 1) rc = launch_wgrad<9, 1, 2, 4>(a, S, s);
+    else if (tn == 2) rc = launch_wgrad<9, 2, 2, 4>(a, S, s);
+    else rc = launch_wgrad<9, 3, 1, 4>(a, S, s);
   } else {
-#define SQD_WG_CASE(TNv, TCv) if (tn == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, 4>(a, S, s);
+    const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
+#define SQD_WG_CASE(TNv, TCv) if (tn == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, 8>(a, S, s);
     SQD_WG_CASE(1, 1) SQD_WG_CASE(1, 2) SQD_WG_CASE(1, 3) SQD_WG_CASE(1, 4)
     SQD_WG_CASE(2, 1) SQD_WG_CASE(2, 2) SQD_WG_CASE(2, 3) SQD_WG_CASE(2, 4)
     SQD_WG_CASE(3, 1) SQD_WG_CASE(3, 2) SQD_WG_CASE(3, 3) SQD_WG_CASE(3, 4)
@@ -224,8 +317,8 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
   }
   if (rc != SQD_OK) return rc;
   const long long outs = a.slab_stride;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, s, slab, dw, db, S, a.slab_stride,
-                     N, C, taps);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs + WGR_OUT - 1) / WGR_OUT)), dim3(WGR_OUT * WGR_PARTS), 0, s, slab, dw, db, S,
+                     a.slab_stride, N, C, taps);
   return sqd_launch_status();
 }
 
@@ -256,8 +349,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
   const int lr = lane & 15, kq = lane >> 4;
 
   f32x4 acc[NACC], bacc[BACC];
-  int aoff[NACC], boff[NACC];
-  bool bok[NACC];
+  // per-lane LDS offsets computed once; the unrolled k-loop adds compile-time immediates only.  Padded im2col
+  // columns (k >= K) read a valid address (offset 0 of the patch); their products land in columns of D that are
+  // never stored, so no zero slot is needed on this side.
+  int al[NACC], bl[NACC], abias[BACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
     acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -266,12 +361,15 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
     const int kt = t % KT, nt = t / KT;
     const int k = kt * 16 + lr;                                 // this lane's im2col column
     const int ci = k / (KS * KS), rem = k - ci * (KS * KS), ky = rem / KS, kx = rem - ky * KS;
-    aoff[i] = nt * 16 + lr;
-    bok[i] = k < K;
-    boff[i] = bok[i] ? (ci * IH + ky) * IWP + kx : 0;
+    al[i] = kq * PN + nt * 16 + lr;
+    bl[i] = 2 * kq + ((k < K) ? (ci * IH + ky) * IWP + kx : 0);
   }
 #pragma unroll
-  for (int i = 0; i < BACC; ++i) bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < BACC; ++i) {
+    bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int bt = (wave + 4 * i < TN) ? wave + 4 * i : 0;
+    abias[i] = kq * PN + bt * 16 + lr;
+  }
 
   bool first = true;
   for (int pb = blockIdx.x; pb < a.nblocks; pb += gridDim.x) {
@@ -295,21 +393,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
       if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) v = a.img[(((long long)b * 3 + ci) * a.Hin + iy) * a.Win + ix];
       inT[(ci * IH + r) * IWP + c] = v;
     }
-    if (tid == 0) inT[NIN] = 0.f;
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
     for (int s = 0; s < TH * 4; ++s) {
       const int r = s >> 2, cq = s & 3;
-      const int col = cq * 4 + kq;
-      const float* ap = dyT + (r * 16 + col) * PN;
-      const int pbase = (2 * r) * IWP + 2 * col;
+      const int immA = (r * 16 + cq * 4) * PN;                  // compile-time after unrolling
+      const int immB = (2 * r) * IWP + 8 * cq;
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) acc[i] = mfma16(ap[aoff[i]], inT[bok[i] ? pbase + boff[i] : NIN], acc[i]);
+      for (int i = 0; i < NACC; ++i) acc[i] = mfma16(dyT[al[i] + immA], inT[bl[i] + immB], acc[i]);
 #pragma unroll
-      for (int i = 0; i < BACC; ++i) {
-        const int bt = (wave + 4 * i < TN) ? wave + 4 * i : 0;
-        bacc[i] = mfma16(ap[bt * 16 + lr], 1.0f, bacc[i]);
-      }
+      for (int i = 0; i < BACC; ++i) bacc[i] = mfma16(dyT[abias[i] + immA], 1.0f, bacc[i]);
     }
   }
   float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
@@ -375,7 +468,7 @@ extern "C" int sqd_stem_wgrad(const float* dy, const float* img, float* slab, fl
   }
   if (rc != SQD_OK) return rc;
   // slab layout [n][K] is already OIHW-flat: reduce with C := K, TAPS := 1
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.slab_stride + 255) / 256)), dim3(256), 0, s, slab, dw, db, S,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.slab_stride + WGR_OUT - 1) / WGR_OUT)), dim3(WGR_OUT * WGR_PARTS), 0, s, slab, dw, db, S,
                      a.slab_stride, N, K, 1);
   return sqd_launch_status();
 }

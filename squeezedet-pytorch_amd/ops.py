@@ -399,15 +399,21 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps):
     if dy_coff + N > dyp or x_coff + C > xp or N % 4 or C % 4 or taps not in (1, 9):
         raise ValueError('wgrad: channel window out of range')
     k = 3 if taps == 9 else 1
+    tn = 4 if N >= 64 else -(-N // 16)
     if taps == 9:
-        tn = 5 if 64 < N <= 80 else 4
-        groups = -(-N // (tn * 16)) * -(-C // 16)
-        nblocks = B * -(-H // 8) * -(-W // 16)
+        if 64 < N <= 80:
+            tn, tc = 5, 1
+        elif tn == 4:
+            tc = 2 if C % 32 == 0 else 1
+        elif tn in (1, 2):
+            tc = 2
+        else:
+            tc = 1
+        nblocks = B * -(-H // 4) * -(-W // 16)
     else:
-        tn = 4 if N >= 64 else -(-N // 16)
         tc = 4 if C >= 64 else -(-C // 16)
-        groups = -(-N // (tn * 16)) * -(-C // (tc * 16))
-        nblocks = -(-(B * H * W) // 64)
+        nblocks = -(-(B * H * W) // 128)
+    groups = -(-N // (tn * 16)) * -(-C // (tc * 16))
     S = max(1, min(nblocks, _TARGET_WGS // groups, 256))
     stride = N * taps * C + N
     slab = torch.empty(S * stride, device=dy.device, dtype=torch.float32)
