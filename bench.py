@@ -25,7 +25,7 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (spec)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-FWD_GFLOP_PER_IMAGE = 10.566       # SURVEY.md section 8d / BASELINE.md section 3 (2*MAC, convs only)
+FWD_GFLOP_PER_IMAGE = {'squeezedet': 10.566, 'squeezedetplus': 83.386}   # SURVEY.md 8d / BASELINE.md 3 (2*MAC, convs only)
 
 
 def parse():
@@ -33,10 +33,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=20, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=0, help='images per GPU per step (default 20; 16 for squeezedetplus)')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
     ap.add_argument('--arch', default='squeezedet')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
     return ap.parse_args()
 
@@ -78,13 +79,20 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == 'nccl':
+        raise SystemExit(f'LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible')
+    dev_index = local_rank % max(ndev, 1)      # == local_rank except in a gloo rehearsal on fewer GPUs
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import squeezedet_pytorch_amd as sqd
     from squeezedet_pytorch_amd import ops, synthetic
@@ -93,7 +101,7 @@ def main():
 
     cfg = sqd.make_cfg(arch=args.arch, device=dev)
     sd = synthetic.make_state_dict(args.arch, seed=1234)
-    B = args.batch
+    B = args.batch if args.batch > 0 else (16 if args.arch == 'squeezedetplus' else 20)
     x = synthetic.make_images(B, cfg.input_size, seed=rank).to(dev)
 
     if args.mode == 'train':
@@ -107,7 +115,8 @@ def main():
 
         def step():
             return det.detect_device(x, out=out_bufs)
-        describe = 'SqueezeDet KITTI 1248x384 bs=20 inference on 1 MI355X (Fire+ConvDet HIP kernels, fused NMS)'
+        describe = ('SqueezeDet KITTI 1248x384 bs=20 inference on 1 MI355X (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
+                    else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on 1 MI355X')
 
     def barrier():
         if dist is not None:
@@ -157,7 +166,7 @@ def main():
     dominant = max(summ.items(), key=lambda kv: kv[1]['ms'])[0] if summ else None
 
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -184,9 +193,9 @@ def main():
                          'algorithmic_per_launch': {'gflop': round(flops_per_launch / 1e9, 3), 'mbytes': round(bytes_per_launch / 1e6, 3)},
                          'share_of_step': round(d['ms'] / nprof / (elapsed / args.steps * 1e3), 3),
                          'how': f'HIP events around every launch of {nprof} eager steps enqueued behind the timed region'})
-        whole = {'tflops': round(value * FWD_GFLOP_PER_IMAGE / 1e3, 2),
-                 'frac_of_fp32_mfma_peak': round(value / world * FWD_GFLOP_PER_IMAGE / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)} \
-            if args.arch == 'squeezedet' and args.mode == 'infer' else None
+        gf = FWD_GFLOP_PER_IMAGE[args.arch]
+        whole = {'tflops': round(value * gf / 1e3, 2),
+                 'frac_of_fp32_mfma_peak': round(value / world * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)} if args.mode == 'infer' else None
         kernels = {k: {'ms_per_step': round(v['ms'] / nprof, 4),
                        'launches_per_step': v['launches'] // nprof,
                        'tflops': round(v['flops'] / (v['ms'] / 1e3) / 1e12, 2) if v['ms'] > 0 else 0,
@@ -196,7 +205,7 @@ def main():
         if not args.no_cpu_baseline and args.mode == 'infer':
             cpu = cpu_baseline(cfg, sd, B)
         line = {
-            'metric': 'images/sec SqueezeDet 1248x384 bs=20 ' + ('inference' if args.mode == 'infer' else 'training'),
+            'metric': f'images/sec {"SqueezeDet" if args.arch == "squeezedet" else "SqueezeDet+"} 1248x384 bs={B} ' + ('inference' if args.mode == 'infer' else 'training'),
             'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

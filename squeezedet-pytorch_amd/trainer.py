@@ -185,6 +185,6 @@ def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1):
         opt.step()
         return loss
 
-    desc = (f'SqueezeDet KITTI 1248x384 bs={image.shape[0]}/GPU training: fwd + multi-task loss + bwd + clip(5.0) + SGD'
+    desc = (f'{"SqueezeDet" if cfg.arch == "squeezedet" else "SqueezeDet+"} KITTI 1248x384 bs={image.shape[0]}/GPU training: fwd + multi-task loss + bwd + clip(5.0) + SGD'
             + (f' + RCCL grad all-reduce over {world} GPUs' if world > 1 else ''))
     return step, desc
