@@ -28,6 +28,17 @@ PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3
 FWD_GFLOP_PER_IMAGE = {'squeezedet': 10.566, 'squeezedetplus': 83.386}   # SURVEY.md 8d / BASELINE.md 3 (2*MAC, convs only)
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/traffic.json, written by
+    scratch/traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for gfx950), or None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            t = json.load(f)
+        return int(t[kernel]['hbm_bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -188,6 +199,7 @@ def main():
                 ach = bytes_per_launch / avg_s / 1e9
                 roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
+            roof['traffic'] = measured_traffic(dominant)
             roof.update({'kernel': dominant, 'launches_per_step': d['launches'] // nprof,
                          'avg_launch_us': round(avg_s * 1e6, 2),
                          'algorithmic_per_launch': {'gflop': round(flops_per_launch / 1e9, 3), 'mbytes': round(bytes_per_launch / 1e6, 3)},

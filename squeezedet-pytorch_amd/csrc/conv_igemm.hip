@@ -37,6 +37,7 @@ struct ConvArgs {
   int N, Npad, y_pitch, y_coff;
   int relu, accumulate;
   int tiles_x, tiles_y, ntiles;
+  int nslices, gx;                           // persistent grid: gx tile streams x nslices channel slices (1-D launch)
   int xmask_pitch, xmask_coff;
   const float* ymask; const float* ymul;      // epilogue: zero where ymask <= 0 (ReLU backward), multiply by ymul (dropout)
   int ymask_pitch, ymask_coff, ymul_pitch, ymul_coff;
@@ -65,11 +66,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware mapping (workgroups b and b+8 share an XCD and its L2): the channel slices of one tile stream get
+  // consecutive ids on the SAME XCD, so they run together and re-read their activation tiles from that L2
+  const int wgq = (int)blockIdx.x >> 3;
+  const int n0 = (wgq % a.nslices) * BN;
+  const int tstride = a.gx;
   const int nchunks = (a.C + KC - 1) / KC;
   const bool w_stationary = (nchunks == 1);   // whole K fits one chunk: weights stay in LDS across tiles
   const int ntiles = a.ntiles;
-  int tile = blockIdx.x;
+  int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
   if (tile >= ntiles) return;
 
   f32x4 ra[A_IT], rw[W_IT];
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     for (int cc = 0; cc < nchunks; ++cc) {
       // ---- prefetch the next stage (next K chunk, or chunk 0 of this workgroup's next tile) ----
       int ncc = cc + 1, ntile = tile;
-      if (ncc == nchunks) { ncc = 0; ntile = tile + (int)gridDim.x; }
+      if (ncc == nchunks) { ncc = 0; ntile = tile + tstride; }
       const bool has_next = ntile < ntiles;
       const bool next_w = has_next && !w_stationary;
       if (has_next) load_act(ntile, ncc);
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
       if (next_w) store_w();
       __syncthreads();
     }
-    tile += (int)gridDim.x;
+    tile += tstride;
     if (tile >= ntiles) break;
   }
 }
@@ -280,11 +285,14 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware mapping: see conv_igemm_kernel
+  const int wgq = (int)blockIdx.x >> 3;
+  const int n0 = (wgq % a.nslices) * BN;
+  const int tstride = a.gx;
   const int nchunks = (a.C + KC - 1) / KC;
   const bool w_stationary = (nchunks == 1);
   const int ntiles = a.ntiles;
-  int tile = blockIdx.x;
+  int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
   if (tile >= ntiles) return;
 
   // tile-independent part of every lane's DMA slots
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
       __syncthreads();                 // vmcnt(0): this stage's DMA has landed; all waves left the previous stage
       if (pending >= 0) { flush(pending); pending = -1; }
       int ncc = cc + 1, ntile = tile;
-      if (ncc == nchunks) { ncc = 0; ntile = tile + (int)gridDim.x; }
+      if (ncc == nchunks) { ncc = 0; ntile = tile + tstride; }
       const bool has_next = ntile < ntiles;
       const bool next_w = has_next && !w_stationary;
       const TilePos ntp = tile_pos(has_next ? ntile : tile);
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
       sbuf ^= 1;
       if (!w_stationary) wbuf ^= 1;
     }
-    tile += (int)gridDim.x;
+    tile += tstride;
     if (tile >= ntiles) break;
   }
   if (pending >= 0) flush(pending);
@@ -495,8 +503,9 @@ static int launch_conv(ConvArgs a, hipStream_t stream) {
   const int slots = sqd_num_cus() * wgs_per_cu;
   int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
   const int per_wg = sqd_cdiv(a.ntiles, gx_max);
-  const int gx = sqd_cdiv(a.ntiles, per_wg);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(256), lds, stream, a);
+  const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;        // tile streams, a multiple of 8 (one per XCD lane)
+  a.nslices = nslices; a.gx = gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx * nslices)), dim3(256), lds, stream, a);
   return sqd_launch_status();
 }
 
@@ -537,8 +546,9 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   const int slots = sqd_num_cus() * wgs_per_cu[stationary];
   int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
   const int per_wg = sqd_cdiv(a.ntiles, gx_max);
-  const int gx = sqd_cdiv(a.ntiles, per_wg);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(256), lds, stream, a);
+  const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;        // tile streams, a multiple of 8 (one per XCD lane)
+  a.nslices = nslices; a.gx = gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx * nslices)), dim3(256), lds, stream, a);
   return sqd_launch_status();
 }
 
@@ -654,7 +664,7 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.xmask = xmask;
   a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff;
-  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0;
+  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8;
   a.xmask_pitch = xmask_pitch; a.xmask_coff = xmask_coff;
   a.total_px = (long long)B * H * W;
   hipStream_t s = (hipStream_t)stream;

@@ -203,7 +203,7 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
     br = None
     if _timer is not None:
         npix = B * H * W
-        br = _Bracket(f'conv_igemm<{plan.taps},{plan.kc},{cfg_table()[plan.cfg_id][2] // 64},{plan.bn // 16}>',
+        br = _Bracket(f'{"conv_dma" if cfg_is_dma(plan.cfg_id) else "conv_igemm"}<{plan.taps},{plan.kc},{cfg_table()[plan.cfg_id][2] // 64},{plan.bn // 16}>',
                       f'{plan.taps}tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * plan.taps,
                       4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * plan.taps))
     rc = nat.lib().sqd_conv_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(xmask),
