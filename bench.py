@@ -122,7 +122,7 @@ def main():
         model = SqueezeDet(cfg)
         model.load_state_dict(sd)
         det = Detector(model, cfg)
-        out_bufs = ops._det_buffers(B, cfg.keep_top_k, dev)
+        out_bufs = ops._det_buffers(B, cfg.keep_top_k, dev, cfg.num_anchors)
 
         def step():
             return det.detect_device(x, out=out_bufs)

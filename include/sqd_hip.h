@@ -87,14 +87,15 @@ int sqd_decode_fwd(const float* pred, const float* anchors, long long* class_ids
  * the scale division of boxes_postprocess, src/utils/boxes.py:145-147): top keep_top_k (<= 64) by score,
  * class-wise NMS, score threshold, compacted in class order.  Fixed-capacity outputs [B][keep_top_k];
  * det_count[b] rows are valid.  det_anchor = anchor index of every kept detection (not returned by the
- * reference; this is what "box indices bit-exact" is asserted on).  scales [B][2]=(sy,sx) or NULL. */
-int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, int* det_count,
+ * reference; this is what "box indices bit-exact" is asserted on).  scales [B][2]=(sy,sx) or NULL.
+ * keys_ws: workspace of B*A uint32 (per-anchor score keys written by the first of the two launches). */
+int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, unsigned* keys_ws, int* det_count,
                    long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
                    int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
                    float score_thresh, void* stream);
 
 /* Detector.filter on already decoded dense tensors (class_ids int64 [B][A], scores [B][A], boxes [B][A][4]). */
-int sqd_filter_fwd(const long long* class_ids, const float* scores, const float* boxes, int* det_count,
+int sqd_filter_fwd(const long long* class_ids, const float* scores, const float* boxes, unsigned* keys_ws, int* det_count,
                    long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
                    int num_classes, int keep_top_k, float nms_thresh, float score_thresh, void* stream);
 

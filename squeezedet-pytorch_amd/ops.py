@@ -336,10 +336,14 @@ def decode(pred, anchors, input_size, num_classes):
     return ids, scores, boxes
 
 
-def _det_buffers(B, K, device):
-    return (torch.zeros(B, device=device, dtype=torch.int32), torch.zeros(B, K, device=device, dtype=torch.int64),
+def _det_buffers(B, K, device, A=None):
+    """(count, class_ids, scores, boxes, anchor_idx[, keys workspace]) for the fused detection kernels."""
+    bufs = (torch.zeros(B, device=device, dtype=torch.int32), torch.zeros(B, K, device=device, dtype=torch.int64),
             torch.zeros(B, K, device=device, dtype=torch.float32), torch.zeros(B, K, 4, device=device, dtype=torch.float32),
             torch.zeros(B, K, device=device, dtype=torch.int32))
+    if A is not None:
+        bufs = bufs + (torch.empty(B * A, device=device, dtype=torch.int32),)
+    return bufs
 
 
 def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3, scales=None, out=None):
@@ -353,17 +357,21 @@ def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4
         raise ValueError('detect: anchors must be fp32 [A,4] on the same device')
     if scales is not None and (tuple(scales.shape) != (B, 2) or scales.dtype != torch.float32 or scales.device != pred.device):
         raise ValueError('detect: scales must be fp32 [B,2] (sy, sx)')
-    bufs = out if out is not None else _det_buffers(B, keep_top_k, pred.device)
-    cnt, cls, sc, bx, idx = bufs
+    bufs = out if out is not None else _det_buffers(B, keep_top_k, pred.device, A)
+    if len(bufs) == 5:
+        bufs = tuple(bufs) + (torch.empty(B * A, device=pred.device, dtype=torch.int32),)
+    cnt, cls, sc, bx, idx, keys = bufs
+    if keys.numel() < B * A or keys.dtype != torch.int32 or keys.device != pred.device:
+        raise ValueError('detect: keys workspace must be int32 with at least B*A elements')
     br = _Bracket('detect', f'detect A{A}', 0.0, 4.0 * B * A * (num_classes + 5)) if _timer is not None else None
-    rc = nat.lib().sqd_detect_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(cnt), nat.ptr(cls),
+    rc = nat.lib().sqd_detect_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(keys), nat.ptr(cnt), nat.ptr(cls),
                                   nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes, int(input_size[0]),
                                   int(input_size[1]), int(keep_top_k), float(nms_thresh), float(score_thresh),
                                   nat.stream_handle(pred.device))
     nat.check(rc, 'sqd_detect_fwd')
     if br is not None:
         br.done()
-    return bufs
+    return bufs[:5]
 
 
 def filter_dense(class_ids, scores, boxes, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3):
@@ -373,13 +381,13 @@ def filter_dense(class_ids, scores, boxes, num_classes, keep_top_k=64, nms_thres
     if class_ids.dtype != torch.int64 or scores.dtype != torch.float32 or boxes.dtype != torch.float32 or not scores.is_cuda:
         raise ValueError('filter: dtype/device mismatch')
     B, A = scores.shape
-    bufs = _det_buffers(B, keep_top_k, scores.device)
-    cnt, cls, sc, bx, idx = bufs
+    bufs = _det_buffers(B, keep_top_k, scores.device, A)
+    cnt, cls, sc, bx, idx, keys = bufs
     rc = nat.lib().sqd_filter_fwd(nat.ptr(class_ids.contiguous()), nat.ptr(scores.contiguous()), nat.ptr(boxes.contiguous()),
-                                  nat.ptr(cnt), nat.ptr(cls), nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes,
+                                  nat.ptr(keys), nat.ptr(cnt), nat.ptr(cls), nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes,
                                   int(keep_top_k), float(nms_thresh), float(score_thresh), nat.stream_handle(scores.device))
     nat.check(rc, 'sqd_filter_fwd')
-    return bufs
+    return bufs[:5]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -75,7 +75,7 @@ def test_status_codes_without_gpu():
     assert lib.sqd_conv_cfg_info(n, None, None, None, None) == 1           # bad cfg id
     null = ctypes.c_void_p(0)
     assert lib.sqd_conv_fwd(null, null, null, null, null, null, null, 1, 1, 1, 4, 4, 0, 4, 16, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, null) == 1
-    assert lib.sqd_detect_fwd(null, null, null, null, null, null, null, null, 1, 1, 3, 1, 1, 64, 0.4, 0.3, null) == 1
+    assert lib.sqd_detect_fwd(null, null, null, null, null, null, null, null, null, 1, 1, 3, 1, 1, 64, 0.4, 0.3, null) == 1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
