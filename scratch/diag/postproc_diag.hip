@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void score_keys_kernel(DetArgs a) {
   }
 }
 
-#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) ((unsigned long long*)(a.keys + (long long)a.B * a.A))[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RSTAMP(i) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) ((unsigned long long*)(a.keys + (long long)a.B * a.A))[blockIdx.x * 4 + i] = (i < 2 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()); } while (0)
 __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* keysL = (unsigned*)smem_raw;                      // [A4] all keys of this image (A rounded up to 4)
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
   const float* pred = a.pred ? a.pred + (long long)b * A * (C + 5) : nullptr;
   const unsigned* keys = a.keys + (long long)b * A;
   const bool dense = a.in_score != nullptr;
-  STAMP(0);
+  RSTAMP(0); RSTAMP(2);
   // 0. all keys of the image -> LDS, coalesced (16-byte loads when the row is 16-byte aligned)
   if ((((long long)b * A) & 3) == 0) {
     const uint4* k4 = (const uint4*)keys;
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
   const int chunk = (A + DET_THREADS - 1) / DET_THREADS;
   const int lo = tid * chunk, hi = min(A, lo + chunk);
   __syncthreads();
-  STAMP(1);
   unsigned c = 0u;
   for (int i = lo; i < hi; ++i) c += keysL[i] != 0u ? 1u : 0u;
   unsigned M;
@@ -183,7 +182,6 @@ __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
     if (keysL[i] != 0u) { cidx[off] = (unsigned short)i; ++off; }
   __syncthreads();
 
-  STAMP(2);
   int ncand;
   if ((int)M <= K) {
     for (int i = tid; i < (int)M; i += DET_THREADS) { cand_key[i] = keysL[cidx[i]]; cand_idx[i] = cidx[i]; }
@@ -254,7 +252,6 @@ __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
     __syncthreads();
   }
 
-  STAMP(3);
   // 4. rank the candidates: score desc, anchor index asc (sentinels: key 0, idx ~INT_MAX -> last)
   if (tid < DET_K) {
     const unsigned mykey = cand_key[tid];
@@ -267,7 +264,6 @@ __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
     sorted_pos[rank] = tid;             // ranks are a permutation (indices are distinct)
   }
   __syncthreads();
-  STAMP(4);
   if (wave != 0) return;                // 5..7: one wave
   const int src = sorted_pos[lane];
   const int idx = cand_idx[src];
@@ -284,7 +280,6 @@ __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
     anchor_score(p, C, score, cls);
     bx = anchor_box(p + C + 1, a.anchors + 4 * idx, a.wmax, a.hmax);
   }
-  STAMP(5);
   // suppression row: bit j set if j ranks after me, same class, IoU > thresh
   const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
   unsigned long long row = 0ull;
@@ -298,14 +293,12 @@ __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
     const float ovr = inter / ((area + jarea) - inter);
     if (j > lane && jcls == cls && cls >= 0 && ovr > a.nms_thresh) row |= 1ull << j;
   }
-  STAMP(6);
   unsigned long long alive = __ballot(ok);
   for (int i = 0; i < DET_K; ++i) {
     const unsigned lo32 = __shfl((unsigned)(row & 0xffffffffull), i);
     const unsigned hi32 = __shfl((unsigned)(row >> 32), i);
     if ((alive >> i) & 1ull) alive &= ~(((unsigned long long)hi32 << 32) | lo32);
   }
-  STAMP(7);
   const bool keep = ((alive >> lane) & 1ull) && score > a.score_thresh;
   int pos = 0, total = 0;
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -315,7 +308,7 @@ __global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
     else if (c == cls) pos += __popcll(m & below);
     total += __popcll(m);
   }
-  STAMP(8);
+  RSTAMP(1); RSTAMP(3);
   if (lane == 0) a.det_count[b] = total;
   if (keep) {
     float sx = 1.f, sy = 1.f;
