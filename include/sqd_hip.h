@@ -45,6 +45,11 @@ int sqd_conv_fwd(const float* x, const float* w_packed, const float* bias, float
 int sqd_pack_conv_weight(const float* w_oihw, float* w_packed, int No, int Ci, int taps, int kc, int Npad,
                          int dgrad, void* stream);
 
+/* The same for n weights in ONE launch (training: every packed copy is refreshed after each optimizer step).
+ * descs_dev: device array of n records of ten int64 {w ptr, out ptr, No, Ci, taps, kc, Npad, ceil(C/kc), dgrad,
+ * total output floats}; grid = blocks_per_desc x n. */
+int sqd_pack_conv_weights_batched(const void* descs_dev, int n, int blocks_per_desc, void* stream);
+
 /* Weight + bias gradient of a 1x1 / 3x3 conv (autograd of nn.Conv2d, src/engine/trainer.py:47).
  * dy window [dy_coff, dy_coff+N) must already carry its ReLU mask; slab = workspace of
  * S*(N*taps*C + N) floats (S pixel-splits, summed in fixed order => bitwise reproducible);
@@ -56,6 +61,12 @@ int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, floa
 /* Stem weight + bias gradient (the image needs no data gradient).  slab: S*(N*3*k*k + N) floats. */
 int sqd_stem_wgrad(const float* dy_nhwc, const float* img_nchw, float* slab, float* dw_oihw, float* db,
                    int B, int Hin, int Win, int N, int ksize, int S, void* stream);
+
+/* The same when the forward ran fused (sqd_stem_conv_relu_pool_fwd): the backward of ReLU + MaxPool is folded
+ * into the staging.  dpool / pooled: NHWC [B][Hp][Wp][N]; argmax: the uint8 tensor written by the forward. */
+int sqd_stem_wgrad_pooled(const float* dpool, const float* pooled, const unsigned char* argmax, const float* img_nchw,
+                          float* slab, float* dw_oihw, float* db, int B, int Hin, int Win, int N, int ksize, int S,
+                          void* stream);
 
 /* Stem: Conv2d(3, N, k, stride 2, pad k/2) + ReLU, NCHW image -> NHWC features.
  * (k,N) = (3,64) squeezedet (src/model/squeezedet.py:34-35) or (7,96) squeezedetplus (:52-53).

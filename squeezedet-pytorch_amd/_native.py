@@ -29,8 +29,10 @@ _SIGNATURES = {
     'sqd_conv_cfg_is_dma': [c_i],
     'sqd_conv_fwd': [c_p] * 7 + [c_i] * 19 + [c_p],
     'sqd_pack_conv_weight': [c_p, c_p] + [c_i] * 6 + [c_p],
+    'sqd_pack_conv_weights_batched': [c_p, c_i, c_i, c_p],
     'sqd_conv_wgrad': [c_p] * 5 + [c_i] * 11 + [c_p],
     'sqd_stem_wgrad': [c_p] * 5 + [c_i] * 6 + [c_p],
+    'sqd_stem_wgrad_pooled': [c_p] * 7 + [c_i] * 6 + [c_p],
     'sqd_stem_conv_relu_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_stem_conv_relu_pool_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_fwd': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],

@@ -30,17 +30,24 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
     feats = base.features
     B = image.shape[0]
     saved = {} if save else None
+    base.refresh_plans()                       # one batched re-pack if the optimizer touched the parameters
     stem = feats[0]
     first = 2
-    if not save and layers[2][0] == 'pool':
-        # inference: conv + ReLU + pool fused, the 30.7 MB/image stem output never reaches HBM
-        a = ops.stem_pool(image, stem.weight, stem.bias)
+    if layers[2][0] == 'pool':
+        # conv + ReLU + pool fused: the 30.7 MB/image stem output never reaches HBM.  Training keeps the pool
+        # argmax; the backward folds ReLU + pool into the stem weight-gradient kernel (ops.stem_wgrad_pooled)
+        Hs, Ws = ops.stem_out_size(image.shape[2], image.shape[3], stem.kernel_size[0])
+        am = torch.empty(B, *ops.pool_out_size(Hs, Ws), stem.out_channels, device=image.device, dtype=torch.uint8) if save else None
+        a = ops.stem_pool(image, stem.weight, stem.bias, argmax=am)
         first = 3
+        if save:
+            saved['stem_pool'] = (am, a)
     else:
         a = ops.stem_conv_relu(image, stem.weight, stem.bias)
+        if save:
+            saved['stem_out'] = a
     if save:
         saved['image'] = image
-        saved['stem_out'] = a
     for i in range(first, len(layers)):
         l = layers[i]
         if l[0] == 'pool':

@@ -37,6 +37,8 @@ def run_backbone_backward(base, saved, dpred):
     for i in range(last, 1, -1):
         l = layers[i]
         if l[0] == 'pool':
+            if i == 2 and 'stem_pool' in saved:
+                continue                                   # folded into the stem weight gradient below
             am, (Hi, Wi) = saved[f'pool{i}']
             prev = layers[i - 1][0]
             relu_src = saved[f'fire{i - 1}'][2] if prev == 'fire' else saved['stem_out']
@@ -61,8 +63,13 @@ def run_backbone_backward(base, saved, dpred):
                  ymask=x_in if prev_is_fire else None)
         dA = dIn
     stem = feats[0]
-    grads['features.0.weight'], grads['features.0.bias'] = ops.stem_wgrad(dA, saved['image'].contiguous(), stem.out_channels,
-                                                                           stem.kernel_size[0])
+    if 'stem_pool' in saved:
+        am, pooled = saved['stem_pool']
+        grads['features.0.weight'], grads['features.0.bias'] = ops.stem_wgrad_pooled(dA, pooled, am, saved['image'].contiguous(),
+                                                                                      stem.out_channels, stem.kernel_size[0])
+    else:
+        grads['features.0.weight'], grads['features.0.bias'] = ops.stem_wgrad(dA, saved['image'].contiguous(), stem.out_channels,
+                                                                               stem.kernel_size[0])
     return grads
 
 

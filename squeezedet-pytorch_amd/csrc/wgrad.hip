@@ -328,12 +328,19 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
 // ---------------------------------------------------------------------------------------------
 struct StemWgradArgs {
   const float* dy; const float* img; float* slab;
+  const float* pooled; const unsigned char* amax;    // POOLED variant: dy is dPool [B][Hp][Wp][N]
+  int Hp, Wp;
   int B, Hin, Win, Ho, Wo, N;
   int tiles_x, tiles_y, nblocks;
   long long slab_stride;
 };
 
-template <int KS, int PAD, int TN>
+// POOLED = true folds the backward of the fused ReLU + MaxPool(3,2,ceil) into the dY staging: the gradient of a
+// conv output is the sum of dPool over the (at most 4) windows whose argmax it is, masked by pooled > 0 (the
+// pooled value IS the conv output at the argmax, so this is the ReLU mask).  Windows are scattered into the LDS
+// tile in four (row parity, column parity) phases: same-parity windows never overlap, so every element receives
+// its contributions in a fixed order -- no atomics, bitwise reproducible.
+template <int KS, int PAD, int TN, bool POOLED>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
   constexpr int TH = 8;
   constexpr int K = 3 * KS * KS, KT = (K + 15) / 16;          // k-tiles of 16 im2col columns
@@ -379,12 +386,40 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
     const int y0 = ty * TH, x0 = tx * 16;
     if (!first) __syncthreads();
     first = false;
-    for (int idx = tid; idx < 128 * TN * 4; idx += 256) {
-      const int pix = idx / (TN * 4), v = idx - pix * (TN * 4);
-      const int oy = y0 + (pix >> 4), ox = x0 + (pix & 15), n = 4 * v;
-      f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (oy < a.Ho && ox < a.Wo && n < a.N) val = *(const f32x4*)(a.dy + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.N + n);
-      *(f32x4*)(dyT + pix * PN + 4 * v) = val;
+    if (!POOLED) {
+      for (int idx = tid; idx < 128 * TN * 4; idx += 256) {
+        const int pix = idx / (TN * 4), v = idx - pix * (TN * 4);
+        const int oy = y0 + (pix >> 4), ox = x0 + (pix & 15), n = 4 * v;
+        f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (oy < a.Ho && ox < a.Wo && n < a.N) val = *(const f32x4*)(a.dy + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.N + n);
+        *(f32x4*)(dyT + pix * PN + 4 * v) = val;
+      }
+    } else {
+      for (int idx = tid; idx < 128 * PN / 4; idx += 256) ((f32x4*)dyT)[idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int py_lo = y0 >= 2 ? (y0 - 1) / 2 : 0, py_hi = min(a.Hp - 1, (y0 + TH - 1) / 2);
+      const int px_lo = x0 >= 2 ? (x0 - 1) / 2 : 0, px_hi = min(a.Wp - 1, (x0 + 15) / 2);
+      const int nwx = px_hi - px_lo + 1, nq = a.N >> 2;
+      const int items = (py_hi - py_lo + 1) * nwx * nq;
+      __syncthreads();
+      for (int phase = 0; phase < 4; ++phase) {
+        for (int item = tid; item < items; item += 256) {
+          const int q = item % nq; const int w = item / nq;
+          const int py = py_lo + w / nwx, px = px_lo + w % nwx;
+          if ((py & 1) != (phase >> 1) || (px & 1) != (phase & 1)) continue;
+          const long long o = (((long long)b * a.Hp + py) * a.Wp + px) * a.N + 4 * q;
+          const unsigned am = *(const unsigned*)(a.amax + o);
+          const f32x4 pl = *(const f32x4*)(a.pooled + o);
+          const f32x4 dp = *(const f32x4*)(a.dy + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (!(pl[e] > 0.f)) continue;
+            const int t = (int)((am >> (8 * e)) & 255u);
+            const int oy = 2 * py + t / 3 - y0, ox = 2 * px + t % 3 - x0;
+            if (oy >= 0 && oy < TH && ox >= 0 && ox < 16) dyT[(oy * 16 + ox) * PN + 4 * q + e] += dp[e];
+          }
+        }
+        __syncthreads();
+      }
     }
     for (int idx = tid; idx < 3 * IH * IW; idx += 256) {
       const int c = idx % IW; int r = idx / IW; const int ci = r / IH; r -= ci * IH;
@@ -433,17 +468,33 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
   }
 }
 
-template <int KS, int PAD, int TN>
+template <int KS, int PAD, int TN, bool POOLED>
 static int launch_stem_wgrad(StemWgradArgs a, int S, hipStream_t s) {
   constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16);
   constexpr int IH = 14 + KS, IW = 30 + KS, IWP = IW | 1;
   constexpr size_t lds = (size_t)(128 * PN + 3 * IH * IWP + 1) * sizeof(float);
   a.tiles_x = sqd_cdiv(a.Wo, 16); a.tiles_y = sqd_cdiv(a.Ho, 8);
   a.nblocks = a.B * a.tiles_x * a.tiles_y;
-  auto kern = stem_wgrad_kernel<KS, PAD, TN>;
+  auto kern = stem_wgrad_kernel<KS, PAD, TN, POOLED>;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return SQD_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(256), lds, s, a);
+  return sqd_launch_status();
+}
+
+static int stem_wgrad_common(StemWgradArgs a, int ksize, int S, float* dw, float* db, bool pooled, hipStream_t s) {
+  const int K = 3 * ksize * ksize;
+  a.slab_stride = (long long)a.N * K + a.N;
+  const int pad = ksize == 3 ? 1 : 3;
+  a.Ho = (a.Hin + 2 * pad - ksize) / 2 + 1; a.Wo = (a.Win + 2 * pad - ksize) / 2 + 1;
+  a.Hp = (a.Ho - 3 + 1) / 2 + 1; a.Wp = (a.Wo - 3 + 1) / 2 + 1;
+  int rc = SQD_ERR_UNSUPPORTED;
+  if (ksize == 3 && a.N == 64) rc = pooled ? launch_stem_wgrad<3, 1, 4, true>(a, S, s) : launch_stem_wgrad<3, 1, 4, false>(a, S, s);
+  else if (ksize == 7 && a.N == 96) rc = pooled ? launch_stem_wgrad<7, 3, 6, true>(a, S, s) : launch_stem_wgrad<7, 3, 6, false>(a, S, s);
+  if (rc != SQD_OK) return rc;
+  // slab layout [n][K] is already OIHW-flat: reduce with C := K, TAPS := 1
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.slab_stride + WGR_OUT - 1) / WGR_OUT)), dim3(WGR_OUT * WGR_PARTS), 0, s, a.slab, dw, db, S,
+                     a.slab_stride, a.N, K, 1);
   return sqd_launch_status();
 }
 
@@ -454,23 +505,20 @@ extern "C" int sqd_stem_wgrad(const float* dy, const float* img, float* slab, fl
   SQD_CHECK_ARG(dy && img && slab && dw && B > 0 && Hin > 0 && Win > 0 && S > 0 && S <= 65535);
   SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0);
   StemWgradArgs a;
-  a.dy = dy; a.img = img; a.slab = slab; a.B = B; a.Hin = Hin; a.Win = Win; a.N = N;
-  const int K = 3 * ksize * ksize;
-  a.slab_stride = (long long)N * K + N;
-  hipStream_t s = (hipStream_t)stream;
-  int rc = SQD_ERR_UNSUPPORTED;
-  if (ksize == 3 && N == 64) {
-    a.Ho = (Hin + 2 - 3) / 2 + 1; a.Wo = (Win + 2 - 3) / 2 + 1;
-    rc = launch_stem_wgrad<3, 1, 4>(a, S, s);
-  } else if (ksize == 7 && N == 96) {
-    a.Ho = (Hin + 6 - 7) / 2 + 1; a.Wo = (Win + 6 - 7) / 2 + 1;
-    rc = launch_stem_wgrad<7, 3, 6>(a, S, s);
-  }
-  if (rc != SQD_OK) return rc;
-  // slab layout [n][K] is already OIHW-flat: reduce with C := K, TAPS := 1
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.slab_stride + WGR_OUT - 1) / WGR_OUT)), dim3(WGR_OUT * WGR_PARTS), 0, s, slab, dw, db, S,
-                     a.slab_stride, N, K, 1);
-  return sqd_launch_status();
+  a.dy = dy; a.img = img; a.slab = slab; a.pooled = nullptr; a.amax = nullptr; a.B = B; a.Hin = Hin; a.Win = Win; a.N = N;
+  return stem_wgrad_common(a, ksize, S, dw, db, false, (hipStream_t)stream);
+}
+
+// The same gradient when the forward ran fused (sqd_stem_conv_relu_pool_fwd): dpool / pooled are NHWC
+// [B][Hp][Wp][N] (gradient w.r.t. and value of the pooled output), argmax the uint8 tensor the forward wrote.
+extern "C" int sqd_stem_wgrad_pooled(const float* dpool, const float* pooled, const unsigned char* argmax, const float* img,
+                                     float* slab, float* dw, float* db, int B, int Hin, int Win, int N, int ksize, int S,
+                                     void* stream) {
+  SQD_CHECK_ARG(dpool && pooled && argmax && img && slab && dw && B > 0 && Hin > 0 && Win > 0 && S > 0 && S <= 65535);
+  SQD_CHECK_ARG(((uintptr_t)dpool & 15) == 0 && ((uintptr_t)pooled & 15) == 0 && ((uintptr_t)argmax & 3) == 0);
+  StemWgradArgs a;
+  a.dy = dpool; a.img = img; a.slab = slab; a.pooled = pooled; a.amax = argmax; a.B = B; a.Hin = Hin; a.Win = Win; a.N = N;
+  return stem_wgrad_common(a, ksize, S, dw, db, true, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -510,5 +558,36 @@ extern "C" int sqd_pack_conv_weight(const float* w, float* out, int No, int Ci, 
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, No, Ci, taps, kc, Npad,
                      nchunks, dgrad);
+  return sqd_launch_status();
+}
+
+// Batched re-pack: one launch refreshes every packed copy after an optimizer step.  descs: device array of
+// n records of 10 int64 {w ptr, out ptr, No, Ci, taps, kc, Npad, nchunks, dgrad, total elements}.
+struct PackDesc { const float* w; float* out; long long No, Ci, taps, kc, Npad, nchunks, dgrad, total; };
+
+__global__ __launch_bounds__(256) void pack_weight_batched_kernel(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const int Ci = (int)d.Ci, taps = (int)d.taps, kc = (int)d.kc, Npad = (int)d.Npad;
+  const int N = d.dgrad ? (int)d.Ci : (int)d.No, C = d.dgrad ? (int)d.No : (int)d.Ci;
+  const int kv = kc >> 2;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < d.total; idx += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 3); long long t = idx >> 2;
+    const int n = (int)(t % Npad); t /= Npad;
+    const int tap = (int)(t % taps); t /= taps;
+    const int v = (int)(t % kv); const int cc = (int)(t / kv);
+    const int c = cc * kc + 4 * v + e;
+    float val = 0.f;
+    if (n < N && c < C) {
+      if (!d.dgrad) val = d.w[((long long)n * Ci + c) * taps + tap];
+      else val = d.w[((long long)c * Ci + n) * taps + (taps - 1 - tap)];
+    }
+    d.out[idx] = val;
+  }
+}
+
+extern "C" int sqd_pack_conv_weights_batched(const void* descs_dev, int n, int blocks_per_desc, void* stream) {
+  SQD_CHECK_ARG(descs_dev && n > 0 && n <= 65535 && blocks_per_desc > 0 && blocks_per_desc <= 4096);
+  hipLaunchKernelGGL(pack_weight_batched_kernel, dim3((unsigned)blocks_per_desc, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     (const PackDesc*)descs_dev);
   return sqd_launch_status();
 }

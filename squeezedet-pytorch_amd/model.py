@@ -89,6 +89,7 @@ class SqueezeDetBase(nn.Module):
         self.dropout = nn.Dropout(cfg.dropout_prob, inplace=True) if cfg.dropout_prob > 0 else None
         self.convdet = _ConvParams(convdet_in_channels(cfg.arch), cfg.anchors_per_grid * (cfg.num_classes + 5), 3, padding=1)
         self._plans = {}
+        self._pack_table_keepalive = None
         self._forced_drop_mask = None       # tests: NCHW mask (already scaled by 1/(1-p)) instead of RNG
         self.init_weights()
 
@@ -109,6 +110,28 @@ class SqueezeDetBase(nn.Module):
         p = ops.ConvPlan(mod.weight, mod.bias, cfg_id, dgrad=(direction != 'fwd'))
         self._plans[key] = (ver, p)
         return p
+
+    def refresh_plans(self):
+        """Re-pack every cached plan whose parameter changed since it was packed (after an optimizer step that
+        is all of them) with ONE batched kernel launch instead of one launch per plan."""
+        stale, dg, keys = [], [], []
+        for key, (ver, plan) in self._plans.items():
+            name, _cfg, direction = key
+            mod = self.convdet if name == 'convdet' else getattr(self.features[int(name.split('.')[0])], name.split('.')[1]) \
+                if '.' in name else self.features[int(name)]
+            now = (mod.weight._version, mod.weight.data_ptr(), mod.bias._version, mod.bias.data_ptr())
+            if now != ver:
+                stale.append((plan, mod.weight)); dg.append(direction != 'fwd'); keys.append((key, now, mod))
+        if not stale:
+            return
+        if self._pack_table_keepalive is not None and len(self._pack_table_keepalive) > 8:
+            self._pack_table_keepalive = self._pack_table_keepalive[-4:]
+        table = ops.repack_batched(stale, dg)
+        self._pack_table_keepalive = (self._pack_table_keepalive or []) + [table]     # keep the descriptor table alive until consumed
+        for (key, now, mod), (plan, _w) in zip(keys, stale):
+            if plan.bias is not None:
+                plan.bias = mod.bias.detach()
+            self._plans[key] = (now, plan)
 
     def forward(self, x):
         from .autograd import backbone_apply

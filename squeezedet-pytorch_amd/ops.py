@@ -159,6 +159,24 @@ class ConvPlan:
         self.bias = None if (bias is None or dgrad) else bias.detach().contiguous()
 
 
+def repack_batched(plans_and_weights, is_dgrad):
+    """Refresh many packed weight copies with ONE kernel launch.  plans_and_weights: [(ConvPlan, weight)],
+    is_dgrad: parallel list of bools."""
+    if not plans_and_weights:
+        return
+    rows = []
+    for (plan, w), dg in zip(plans_and_weights, is_dgrad):
+        if not w.is_contiguous():
+            raise ValueError('repack_batched: parameters must be contiguous')
+        rows.append([w.data_ptr(), plan.w.data_ptr(), w.shape[0], w.shape[1], plan.taps, plan.kc, plan.Npad, plan.w.shape[0],
+                     int(dg), plan.w.numel()])
+    dev = plans_and_weights[0][1].device
+    table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
+    rc = nat.lib().sqd_pack_conv_weights_batched(nat.ptr(table), len(rows), 16, nat.stream_handle(dev))
+    nat.check(rc, 'sqd_pack_conv_weights_batched')
+    return table
+
+
 def dgrad_weight(w_oihw):
     """Weights of the convolution that computes dX from dY: swap in/out channels, flip taps."""
     return w_oihw.permute(1, 0, 2, 3).flip(2, 3).contiguous()
@@ -457,6 +475,35 @@ def stem_wgrad(dy, image, N, ksize):
     rc = nat.lib().sqd_stem_wgrad(nat.ptr(dy), nat.ptr(image), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, ksize, S,
                                   nat.stream_handle(dy.device))
     nat.check(rc, 'sqd_stem_wgrad')
+    if br is not None:
+        br.done()
+    return dw, db
+
+
+def stem_wgrad_pooled(dpool, pooled, argmax, image, N, ksize):
+    """Stem (dW, db) when the forward ran fused (stem_pool with argmax): ReLU + max-pool backward folded in."""
+    _check_nhwc(dpool, 'dpool'); _check_nhwc(pooled, 'pooled')
+    B, Hp, Wp, n = dpool.shape
+    if n != N or tuple(pooled.shape) != (B, Hp, Wp, N) or tuple(argmax.shape) != (B, Hp, Wp, N) or argmax.dtype != torch.uint8 \
+            or not argmax.is_contiguous():
+        raise ValueError('stem_wgrad_pooled: dpool / pooled / argmax geometry mismatch')
+    if image.dim() != 4 or image.shape[0] != B or image.shape[1] != 3 or not image.is_contiguous():
+        raise ValueError('stem_wgrad_pooled: bad image')
+    H, W = image.shape[2], image.shape[3]
+    Ho, Wo = stem_out_size(H, W, ksize)
+    if pool_out_size(Ho, Wo) != (Hp, Wp) or (ksize, N) not in ((3, 64), (7, 96)):
+        raise ValueError('stem_wgrad_pooled: unsupported geometry')
+    nblocks = B * -(-Ho // 8) * -(-Wo // 16)
+    S = max(1, min(nblocks, 1024))
+    K = 3 * ksize * ksize
+    slab = torch.empty(S * (N * K + N), device=dpool.device, dtype=torch.float32)
+    dw = torch.empty(N, 3, ksize, ksize, device=dpool.device, dtype=torch.float32)
+    db = torch.empty(N, device=dpool.device, dtype=torch.float32)
+    br = _Bracket(f'stem_wgrad_pooled<{ksize}>', f'stem wgrad (pooled) {H}x{W}', 2.0 * B * Ho * Wo * N * K,
+                  4.0 * (B * Hp * Wp * N * 2.25 + B * 3 * H * W)) if _timer is not None else None
+    rc = nat.lib().sqd_stem_wgrad_pooled(nat.ptr(dpool), nat.ptr(pooled), nat.ptr(argmax), nat.ptr(image), nat.ptr(slab), nat.ptr(dw),
+                                         nat.ptr(db), B, H, W, N, ksize, S, nat.stream_handle(dpool.device))
+    nat.check(rc, 'sqd_stem_wgrad_pooled')
     if br is not None:
         br.done()
     return dw, db

@@ -217,3 +217,22 @@ def test_kitti_size_backward_spot_check():
     _, _, grads, total, loss_vec, _ = oracle.train_step_reference(sd, None, x, gt, cfg.anchors, size)
     np.testing.assert_allclose(loss.detach().cpu().numpy(), loss_vec.numpy(), rtol=1e-4)
     _check_grads_flip_aware(m.named_parameters(), grads)
+
+
+@pytest.mark.parametrize("k,N,H,W", [(3, 64, 64, 96), (3, 64, 50, 70), (7, 96, 64, 96)])
+def test_stem_wgrad_pooled(k, N, H, W):
+    """Fused forward (conv+ReLU+pool with argmax) + backward folded into the stem wgrad vs CPU autograd."""
+    from squeezedet_pytorch_amd import ops
+    x = _rand(2, 3, H, W, seed=31)
+    w = _rand(N, 3, k, k, seed=32, scale=0.2).requires_grad_(True)
+    b = _rand(N, seed=33, scale=0.1).requires_grad_(True)
+    y = F.max_pool2d(F.relu(F.conv2d(x, w, b, stride=2, padding=1 if k == 3 else 3)), 3, 2, ceil_mode=True)
+    dy = _rand(*y.shape, seed=34)
+    y.backward(dy)
+    am = torch.empty(*_nhwc(y.detach()).shape, dtype=torch.uint8, device='cuda')
+    pooled = ops.stem_pool(x.cuda(), w.detach().cuda(), b.detach().cuda(), argmax=am)
+    dw, db = ops.stem_wgrad_pooled(_nhwc(dy).cuda(), pooled, am, x.cuda(), N, k)
+    assert (dw.cpu() - w.grad).abs().max().item() <= 2e-4 * max(1.0, float(w.grad.abs().max()))
+    assert (db.cpu() - b.grad).abs().max().item() <= 2e-4 * max(1.0, float(b.grad.abs().max()))
+    dw2, db2 = ops.stem_wgrad_pooled(_nhwc(dy).cuda(), pooled, am, x.cuda(), N, k)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)          # deterministic
