@@ -165,15 +165,15 @@ def main():
     # `nprof` eager steps is bracketed on its launch stream.  Two un-bracketed steps are enqueued first so the
     # host runs ahead of the GPU and no bracket absorbs a launch gap (brackets are only exact when the GPU is
     # the bottleneck; checked against rocprofv3 --kernel-trace, profiles/). ----
-    nprof = 3
+    nprof = 5
     timer = ops.KernelTimer()
-    run(); run()
+    run(); run(); run()
     ops.set_timer(timer)
     for _ in range(nprof):
         step()
     ops.set_timer(None)
     torch.cuda.synchronize()
-    summ = timer.summary()
+    summ = timer.summary(nsteps=nprof)               # per-step totals from per-shape medians
     dominant = max(summ.items(), key=lambda kv: kv[1]['ms'])[0] if summ else None
 
     if dist is not None:
@@ -200,16 +200,16 @@ def main():
                 roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
             roof['traffic'] = measured_traffic(dominant)
-            roof.update({'kernel': dominant, 'launches_per_step': d['launches'] // nprof,
+            roof.update({'kernel': dominant, 'launches_per_step': int(round(d['launches'])),
                          'avg_launch_us': round(avg_s * 1e6, 2),
                          'algorithmic_per_launch': {'gflop': round(flops_per_launch / 1e9, 3), 'mbytes': round(bytes_per_launch / 1e6, 3)},
-                         'share_of_step': round(d['ms'] / nprof / (elapsed / args.steps * 1e3), 3),
-                         'how': f'HIP events around every launch of {nprof} eager steps enqueued behind the timed region'})
+                         'share_of_step': round(d['ms'] / (elapsed / args.steps * 1e3), 3),
+                         'how': f'HIP events around every launch of {nprof} eager steps enqueued behind the timed region; median per kernel shape'})
         gf = FWD_GFLOP_PER_IMAGE[args.arch]
         whole = {'tflops': round(value * gf / 1e3, 2),
                  'frac_of_fp32_mfma_peak': round(value / world * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)} if args.mode == 'infer' else None
-        kernels = {k: {'ms_per_step': round(v['ms'] / nprof, 4),
-                       'launches_per_step': v['launches'] // nprof,
+        kernels = {k: {'ms_per_step': round(v['ms'], 4),
+                       'launches_per_step': int(round(v['launches'])),
                        'tflops': round(v['flops'] / (v['ms'] / 1e3) / 1e12, 2) if v['ms'] > 0 else 0,
                        'gbs': round(v['bytes'] / (v['ms'] / 1e3) / 1e9, 1) if v['ms'] > 0 else 0}
                    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}

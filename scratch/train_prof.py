@@ -22,9 +22,9 @@ t = ops.KernelTimer(); ops.set_timer(t)
 for _ in range(3): step()
 ops.set_timer(None); torch.cuda.synchronize()
 rows = []
-for name, d in t.summary().items():
+for name, d in t.summary(nsteps=3).items():
     for tag, (n, ms) in d['tags'].items():
-        rows.append((ms / 3, n // 3, name, tag))
+        rows.append((ms, int(round(n)), name, tag))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f'total bracketed {tot:.3f} ms/step')

@@ -27,14 +27,24 @@ class KernelTimer:
     def wants(self, name):
         return self.select is None or name in self.select
 
-    def summary(self):
-        """{name: dict(launches, ms, flops, bytes)} -- call after a synchronize."""
-        out = {}
+    def summary(self, nsteps=1):
+        """{name: dict(launches, ms, flops, bytes, tags)} per step -- call after a synchronize.  ``nsteps`` = number
+        of identical steps that were bracketed: per (kernel, shape) the MEDIAN launch time over all its samples is
+        used, so a bracket that absorbed a host stall (GPU idle between the start marker and the launch) cannot
+        distort the totals."""
+        groups = {}
         for name, tag, fl, by, e0, e1 in self.records:
-            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, tags={}))
-            ms = e0.elapsed_time(e1)
-            d['launches'] += 1; d['ms'] += ms; d['flops'] += fl; d['bytes'] += by
-            t = d['tags'].setdefault(tag, [0, 0.0]); t[0] += 1; t[1] += ms
+            g = groups.setdefault((name, tag), dict(ms=[], flops=fl, bytes=by))
+            g['ms'].append(e0.elapsed_time(e1))
+        out = {}
+        for (name, tag), g in groups.items():
+            ms = sorted(g['ms'])
+            med = ms[len(ms) // 2]
+            per_step = len(ms) / float(nsteps)             # launches of this shape per step
+            d = out.setdefault(name, dict(launches=0.0, ms=0.0, flops=0.0, bytes=0.0, tags={}))
+            d['launches'] += per_step; d['ms'] += med * per_step
+            d['flops'] += g['flops'] * per_step; d['bytes'] += g['bytes'] * per_step
+            d['tags'][tag] = [per_step, med * per_step]
         return out
 
 
