@@ -94,6 +94,11 @@ int sqd_maxpool3x3s2_ceil_bwd(const float* dy, const unsigned char* argmax, floa
 int sqd_decode_fwd(const float* pred, const float* anchors, long long* class_ids, float* scores, float* boxes,
                    int B, int A, int num_classes, int input_h, int input_w, void* stream);
 
+/* PredictionResolver.forward itself (src/model/squeezedet.py:109-120): the reference's five dense outputs.
+ * probs / logp [B][A][C] (logp may be NULL = log_softmax=False), scores [B][A], deltas / boxes [B][A][4]. */
+int sqd_resolve_fwd(const float* pred, const float* anchors, float* probs, float* logp, float* scores, float* deltas,
+                    float* boxes, int B, int A, int num_classes, int input_h, int input_w, void* stream);
+
 /* Fused decode + Detector.filter for a whole batch (src/engine/detector.py:87-122 + torchvision nms +
  * the scale division of boxes_postprocess, src/utils/boxes.py:145-147): top keep_top_k (<= 64) by score,
  * class-wise NMS, score threshold, compacted in class order.  Fixed-capacity outputs [B][keep_top_k];

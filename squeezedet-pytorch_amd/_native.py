@@ -37,6 +37,7 @@ _SIGNATURES = {
     'sqd_stem_conv_relu_pool_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_fwd': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_bwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    'sqd_resolve_fwd': [c_p] * 7 + [c_i] * 5 + [c_p],
     'sqd_decode_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_detect_fwd': [c_p] * 9 + [c_i] * 6 + [c_f, c_f, c_p],
     'sqd_filter_fwd': [c_p] * 9 + [c_i] * 4 + [c_f, c_f, c_p],

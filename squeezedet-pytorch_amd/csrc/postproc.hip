@@ -93,6 +93,47 @@ extern "C" int sqd_decode_fwd(const float* pred, const float* anchors, long long
   return sqd_launch_status();
 }
 
+// ---- PredictionResolver.forward proper: the reference's five dense outputs (src/model/squeezedet.py:109-120) ----
+__global__ __launch_bounds__(256) void resolve_kernel(const float* __restrict__ pred, const float* __restrict__ anchors,
+                                                      float* __restrict__ probs, float* __restrict__ logp, float* __restrict__ scores,
+                                                      float* __restrict__ deltas, float* __restrict__ boxes, int B, int A, int C,
+                                                      float wmax, float hmax) {
+  const long long total = (long long)B * A;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const float* p = pred + i * (C + 5);
+    float l[SQD_MAX_CLASSES];
+    float m = p[0];
+    for (int c = 0; c < C; ++c) { l[c] = p[c]; m = fmaxf(m, l[c]); }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(l[c] - m);
+    const float lse = logf(sum);
+    for (int c = 0; c < C; ++c) {
+      probs[i * C + c] = expf(l[c] - m) / sum;                 // safe_softmax (modules.py:66-68)
+      if (logp) logp[i * C + c] = (l[c] - m) - lse;            // torch.log_softmax
+    }
+    scores[i] = 1.f / (1.f + expf(-p[C]));
+    const float* d = p + C + 1;
+    *(f32x4*)(deltas + 4 * i) = (f32x4){d[0], d[1], d[2], d[3]};
+    const BoxF b = anchor_box(d, anchors + 4 * a, wmax, hmax);
+    *(f32x4*)(boxes + 4 * i) = (f32x4){b.x1, b.y1, b.x2, b.y2};
+  }
+}
+
+// probs [B][A][C], logp [B][A][C] or NULL, scores [B][A] (the reference's [B,A,1]), deltas [B][A][4], boxes [B][A][4]
+extern "C" int sqd_resolve_fwd(const float* pred, const float* anchors, float* probs, float* logp, float* scores,
+                               float* deltas, float* boxes, int B, int A, int num_classes, int input_h, int input_w,
+                               void* stream) {
+  SQD_CHECK_ARG(pred && anchors && probs && scores && deltas && boxes && B > 0 && A > 0);
+  SQD_CHECK_ARG(num_classes >= 1 && num_classes <= SQD_MAX_CLASSES);
+  SQD_CHECK_ARG(((uintptr_t)deltas & 15) == 0 && ((uintptr_t)boxes & 15) == 0);
+  const long long total = (long long)B * A;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, anchors, probs, logp, scores,
+                     deltas, boxes, B, A, num_classes, (float)(input_w - 1), (float)(input_h - 1));
+  return sqd_launch_status();
+}
+
 // ---- fused detection ----
 // Two launches on the stream: (1) score_keys_kernel spreads the per-anchor scoring (4 exp + 2 div each) over
 // the whole chip and writes one uint32 key per anchor -- the fp32 score bits if score > score_thresh, else 0;

@@ -156,8 +156,14 @@ class PredictionResolver(nn.Module):
         return a
 
     def forward(self, pred):
-        """Dense decode on the GPU: returns (class_ids int64 [B,A], scores [B,A], boxes [B,A,4]) -- the three
-        tensors ``SqueezeDet.forward`` derives from the resolver's five outputs (:199-202)."""
+        """Same five outputs as the reference (src/model/squeezedet.py:109-120): (pred_class_probs [B,A,C],
+        pred_log_class_probs | None, pred_scores [B,A,1], pred_deltas [B,A,4], pred_boxes [B,A,4]) -- inference only
+        (not differentiable; the training path differentiates through ``Loss``, whose kernel has the analytic backward)."""
+        return ops.resolve(pred.detach(), self.anchors_on(pred.device), self.input_size, self.num_classes, self.log_softmax)
+
+    def decode(self, pred):
+        """Fused resolver + ``probs *= score; argmax; max`` of ``SqueezeDet.forward`` (:199-202):
+        (class_ids int64 [B,A], scores [B,A], boxes [B,A,4])."""
         return ops.decode(pred, self.anchors_on(pred.device), self.input_size, self.num_classes)
 
 
@@ -171,7 +177,7 @@ class SqueezeDet(nn.Module):
 
     def forward(self, batch):
         pred = self.base(batch['image'])
-        class_ids, scores, boxes = self.resolver(pred)
+        class_ids, scores, boxes = self.resolver.decode(pred)
         return {'class_ids': class_ids, 'scores': scores, 'boxes': boxes}
 
 

@@ -364,6 +364,28 @@ def decode(pred, anchors, input_size, num_classes):
     return ids, scores, boxes
 
 
+def resolve(pred, anchors, input_size, num_classes, log_softmax=False):
+    """The reference's PredictionResolver outputs: (probs [B,A,C], log_probs [B,A,C] | None, scores [B,A,1],
+    deltas [B,A,4], boxes [B,A,4])."""
+    if pred.dim() != 3 or pred.shape[2] != num_classes + 5 or pred.dtype != torch.float32 or not pred.is_cuda:
+        raise ValueError(f'resolve: bad pred {tuple(pred.shape)}')
+    pred = pred.contiguous()
+    B, A, _ = pred.shape
+    if tuple(anchors.shape) != (A, 4) or anchors.dtype != torch.float32 or anchors.device != pred.device:
+        raise ValueError('resolve: anchors must be fp32 [A,4] on the same device')
+    dev = pred.device
+    probs = torch.empty(B, A, num_classes, device=dev, dtype=torch.float32)
+    logp = torch.empty(B, A, num_classes, device=dev, dtype=torch.float32) if log_softmax else None
+    scores = torch.empty(B, A, 1, device=dev, dtype=torch.float32)
+    deltas = torch.empty(B, A, 4, device=dev, dtype=torch.float32)
+    boxes = torch.empty(B, A, 4, device=dev, dtype=torch.float32)
+    rc = nat.lib().sqd_resolve_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(probs), nat.ptr(logp), nat.ptr(scores),
+                                   nat.ptr(deltas), nat.ptr(boxes), B, A, num_classes, int(input_size[0]), int(input_size[1]),
+                                   nat.stream_handle(dev))
+    nat.check(rc, 'sqd_resolve_fwd')
+    return probs, logp, scores, deltas, boxes
+
+
 def _det_buffers(B, K, device, A=None):
     """(count, class_ids, scores, boxes, anchor_idx[, keys workspace]) for the fused detection kernels."""
     bufs = (torch.zeros(B, device=device, dtype=torch.int32), torch.zeros(B, K, device=device, dtype=torch.int64),

@@ -190,3 +190,21 @@ def test_detector_end_to_end_kitti():
         if margin_topk > 2e-4 and np.min(np.abs(so[order[:64]] - 0.3)) > 2e-4:
             assert len(common) >= len(do['anchor_idx']) - 2
         np.testing.assert_allclose(sc_h[b].numpy(), so, atol=TOL)
+
+
+def test_prediction_resolver_five_outputs_vs_golden(golden_dir):
+    """PredictionResolver.forward returns the reference's own 5-tuple (src/model/squeezedet.py:109-120)."""
+    from squeezedet_pytorch_amd.model import PredictionResolver
+    g = np.load(os.path.join(golden_dir, "decode.npz"))
+    cfg = sqd.make_cfg()
+    pred = _decode_pred()
+    res = PredictionResolver(cfg, log_softmax=True)
+    probs, logp, scores, deltas, boxes = res(pred.cuda())
+    assert tuple(scores.shape) == (2, 16848, 1) and tuple(probs.shape) == (2, 16848, 3)
+    sel = g["sel"]
+    np.testing.assert_allclose(probs.cpu().numpy()[:, sel], g["probs"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(logp.cpu().numpy()[:, sel], g["logp"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(scores.cpu().numpy()[:, sel], g["scores"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(boxes.cpu().numpy()[:, sel], g["boxes"], atol=1e-3, rtol=0)
+    assert torch.equal(deltas.cpu(), pred[..., 4:])
+    assert PredictionResolver(cfg, log_softmax=False)(pred.cuda())[1] is None
