@@ -22,7 +22,8 @@ extern "C" {
 int sqd_conv_num_cfgs(void);
 /* taps (1 or 9), K-chunk, pixels per workgroup tile, output channels per workgroup slice */
 int sqd_conv_cfg_info(int cfg_id, int* taps, int* kc, int* tile_px, int* bn);
-/* 1: stages through LDS-DMA double buffering (xmask unsupported), 0: register-staged, -1: bad id */
+/* 0: register-staged, 4 waves; 1: LDS-DMA double buffering, 4 waves; 2: LDS-DMA, 8 waves (xmask unsupported
+ * when != 0); -1: bad id */
 int sqd_conv_cfg_is_dma(int cfg_id);
 
 /* Convolution 1x1 or 3x3/pad 1, stride 1, on the fp32 matrix cores, with fused bias / ReLU /

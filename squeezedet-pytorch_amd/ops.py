@@ -82,7 +82,7 @@ def cfg_table():
     if _CFG_TABLE is None:
         rows = nat.conv_cfgs()
         _CFG_TABLE = {i: (t, k, px, bn) for i, t, k, px, bn, _ in rows}
-        _CFG_DMA.update({i: bool(d) for i, _, _, _, _, d in rows})
+        _CFG_DMA.update({i: int(d) for i, _, _, _, _, d in rows})
     return _CFG_TABLE
 
 
@@ -91,7 +91,16 @@ _CFG_DMA = {}
 
 def cfg_is_dma(cfg_id):
     cfg_table()
-    return _CFG_DMA[cfg_id]
+    return _CFG_DMA[cfg_id] != 0
+
+
+def cfg_kernel_name(cfg_id):
+    """Canonical kernel name of a configuration: conv_igemm<TAPS,KC,MT,NT> or conv_dma<TAPS,KC,MT,NT,WAVES>."""
+    taps, kc, px, bn = cfg_table()[cfg_id]
+    d = _CFG_DMA[cfg_id]
+    waves = 8 if d == 2 else 4
+    mt = px // (16 * waves)
+    return f'conv_dma<{taps},{kc},{mt},{bn // 16},{waves}>' if d else f'conv_igemm<{taps},{kc},{mt},{bn // 16}>'
 
 
 _TUNING = None
@@ -231,7 +240,7 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
     br = None
     if _timer is not None:
         npix = B * H * W
-        br = _Bracket(f'{"conv_dma" if cfg_is_dma(plan.cfg_id) else "conv_igemm"}<{plan.taps},{plan.kc},{cfg_table()[plan.cfg_id][2] // 64},{plan.bn // 16}>',
+        br = _Bracket(cfg_kernel_name(plan.cfg_id),
                       f'{plan.taps}tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * plan.taps,
                       4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * plan.taps))
     rc = nat.lib().sqd_conv_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(xmask),
