@@ -116,6 +116,14 @@ int sqd_filter_fwd(const long long* class_ids, const float* scores, const float*
                    long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
                    int num_classes, int keep_top_k, float nms_thresh, float score_thresh, void* stream);
 
+/* GPU-side input pipeline: whiten + cv2.resize(INTER_LINEAR) + HWC->CHW of
+ * DataWrapper.__getitem__ / BaseDataset.preprocess / whiten / resize (src/engine/detector.py:132-142,
+ * src/datasets/base.py:43-59, src/utils/image.py:9-19,77-88) for a batch of uint8 RGB images of arbitrary sizes.
+ * src: device buffer with the images back to back (HWC); offsets [B] (bytes); sizes [B][2] = (H0, W0);
+ * out: NCHW fp32 [B][3][H][W]; scales [B][2] = (H/H0, W/W0) or NULL; mean3 / std3: HOST pointers to 3 floats. */
+int sqd_preprocess_u8_fwd(const unsigned char* src, const long long* offsets, const int* sizes, float* out,
+                          float* scales, const float* mean3, const float* std3, int B, int H, int W, void* stream);
+
 /* Multi-task loss (Loss.forward, src/model/squeezedet.py:133-174; compute_overlaps, modules.py:48-63).
  * pred [B][A][C+5], gt [B][A][C+9] = (mask, x1,y1,x2,y2, dx,dy,dw,dh, onehot[C]), anchors [A][4].
  * workspace: B*16*5 floats.  losses: [4][B] = (class, score = pos+neg, bbox, total); nobj: [B]. */

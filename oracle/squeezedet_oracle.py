@@ -19,7 +19,7 @@ __all__ = [
     "KITTI_ANCHOR_SEED", "KITTI_INPUT_SIZE", "arch_layers", "param_shapes", "generate_anchors",
     "backbone_forward", "resolve_predictions", "inference_head", "nms", "filter_detections",
     "boxes_postprocess", "multitask_loss", "compute_deltas", "encode_gt", "train_step_reference",
-    "xyxy_to_xywh", "xywh_to_xyxy",
+    "xyxy_to_xywh", "xywh_to_xyxy", "KITTI_RGB_MEAN", "KITTI_RGB_STD", "resize_linear_f32", "preprocess_image",
 ]
 
 EPSILON = 1e-10  # src/model/modules.py:3, src/utils/boxes.py:9
@@ -396,3 +396,49 @@ def train_step_reference(params: Dict[str, torch.Tensor], momentum_buf: Optional
         new_m[k] = buf
         new_p[k] = params[k] - lr * buf
     return new_p, new_m, grads, total, loss_vec.detach(), {k: v.detach() for k, v in stats.items()}
+
+
+# --------------------------------------------------------------------------------------
+# input pipeline -- src/utils/image.py:9-19,77-88, src/datasets/base.py:43-59,
+# src/engine/detector.py:132-142; KITTI statistics src/datasets/kitti.py:17-18
+# --------------------------------------------------------------------------------------
+KITTI_RGB_MEAN = np.array([93.877, 98.801, 95.923], dtype=np.float32)
+KITTI_RGB_STD = np.array([78.782, 80.130, 81.200], dtype=np.float32)
+
+
+def resize_linear_f32(img: np.ndarray, dst_hw: Tuple[int, int]) -> np.ndarray:
+    """cv2.resize(img, (W, H)) with the default INTER_LINEAR on float32 HWC data.  OpenCV is third party and absent
+    here (source not under /root/reference): its published algorithm restated -- parity unpinned against cv2 itself.
+    fx = (x + 0.5) * (W0 / W) - 0.5 in float64, cast to float32; sx = floor(fx), fx -= sx; clamped to the border with
+    weight 0 beyond it; horizontal pass then vertical pass, float32 arithmetic."""
+    img = np.asarray(img, dtype=np.float32)
+    H0, W0 = img.shape[:2]
+    H, W = dst_hw
+
+    def coords(n_dst, n_src):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (float(n_src) / float(n_dst)) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        s[lo] = 0; f[lo] = 0
+        hi = s >= n_src - 1
+        s[hi] = n_src - 1; f[hi] = 0
+        return s, np.minimum(s + 1, n_src - 1), f
+
+    sx, sx1, fx = coords(W, W0)
+    sy, sy1, fy = coords(H, H0)
+    ax0 = (np.float32(1) - fx)[None, :, None]; ax1 = fx[None, :, None]
+    rows0 = img[sy][:, sx] * ax0 + img[sy][:, sx1] * ax1
+    rows1 = img[sy1][:, sx] * ax0 + img[sy1][:, sx1] * ax1
+    ay0 = (np.float32(1) - fy)[:, None, None]; ay1 = fy[:, None, None]
+    return (rows0 * ay0 + rows1 * ay1).astype(np.float32)
+
+
+def preprocess_image(img_u8: np.ndarray, input_size: Tuple[int, int], mean=KITTI_RGB_MEAN, std=KITTI_RGB_STD):
+    """Eval-time ``DataWrapper.__getitem__`` for one image: float32 cast (kitti.py:52), whiten (image.py:17), resize
+    (image.py:77-86), HWC->CHW (detector.py:140).  Returns (image float32 [3,H,W], scales float32 [2])."""
+    x = img_u8.astype(np.float32)
+    x = (x - np.asarray(mean, np.float32).reshape(1, 1, 3)) / np.asarray(std, np.float32).reshape(1, 1, 3)
+    scales = np.array([input_size[0] / x.shape[0], input_size[1] / x.shape[1]], dtype=np.float32)
+    y = resize_linear_f32(x, input_size)
+    return np.ascontiguousarray(y.transpose(2, 0, 1)), scales

@@ -66,6 +66,30 @@ class Detector(object):
             results.append(det)
         return results
 
+    @torch.no_grad()
+    def detect_images(self, images, image_ids=None):
+        """Raw path: list of uint8 HWC RGB images (any sizes) -> detections in original-image coordinates.
+        Upload of the uint8 pixels, GPU pre-processing (whiten + resize + CHW), backbone, fused detection with the
+        per-image scale division, one compact D2H copy."""
+        from .preprocess import preprocess_batch
+        cfg = self.cfg
+        mean = getattr(cfg, 'rgb_mean', None)
+        std = getattr(cfg, 'rgb_std', None)
+        kw = {} if mean is None or std is None else {'rgb_mean': np.asarray(mean).reshape(-1), 'rgb_std': np.asarray(std).reshape(-1)}
+        image, scales, meta = preprocess_batch(images, cfg.input_size, device=cfg.device, **kw)
+        cnt, cls, sc, bx, idx = (t.cpu().numpy() for t in self.detect_device(image, scales=scales))
+        results = []
+        for b in range(len(images)):
+            n = int(cnt[b])
+            m = {'orig_size': meta['orig_size'][b], 'scales': meta['scales'][b], 'index': b,
+                 'image_id': image_ids[b] if image_ids is not None else str(b)}
+            if n == 0:
+                results.append({'image_meta': m})
+                continue
+            results.append({'class_ids': cls[b, :n].copy(), 'scores': sc[b, :n].copy(), 'boxes': bx[b, :n].copy(),
+                            'anchor_idx': idx[b, :n].astype(np.int64), 'image_meta': m})
+        return results
+
     def filter(self, det):
         """One image's dense ``{'class_ids' [A], 'scores' [A], 'boxes' [A,4]}`` (GPU tensors) ->
         filtered dict of GPU tensors (plus ``anchor_idx``) or ``None``."""

@@ -1,0 +1,64 @@
+"""GPU-side input pipeline.
+
+The reference pre-processes every image on the CPU inside DataLoader worker processes
+(``DataWrapper.__getitem__`` src/engine/detector.py:132-142 -> ``BaseDataset.preprocess`` src/datasets/base.py:43-59:
+``whiten`` src/utils/image.py:9-19, ``resize`` :77-88 = ``cv2.resize`` INTER_LINEAR, then ``transpose(2, 0, 1)``) and
+uploads 5.75 MB of fp32 per image.  Here the raw uint8 HWC images are uploaded (4x fewer bytes) and ONE kernel
+whitens, resizes and transposes the whole batch on the GPU.  ``image_meta`` carries the same keys the reference's
+eval path produces (``orig_size``, ``rgb_mean``, ``rgb_std``, ``scales``, ``drifts``, ``drifted_size``, ``flipped``).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+KITTI_RGB_MEAN = np.array([93.877, 98.801, 95.923], dtype=np.float32)      # src/datasets/kitti.py:17
+KITTI_RGB_STD = np.array([78.782, 80.130, 81.200], dtype=np.float32)       # src/datasets/kitti.py:18
+
+
+def preprocess_batch(images, input_size, device='cuda', rgb_mean=KITTI_RGB_MEAN, rgb_std=KITTI_RGB_STD, out=None):
+    """images: list of uint8 numpy arrays [H0, W0, 3] (RGB, any sizes).  Returns (image fp32 NCHW [B,3,H,W] on
+    ``device``, scales fp32 [B,2] = (H/H0, W/W0) on ``device``, image_meta dict of per-image lists/arrays)."""
+    if len(images) == 0:
+        raise ValueError('preprocess_batch: empty batch')
+    H, W = int(input_size[0]), int(input_size[1])
+    B = len(images)
+    sizes = np.empty((B, 2), dtype=np.int32)
+    offsets = np.empty(B, dtype=np.int64)
+    total = 0
+    for i, im in enumerate(images):
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise ValueError(f'preprocess_batch: image {i} must be uint8 [H,W,3], got {im.dtype} {im.shape}')
+        if im.shape[0] < 1 or im.shape[1] < 1:
+            raise ValueError('preprocess_batch: empty image')
+        sizes[i] = im.shape[:2]
+        offsets[i] = total
+        total += im.shape[0] * im.shape[1] * 3
+    packed = torch.empty(total, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+    pk = packed.numpy()
+    for i, im in enumerate(images):
+        pk[offsets[i]:offsets[i] + im.size] = np.ascontiguousarray(im).reshape(-1)
+    dev = torch.device(device)
+    src = packed.to(dev, non_blocking=True)
+    d_off = torch.from_numpy(offsets).to(dev, non_blocking=True)
+    d_sizes = torch.from_numpy(sizes).to(dev, non_blocking=True)
+    if out is None:
+        out = torch.empty(B, 3, H, W, device=dev, dtype=torch.float32)
+    elif tuple(out.shape) != (B, 3, H, W) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError('preprocess_batch: bad out tensor')
+    scales = torch.empty(B, 2, device=dev, dtype=torch.float32)
+    mean = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(rgb_mean).reshape(-1)])
+    std = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(rgb_std).reshape(-1)])
+    rc = nat.lib().sqd_preprocess_u8_fwd(nat.ptr(src), nat.ptr(d_off), nat.ptr(d_sizes), nat.ptr(out), nat.ptr(scales), mean, std,
+                                         B, H, W, nat.stream_handle(dev))
+    nat.check(rc, 'sqd_preprocess_u8_fwd')
+    meta = {'orig_size': np.concatenate([sizes, np.full((B, 1), 3, np.int32)], 1),
+            'scales': np.stack([np.array([H / s[0], W / s[1]], dtype=np.float32) for s in sizes]),
+            'drifts': np.zeros((B, 2), np.int32), 'flipped': [False] * B,
+            'rgb_mean': np.tile(np.asarray(rgb_mean, np.float32).reshape(1, 1, 1, 3), (B, 1, 1, 1)),
+            'rgb_std': np.tile(np.asarray(rgb_std, np.float32).reshape(1, 1, 1, 3), (B, 1, 1, 1))}
+    return out, scales, meta

@@ -1,0 +1,85 @@
+"""Input pipeline: oracle known-answer tests on CPU, GPU kernel vs oracle on the MI355X."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+
+def test_resize_identity_and_ramp_known_answers():
+    rs = np.random.RandomState(0)
+    img = rs.uniform(-2, 2, (7, 9, 3)).astype(np.float32)
+    assert np.array_equal(oracle.resize_linear_f32(img, (7, 9)), img)                     # same size: exact copy
+    # 2x upsample of a horizontal ramp: half-pixel centres -> dst x maps to src (x+0.5)/2-0.5, clamped at the border
+    ramp = np.tile(np.arange(4, dtype=np.float32)[None, :, None], (2, 1, 3))
+    up = oracle.resize_linear_f32(ramp, (2, 8))[0, :, 0]
+    np.testing.assert_allclose(up, [0, 0.25, 0.75, 1.25, 1.75, 2.25, 2.75, 3.0], atol=1e-6)
+    # 2x downsample averages pixel pairs
+    down = oracle.resize_linear_f32(ramp, (2, 2))[0, :, 0]
+    np.testing.assert_allclose(down, [0.5, 2.5], atol=1e-6)
+    # constant image stays constant under any resize
+    c = np.full((5, 6, 3), 1.25, np.float32)
+    assert np.allclose(oracle.resize_linear_f32(c, (11, 13)), 1.25)
+
+
+def test_preprocess_image_layout_and_scales():
+    img = np.random.RandomState(1).randint(0, 256, (375, 1242, 3), dtype=np.uint8)
+    x, scales = oracle.preprocess_image(img, (384, 1248))
+    assert x.shape == (3, 384, 1248) and x.dtype == np.float32
+    np.testing.assert_allclose(scales, [384 / 375., 1248 / 1242.], rtol=1e-7)
+    # whitening statistics: channel c of a constant image
+    const = np.zeros((10, 10, 3), np.uint8); const[:] = (93, 98, 95)
+    y, _ = oracle.preprocess_image(const, (20, 20))
+    exp = (np.array([93, 98, 95], np.float32) - oracle.KITTI_RGB_MEAN) / oracle.KITTI_RGB_STD
+    np.testing.assert_allclose(y[:, 3, 4], exp, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [[(375, 1242), (370, 1224)], [(384, 1248)], [(50, 61), (123, 77), (9, 5)], [(800, 2000)]])
+def test_gpu_preprocess_vs_oracle(sizes):
+    from squeezedet_pytorch_amd.preprocess import preprocess_batch
+    rs = np.random.RandomState(2)
+    images = [rs.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    out, scales, meta = preprocess_batch(images, (384, 1248))
+    assert tuple(out.shape) == (len(images), 3, 384, 1248)
+    for b, im in enumerate(images):
+        ref, sc = oracle.preprocess_image(im, (384, 1248))
+        np.testing.assert_allclose(out[b].cpu().numpy(), ref, atol=2e-5, rtol=0)
+        np.testing.assert_allclose(scales[b].cpu().numpy(), sc, rtol=1e-6)
+        np.testing.assert_allclose(meta['scales'][b], sc, rtol=1e-7)
+
+
+@pytest.mark.gpu
+def test_detect_images_end_to_end():
+    """uint8 images -> GPU preprocess -> backbone -> fused detect, vs the oracle fed with the oracle's own
+    pre-processed tensor (same kept anchors away from near-ties; boxes in original-image coordinates)."""
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd import synthetic
+    from squeezedet_pytorch_amd.detector import Detector
+    from squeezedet_pytorch_amd.model import SqueezeDet
+    cfg = sqd.make_cfg()
+    m = SqueezeDet(cfg); sd = synthetic.make_state_dict(); m.load_state_dict(sd)
+    det = Detector(m, cfg)
+    rs = np.random.RandomState(3)
+    base = (rs.standard_normal((2, 48, 156, 3)) * 60 + 100)
+    images = [np.clip(np.kron(base[0], np.ones((8, 8, 1))), 0, 255).astype(np.uint8)[:375, :1242],
+              np.clip(np.kron(base[1], np.ones((8, 8, 1))), 0, 255).astype(np.uint8)[:370, :1224]]
+    res = det.detect_images(images, image_ids=['a', 'b'])
+    assert len(res) == 2
+    for b, im in enumerate(images):
+        x, sc = oracle.preprocess_image(im, cfg.input_size)
+        with torch.no_grad():
+            pred = oracle.backbone_forward(torch.from_numpy(x)[None], sd)
+        ids, s, bx = oracle.inference_head(pred, cfg.anchors, cfg.input_size)
+        d = oracle.filter_detections(ids[0].numpy(), s[0].numpy(), bx[0].numpy())
+        r = res[b]
+        assert r['image_meta']['image_id'] == ['a', 'b'][b]
+        if d is None:
+            assert 'boxes' not in r
+            continue
+        common = set(r['anchor_idx'].tolist()) & set(d['anchor_idx'].tolist())
+        assert len(common) >= len(d['anchor_idx']) - 2
+        ref_boxes = {int(i): bb for i, bb in zip(d['anchor_idx'], oracle.boxes_postprocess(d['boxes'], sc))}
+        for i, bb in zip(r['anchor_idx'], r['boxes']):
+            if int(i) in ref_boxes:
+                np.testing.assert_allclose(bb, ref_boxes[int(i)], atol=2e-2)
