@@ -124,6 +124,16 @@ int sqd_filter_fwd(const long long* class_ids, const float* scores, const float*
 int sqd_preprocess_u8_fwd(const unsigned char* src, const long long* offsets, const int* sizes, float* out,
                           float* scales, const float* mean3, const float* std3, int B, int H, int W, void* stream);
 
+/* On-device GT encoding: compute_deltas (src/utils/boxes.py:84-135: greedy unique
+ * anchor assignment by free-anchor IoU, nearest free anchor by squared (cx,cy,w,h) distance when no free anchor
+ * overlaps) + BaseDataset.prepare_annotations (src/datasets/base.py:61-76: dense gt row = mask, xyxy, deltas,
+ * one-hot).  boxes [total][4] xyxy fp32, class_ids [total] int32, box_offsets [B+1] int32, anchors [A][4] FLOAT64
+ * (cx,cy,w,h; the reference keeps them in float64 and the overlaps are float64 arithmetic).  Outputs, each may be
+ * NULL: gt [B][A][C+9] (fully overwritten), anchor_idx [total] int32 (A = unassigned), deltas [total][4] fp32.
+ * Ties in overlap / distance -> lowest anchor index (the reference leaves them to numpy's unstable argsort). */
+int sqd_encode_gt_fwd(const float* boxes, const int* class_ids, const int* box_offsets, const double* anchors,
+                      float* gt, int* anchor_idx, float* deltas, int B, int A, int num_classes, void* stream);
+
 /* Multi-task loss (Loss.forward, src/model/squeezedet.py:133-174; compute_overlaps, modules.py:48-63).
  * pred [B][A][C+5], gt [B][A][C+9] = (mask, x1,y1,x2,y2, dx,dy,dw,dh, onehot[C]), anchors [A][4].
  * workspace: B*16*5 floats.  losses: [4][B] = (class, score = pos+neg, bbox, total); nobj: [B]. */

@@ -313,8 +313,14 @@ def multitask_loss(pred: torch.Tensor, gt: torch.Tensor, anchors: np.ndarray, in
 # --------------------------------------------------------------------------------------
 # GT encoding (hot-path *input*, CPU) -- src/utils/boxes.py:12-34,70-135, src/datasets/base.py:61-76
 # --------------------------------------------------------------------------------------
-def compute_deltas(boxes_xyxy: np.ndarray, anchors_xywh: np.ndarray):
-    """Greedy unique anchor assignment + regression targets (src/utils/boxes.py:84-135)."""
+def compute_deltas(boxes_xyxy: np.ndarray, anchors_xywh: np.ndarray, ties: str = "argsort"):
+    """Greedy unique anchor assignment + regression targets (src/utils/boxes.py:84-135).
+
+    ``ties="argsort"`` keeps the reference's literal ``np.argsort`` walk (tie order = whatever numpy's unstable sort
+    yields on this machine); ``ties="lowest"`` is the rule the HIP encoder implements: among free anchors with
+    exactly equal overlap (distance) the lowest anchor index wins.  Both pick an anchor of maximal free overlap."""
+    if ties == "lowest":
+        return _compute_deltas_lowest(boxes_xyxy, anchors_xywh)
     boxes_xyxy = np.asarray(boxes_xyxy)
     A = anchors_xywh.shape[0]
     bx = np.stack([(boxes_xyxy[:, 0] + boxes_xyxy[:, 2]) / 2., (boxes_xyxy[:, 1] + boxes_xyxy[:, 3]) / 2.,
@@ -351,9 +357,42 @@ def compute_deltas(boxes_xyxy: np.ndarray, anchors_xywh: np.ndarray):
     return np.array(deltas, dtype=np.float32), np.array(idxs, dtype=np.int32)            # :132-133
 
 
-def encode_gt(class_ids: np.ndarray, boxes_xyxy: np.ndarray, anchors_xywh: np.ndarray, num_classes: int = 3) -> np.ndarray:
+def _compute_deltas_lowest(boxes_xyxy: np.ndarray, anchors_xywh: np.ndarray):
+    """Same arithmetic as ``compute_deltas`` (same numpy expressions, hence the same float32/float64 promotion),
+    selection by masked arg-max / arg-min (numpy returns the first, i.e. lowest-index, extremum)."""
+    boxes_xyxy = np.asarray(boxes_xyxy)
+    A = anchors_xywh.shape[0]
+    bx = np.stack([(boxes_xyxy[:, 0] + boxes_xyxy[:, 2]) / 2., (boxes_xyxy[:, 1] + boxes_xyxy[:, 3]) / 2.,
+                   boxes_xyxy[:, 2] - boxes_xyxy[:, 0] + 1., boxes_xyxy[:, 3] - boxes_xyxy[:, 1] + 1.], 1)
+    ax = np.stack([anchors_xywh[:, 0] - 0.5 * (anchors_xywh[:, 2] - 1), anchors_xywh[:, 1] - 0.5 * (anchors_xywh[:, 3] - 1),
+                   anchors_xywh[:, 0] + 0.5 * (anchors_xywh[:, 2] - 1), anchors_xywh[:, 1] + 0.5 * (anchors_xywh[:, 3] - 1)], 1)
+    taken = np.zeros(A, dtype=bool)
+    idxs, deltas = [], []
+    for i in range(boxes_xyxy.shape[0]):
+        box = boxes_xyxy[i]
+        lr = np.maximum(np.minimum(ax[:, 2], box[2]) - np.maximum(ax[:, 0], box[0]), 0)
+        tb = np.maximum(np.minimum(ax[:, 3], box[3]) - np.maximum(ax[:, 1], box[1]), 0)
+        inter = lr * tb
+        union = (ax[:, 2] - ax[:, 0]) * (ax[:, 3] - ax[:, 1]) + (box[2] - box[0]) * (box[3] - box[1]) - inter
+        ov = inter / (union + EPSILON)
+        if taken.all():
+            idxs.append(A); deltas.append([0., 0., 0., 0.])
+            continue
+        j = int(np.argmax(np.where(taken, -1.0, ov)))
+        if not ov[j] > 0:
+            dist = np.sum((bx[i] - anchors_xywh) ** 2, axis=1)
+            j = int(np.argmin(np.where(taken, np.inf, dist)))
+        taken[j] = True
+        idxs.append(j)
+        deltas.append([(bx[i, 0] - anchors_xywh[j, 0]) / anchors_xywh[j, 2], (bx[i, 1] - anchors_xywh[j, 1]) / anchors_xywh[j, 3],
+                       np.log(bx[i, 2] / anchors_xywh[j, 2]), np.log(bx[i, 3] / anchors_xywh[j, 3])])
+    return np.array(deltas, dtype=np.float32).reshape(-1, 4), np.array(idxs, dtype=np.int32)
+
+
+def encode_gt(class_ids: np.ndarray, boxes_xyxy: np.ndarray, anchors_xywh: np.ndarray, num_classes: int = 3,
+              ties: str = "argsort") -> np.ndarray:
     """Dense gt [A, C+9] = [mask, x1,y1,x2,y2, dx,dy,dw,dh, onehot] (src/datasets/base.py:61-76)."""
-    deltas, idx = compute_deltas(boxes_xyxy, anchors_xywh)
+    deltas, idx = compute_deltas(boxes_xyxy, anchors_xywh, ties=ties)
     gt = np.zeros((anchors_xywh.shape[0], num_classes + 9), dtype=np.float32)
     gt[idx, 0] = 1.
     gt[idx, 1:5] = boxes_xyxy

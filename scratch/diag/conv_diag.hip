@@ -37,6 +37,7 @@ struct ConvArgs {
   int N, Npad, y_pitch, y_coff;
   int relu, accumulate;
   int tiles_x, tiles_y, ntiles;
+  int nslices, gx;                           // persistent grid: gx tile streams x nslices channel slices (1-D launch)
   int xmask_pitch, xmask_coff;
   const float* ymask; const float* ymul;      // epilogue: zero where ymask <= 0 (ReLU backward), multiply by ymul (dropout)
   int ymask_pitch, ymask_coff, ymul_pitch, ymul_coff;
@@ -65,11 +66,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware mapping (workgroups b and b+8 share an XCD and its L2): the channel slices of one tile stream get
+  // consecutive ids on the SAME XCD, so they run together and re-read their activation tiles from that L2
+  const int wgq = (int)blockIdx.x >> 3;
+  const int n0 = (wgq % a.nslices) * BN;
+  const int tstride = a.gx;
   const int nchunks = (a.C + KC - 1) / KC;
   const bool w_stationary = (nchunks == 1);   // whole K fits one chunk: weights stay in LDS across tiles
   const int ntiles = a.ntiles;
-  int tile = blockIdx.x;
+  int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
   if (tile >= ntiles) return;
 
   f32x4 ra[A_IT], rw[W_IT];
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     for (int cc = 0; cc < nchunks; ++cc) {
       // ---- prefetch the next stage (next K chunk, or chunk 0 of this workgroup's next tile) ----
       int ncc = cc + 1, ntile = tile;
-      if (ncc == nchunks) { ncc = 0; ntile = tile + (int)gridDim.x; }
+      if (ncc == nchunks) { ncc = 0; ntile = tile + tstride; }
       const bool has_next = ntile < ntiles;
       const bool next_w = has_next && !w_stationary;
       if (has_next) load_act(ntile, ncc);
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
       if (next_w) store_w();
       __syncthreads();
     }
-    tile += (int)gridDim.x;
+    tile += tstride;
     if (tile >= ntiles) break;
   }
 }
@@ -258,9 +263,9 @@ __device__ __attribute__((aligned(16))) float sqd_zero_page[4] = {0.f, 0.f, 0.f,
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int TAPS, int KC, int MT, int NT, int MINW>
-__global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
-  constexpr int WM = 4;
+template <int TAPS, int KC, int MT, int NT, int WM, int MINW>
+__global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
+  constexpr int NTHR = WM * 64;              // 4 or 8 waves; with 8, two waves per SIMD share one staged tile
   constexpr int TH = MT * WM;
   constexpr int BN = 16 * NT;
   constexpr int NPIX = (TAPS == 9) ? (TH + 2) * 18 : TH * 16;
@@ -268,10 +273,10 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
   constexpr int WROWS = TAPS * BN;
   constexpr int KV = KC / 4;
   // 16-byte slots, rounded to whole workgroup passes (4 waves x 64 lanes) so the DMA issue is branch-free
-  constexpr int ASLOTS = (KV * NPIXP + 255) & ~255;
-  constexpr int WSLOTS = (KV * WROWS + 255) & ~255;
-  constexpr int A_IT = ASLOTS / 256;
-  constexpr int W_IT = WSLOTS / 256;
+  constexpr int ASLOTS = (KV * NPIXP + NTHR - 1) / NTHR * NTHR;
+  constexpr int WSLOTS = (KV * WROWS + NTHR - 1) / NTHR * NTHR;
+  constexpr int A_IT = ASLOTS / NTHR;
+  constexpr int W_IT = WSLOTS / NTHR;
   constexpr int STEPS = TAPS * (KC / 16);               // MFMA groups per stage; DMA issue is spread over them
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // layout: act[0], act[1], w[0], (w[1] unless the weights are stationary)
@@ -280,18 +285,21 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware mapping: see conv_igemm_kernel
+  const int wgq = (int)blockIdx.x >> 3;
+  const int n0 = (wgq % a.nslices) * BN;
+  const int tstride = a.gx;
   const int nchunks = (a.C + KC - 1) / KC;
   const bool w_stationary = (nchunks == 1);
   const int ntiles = a.ntiles;
-  int tile = blockIdx.x;
+  int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
   if (tile >= ntiles) return;
 
   // tile-independent part of every lane's DMA slots
   int a_v[A_IT], a_r[A_IT], a_c[A_IT];                  // plane, tile row / col (3x3) or flat pixel (1x1, in a_c)
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    const int slot = it * 256 + tid;
+    const int slot = it * NTHR + tid;
     const int v = slot / NPIXP, pix = slot - v * NPIXP;
     a_v[it] = (v < KV && pix < NPIX) ? v : -1;
     if (TAPS == 9) { a_r[it] = pix / 18; a_c[it] = pix - a_r[it] * 18; } else { a_r[it] = 0; a_c[it] = pix; }
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
   long long w_off[W_IT];                                // float offset inside one chunk's packed weights, -1 = zero page
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) {
-    const int slot = it * 256 + tid;
+    const int slot = it * NTHR + tid;
     const int v = slot / WROWS, tn = slot - v * WROWS;
     const int tap = tn / BN, n = tn - tap * BN;
     w_off[it] = (v < KV) ? (((long long)v * TAPS + tap) * a.Npad + n0 + n) * 4 : -1;
@@ -331,11 +339,11 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
       ok = ok && gp < a.total_px;
     }
     const float* src = ok ? a.x + gp * a.x_pitch + a.x_coff + c : sqd_zero_page;
-    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(actB + (buf * ASLOTS + it * 256 + wm * 64) * 4), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(actB + (buf * ASLOTS + it * NTHR + wm * 64) * 4), 16, 0, 0);
   };
   auto dma_w_one = [&](int it, int cc, int buf) {
     const float* src = (w_off[it] >= 0) ? a.w + cc * w_chunk + w_off[it] : sqd_zero_page;
-    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(wB + (buf * WSLOTS + it * 256 + wm * 64) * 4), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(wB + (buf * WSLOTS + it * NTHR + wm * 64) * 4), 16, 0, 0);
   };
 
   f32x4 acc[MT][NT], outv[MT][NT];
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
       __syncthreads();                 // vmcnt(0): this stage's DMA has landed; all waves left the previous stage
       if (pending >= 0) { flush(pending); pending = -1; }
       int ncc = cc + 1, ntile = tile;
-      if (ncc == nchunks) { ncc = 0; ntile = tile + (int)gridDim.x; }
+      if (ncc == nchunks) { ncc = 0; ntile = tile + tstride; }
 #ifdef DIAG_NODMA
       const bool has_next = false;
 #else
@@ -427,11 +435,19 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             const int row = (TAPS == 9) ? ((wm * MT + i) + dy) * 18 + lr + dx : (wm * MT + i) * 16 + lr;
+#ifdef DIAG_NOLDS
+            { const float q = (float)(lane + i + tap) * 1e-3f; bf[i] = (f32x4){q, q + 1.f, q + 2.f, q + 3.f}; asm volatile("" : "+v"(bf[i])); }
+#else
             bf[i] = *(const f32x4*)(actT + ((4 * s + g) * NPIXP + row) * 4);
+#endif
           }
 #pragma unroll
           for (int j = 0; j < NT; ++j)
+#ifdef DIAG_NOLDS
+            { const float q = (float)(lane + j + s) * 1e-3f; af[j] = (f32x4){q, q - 1.f, q - 2.f, q - 3.f}; asm volatile("" : "+v"(af[j])); }
+#else
             af[j] = *(const f32x4*)(wT + ((4 * s + g) * WROWS + tap * BN + j * 16 + lr) * 4);
+#endif
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(256, MINW) void conv_dma_kernel(ConvArgs a) {
       sbuf ^= 1;
       if (!w_stationary) wbuf ^= 1;
     }
-    tile += (int)gridDim.x;
+    tile += tstride;
     if (tile >= ntiles) break;
   }
   if (pending >= 0) flush(pending);
@@ -503,34 +519,37 @@ static int launch_conv(ConvArgs a, hipStream_t stream) {
   const int slots = sqd_num_cus() * wgs_per_cu;
   int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
   const int per_wg = sqd_cdiv(a.ntiles, gx_max);
-  const int gx = sqd_cdiv(a.ntiles, per_wg);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(256), lds, stream, a);
+  const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;        // tile streams, a multiple of 8 (one per XCD lane)
+  a.nslices = nslices; a.gx = gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx * nslices)), dim3(256), lds, stream, a);
   return sqd_launch_status();
 }
 
-template <int TAPS, int KC, int MT, int NT>
+template <int TAPS, int KC, int MT, int NT, int WM>
 static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
-  constexpr int TH = MT * 4, BN = 16 * NT;
+  constexpr int TH = MT * WM, BN = 16 * NT, NTHR = WM * 64;
   constexpr int NPIX = (TAPS == 9) ? (TH + 2) * 18 : TH * 16;
   constexpr int NPIXP = (NPIX + 15) & ~15;
   constexpr int KV = KC / 4;
-  constexpr int ASLOTS = (KV * NPIXP + 255) & ~255, WSLOTS = (KV * TAPS * BN + 255) & ~255;
+  constexpr int ASLOTS = (KV * NPIXP + NTHR - 1) / NTHR * NTHR, WSLOTS = (KV * TAPS * BN + NTHR - 1) / NTHR * NTHR;
   constexpr size_t lds_max = (size_t)(2 * ASLOTS + 2 * WSLOTS) * 16;
   static_assert(lds_max <= 160 * 1024, "LDS budget");
   if (a.xmask) return SQD_ERR_UNSUPPORTED;               // input-side mask needs register staging (v3 path)
   const int stationary = (a.C <= KC) ? 1 : 0;            // one K chunk: a single weight buffer suffices
   const size_t lds = (size_t)(2 * ASLOTS + (stationary ? 1 : 2) * WSLOTS) * 16;
+  // waves per SIMD the register allocator must leave room for: workgroups per CU (by LDS) x waves per SIMD of one
   constexpr int REGW = (MT * NT <= 4) ? 4 : ((MT * NT <= 6) ? 3 : 2);
-  constexpr int LDSW = (int)((160 * 1024) / ((size_t)(2 * ASLOTS + WSLOTS) * 16));
-  constexpr int MINW = LDSW < REGW ? (LDSW < 1 ? 1 : LDSW) : REGW;
-  auto kern = conv_dma_kernel<TAPS, KC, MT, NT, MINW>;
+  constexpr int LDSW = (int)((160 * 1024) / ((size_t)(2 * ASLOTS + WSLOTS) * 16)) * (WM / 4);
+  constexpr int MINW0 = LDSW < REGW ? (LDSW < 1 ? 1 : LDSW) : REGW;
+  constexpr int MINW = (MINW0 < WM / 4) ? WM / 4 : MINW0;
+  auto kern = conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW>;
   static int wgs_per_cu[2] = {0, 0};
   if (wgs_per_cu[stationary] == 0) {
     if (lds_max > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
       return SQD_ERR_LAUNCH;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
     wgs_per_cu[stationary] = nb > 6 ? 6 : nb;
   }
   if (TAPS == 9) {
@@ -545,14 +564,15 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   const int slots = sqd_num_cus() * wgs_per_cu[stationary];
   int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
   const int per_wg = sqd_cdiv(a.ntiles, gx_max);
-  const int gx = sqd_cdiv(a.ntiles, per_wg);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(256), lds, stream, a);
+  const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;        // tile streams, a multiple of 8 (one per XCD lane)
+  a.nslices = nslices; a.gx = gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx * nslices)), dim3(NTHR), lds, stream, a);
   return sqd_launch_status();
 }
 
 // Tile configurations (cfg_id) -> template instance.  The host picks per layer; any config is
 // correct for any shape (edges are masked, partial K chunks zero-filled).
-struct ConvCfg { int taps, kc, mt, nt, dma; };
+struct ConvCfg { int taps, kc, mt, nt, dma; };   // dma: 0 = register-staged 4 waves, 1 = LDS-DMA 4 waves, 2 = LDS-DMA 8 waves
 static const ConvCfg kConvCfgs[] = {
     {1, 16, 2, 4, 0},  // 0  1x1, small C (expand1x1), 128 px x 64 ch
     {1, 32, 2, 1, 0},  // 1  1x1 squeeze N<=16
@@ -620,12 +640,26 @@ static const ConvCfg kConvCfgs[] = {
     {1, 64, 1, 6, 1},  // 62
     {1, 64, 2, 1, 1},  // 63
     {1, 64, 2, 2, 1},  // 64
+    // ---- LDS-DMA, 8-wave workgroups (dma = 2): tile = mt*8 rows ----
+    {9, 16, 1, 2, 2},  // 65  8x16 px x 32 ch
+    {9, 16, 1, 3, 2},  // 66
+    {9, 16, 1, 4, 2},  // 67  8x16 px x 64 ch
+    {9, 16, 2, 1, 2},  // 68  16x16 px x 16 ch
+    {9, 16, 2, 2, 2},  // 69  16x16 px x 32 ch
+    {9, 16, 2, 3, 2},  // 70
+    {9, 16, 2, 4, 2},  // 71  16x16 px x 64 ch
+    {9, 16, 1, 5, 2},  // 72  8x16 px x 80 ch
+    {1, 32, 1, 2, 2},  // 73
+    {1, 32, 1, 4, 2},  // 74
+    {1, 32, 2, 2, 2},  // 75
+    {1, 16, 1, 4, 2},  // 76
+    {1, 16, 2, 4, 2},  // 77
 };
 static const int kNumConvCfgs = (int)(sizeof(kConvCfgs) / sizeof(kConvCfgs[0]));
 
 extern "C" int sqd_conv_num_cfgs() { return kNumConvCfgs; }
 
-// 1 if the configuration stages through LDS-DMA (no input-side xmask support), 0 if through registers, -1 bad id
+// 0: register-staged (4 waves); 1: LDS-DMA, 4 waves; 2: LDS-DMA, 8 waves (no xmask support when != 0); -1: bad id
 extern "C" int sqd_conv_cfg_is_dma(int cfg_id) {
   if (cfg_id < 0 || cfg_id >= kNumConvCfgs) return -1;
   return kConvCfgs[cfg_id].dma;
@@ -636,7 +670,7 @@ extern "C" int sqd_conv_cfg_info(int cfg_id, int* taps, int* kc, int* tile_px, i
   const ConvCfg& c = kConvCfgs[cfg_id];
   if (taps) *taps = c.taps;
   if (kc) *kc = c.kc;
-  if (tile_px) *tile_px = c.mt * 4 * 16;
+  if (tile_px) *tile_px = c.mt * (c.dma == 2 ? 8 : 4) * 16;
   if (bn) *bn = 16 * c.nt;
   return SQD_OK;
 }
@@ -662,13 +696,21 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.xmask = xmask;
   a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff;
-  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0;
+  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8;
   a.xmask_pitch = xmask_pitch; a.xmask_coff = xmask_coff;
   a.total_px = (long long)B * H * W;
   hipStream_t s = (hipStream_t)stream;
   const ConvCfg& c = kConvCfgs[cfg_id];
+#define SQD_DMA8_CASE(T, K, M, Nn) \
+  if (c.dma == 2 && c.taps == T && c.kc == K && c.mt == M && c.nt == Nn) return launch_conv_dma<T, K, M, Nn, 8>(a, s);
+  SQD_DMA8_CASE(9, 16, 1, 2) SQD_DMA8_CASE(9, 16, 1, 3) SQD_DMA8_CASE(9, 16, 1, 4) SQD_DMA8_CASE(9, 16, 2, 1)
+  SQD_DMA8_CASE(9, 16, 2, 2) SQD_DMA8_CASE(9, 16, 2, 3) SQD_DMA8_CASE(9, 16, 2, 4) SQD_DMA8_CASE(9, 16, 1, 5)
+  SQD_DMA8_CASE(1, 32, 1, 2) SQD_DMA8_CASE(1, 32, 1, 4) SQD_DMA8_CASE(1, 32, 2, 2) SQD_DMA8_CASE(1, 16, 1, 4)
+  SQD_DMA8_CASE(1, 16, 2, 4)
+#undef SQD_DMA8_CASE
+  if (c.dma == 2) return SQD_ERR_UNSUPPORTED;
 #define SQD_DMA_CASE(T, K, M, Nn) \
-  if (c.dma && c.taps == T && c.kc == K && c.mt == M && c.nt == Nn) return launch_conv_dma<T, K, M, Nn>(a, s);
+  if (c.dma && c.taps == T && c.kc == K && c.mt == M && c.nt == Nn) return launch_conv_dma<T, K, M, Nn, 4>(a, s);
   SQD_DMA_CASE(9, 16, 1, 1) SQD_DMA_CASE(9, 16, 1, 2) SQD_DMA_CASE(9, 16, 1, 3) SQD_DMA_CASE(9, 16, 1, 4)
   SQD_DMA_CASE(9, 16, 2, 1) SQD_DMA_CASE(9, 16, 2, 2) SQD_DMA_CASE(9, 16, 2, 3) SQD_DMA_CASE(9, 16, 2, 4)
   SQD_DMA_CASE(9, 16, 4, 1) SQD_DMA_CASE(9, 16, 4, 2)

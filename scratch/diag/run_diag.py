@@ -5,7 +5,7 @@ import squeezedet_pytorch_amd as sqd
 from squeezedet_pytorch_amd import ops, _native as nat
 shapes = [(9, 16, 64, 96, 312, (38, 42, 44)), (9, 96, 384, 24, 78, (43, 42, 44)), (9, 64, 256, 24, 78, (42, 38))]
 B = 20
-for v in ['base', 'nostore', 'nodma', 'nostore_nodma']:
+for v in ['base', 'nostore_nodma', 'nostore_nodma_nolds']:
     lib = ctypes.CDLL(os.path.join(here, f'libdiag_{v}.so'))
     lib.sqd_conv_fwd.argtypes = nat._SIGNATURES['sqd_conv_fwd']; lib.sqd_conv_fwd.restype = ctypes.c_int
     for taps, C, N, h, w, cfgs in shapes:

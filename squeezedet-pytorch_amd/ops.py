@@ -593,3 +593,31 @@ def loss_bwd(pred, gt, anchors, nobj, coef, input_size, num_classes, weights):
     if br is not None:
         br.done()
     return dpred
+
+
+def encode_gt(boxes, class_ids, box_offsets, anchors64, num_classes, dense=True):
+    """On-device GT encoding (compute_deltas + prepare_annotations, src/utils/boxes.py:84-135,
+    src/datasets/base.py:61-76).  boxes [total,4] fp32 xyxy, class_ids [total] i32, box_offsets [B+1] i32,
+    anchors64 [A,4] float64 -- all on the GPU.  -> (gt [B,A,C+9] or None, anchor_idx [total] i32, deltas [total,4])."""
+    if boxes.dtype != torch.float32 or class_ids.dtype != torch.int32 or box_offsets.dtype != torch.int32:
+        raise ValueError('encode_gt: boxes must be float32, class_ids / box_offsets int32')
+    if anchors64.dtype != torch.float64 or anchors64.dim() != 2 or anchors64.shape[1] != 4:
+        raise ValueError('encode_gt: anchors must be float64 [A,4] (the reference matches anchors in float64)')
+    if boxes.dim() != 2 or boxes.shape[1] != 4 or class_ids.shape[0] != boxes.shape[0] or box_offsets.dim() != 1:
+        raise ValueError('encode_gt: boxes [total,4], class_ids [total], box_offsets [B+1]')
+    B, A, total = box_offsets.shape[0] - 1, anchors64.shape[0], boxes.shape[0]
+    if B < 1:
+        raise ValueError('encode_gt: empty batch')
+    boxes, class_ids, box_offsets, anchors64 = boxes.contiguous(), class_ids.contiguous(), box_offsets.contiguous(), anchors64.contiguous()
+    dev = boxes.device
+    gt = torch.empty(B, A, num_classes + 9, device=dev, dtype=torch.float32) if dense else None
+    idx = torch.empty(max(total, 1), device=dev, dtype=torch.int32)
+    deltas = torch.empty(max(total, 1), 4, device=dev, dtype=torch.float32)
+    br = _Bracket('encode_gt', f'gt A{A}', 0.0, 4.0 * B * A * (num_classes + 9)) if _timer is not None else None
+    rc = nat.lib().sqd_encode_gt_fwd(nat.ptr(boxes) if total else None, nat.ptr(class_ids) if total else nat.ptr(idx),
+                                     nat.ptr(box_offsets), nat.ptr(anchors64), nat.ptr(gt) if dense else None, nat.ptr(idx),
+                                     nat.ptr(deltas), B, A, int(num_classes), nat.stream_handle(dev))
+    nat.check(rc, 'sqd_encode_gt_fwd')
+    if br is not None:
+        br.done()
+    return gt, idx[:total], deltas[:total]

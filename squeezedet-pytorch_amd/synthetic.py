@@ -94,12 +94,12 @@ def make_images(batch, input_size, seed=0):
     return torch.from_numpy(img)
 
 
-def make_gt(batch, anchors, input_size, num_classes=3, seed=1, min_boxes=3, max_boxes=8):
-    """Dense gt ``[B, A, C+9]`` from random boxes (uniform centres, log-uniform sizes
-    20..min(400, dim/2) px, uniform class), encoded with ``prepare_annotations``."""
+def make_gt_boxes(batch, input_size, num_classes=3, seed=1, min_boxes=3, max_boxes=8):
+    """Random sparse annotations: per-image lists (class_ids [n], xyxy boxes [n,4] float32); uniform centres,
+    log-uniform sizes 20..min(400, dim/2) px, uniform class."""
     rs = np.random.RandomState(seed)
     h, w = input_size
-    out = np.zeros((batch, anchors.shape[0], num_classes + 9), dtype=np.float32)
+    cls_list, box_list = [], []
     for b in range(batch):
         n = rs.randint(min_boxes, max_boxes + 1)
         hi_w, hi_h = min(400., w / 2.), min(400., h / 2.)
@@ -109,7 +109,15 @@ def make_gt(batch, anchors, input_size, num_classes=3, seed=1, min_boxes=3, max_
         cy = rs.uniform(0, h - 1, n)
         x1 = np.clip(cx - bw / 2, 0, w - 2); x2 = np.clip(cx + bw / 2, x1 + 1, w - 1)
         y1 = np.clip(cy - bh / 2, 0, h - 2); y2 = np.clip(cy + bh / 2, y1 + 1, h - 1)
-        boxes = np.stack([x1, y1, x2, y2], 1).astype(np.float32)
-        cls = rs.randint(0, num_classes, n)
-        out[b] = prepare_annotations(cls, boxes, anchors, num_classes)
+        box_list.append(np.stack([x1, y1, x2, y2], 1).astype(np.float32))
+        cls_list.append(rs.randint(0, num_classes, n))
+    return cls_list, box_list
+
+
+def make_gt(batch, anchors, input_size, num_classes=3, seed=1, min_boxes=3, max_boxes=8):
+    """Dense gt ``[B, A, C+9]`` from ``make_gt_boxes``, encoded on the host with ``prepare_annotations``."""
+    cls_list, box_list = make_gt_boxes(batch, input_size, num_classes, seed, min_boxes, max_boxes)
+    out = np.zeros((batch, anchors.shape[0], num_classes + 9), dtype=np.float32)
+    for b in range(batch):
+        out[b] = prepare_annotations(cls_list[b], box_list[b], anchors, num_classes)
     return torch.from_numpy(out)

@@ -98,8 +98,15 @@ class Trainer(object):
         for iter_id, batch in enumerate(data_loader):
             if iter_id >= num_iters:
                 break
+            if 'gt' not in batch and 'gt_boxes' in batch:
+                # sparse annotations (per-image lists of xyxy boxes / class ids): encode the dense gt on the GPU
+                # instead of in DataLoader workers (prepare_annotations, src/datasets/base.py:61-76)
+                from .annotations import encode_annotations
+                batch = dict(batch)
+                batch['gt'] = encode_annotations(batch.pop('gt_class_ids'), batch.pop('gt_boxes'), self.cfg.anchors,
+                                                 self.cfg.num_classes, device=self.cfg.device)
             for k in batch:
-                if 'image_meta' not in k:
+                if 'image_meta' not in k and isinstance(batch[k], torch.Tensor):
                     batch[k] = batch[k].to(device=self.cfg.device, non_blocking=True)
             data_timer.update(time.time() - end)
             end = time.time()

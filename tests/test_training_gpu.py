@@ -236,3 +236,49 @@ def test_stem_wgrad_pooled(k, N, H, W):
     assert (db.cpu() - b.grad).abs().max().item() <= 2e-4 * max(1.0, float(b.grad.abs().max()))
     dw2, db2 = ops.stem_wgrad_pooled(_nhwc(dy).cuda(), pooled, am, x.cuda(), N, k)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)          # deterministic
+
+
+def test_trainer_epochs_dense_and_sparse_annotations():
+    """Trainer.train_epoch / val_epoch (src/engine/trainer.py:18-80) over a list "loader": logged losses match the
+    oracle's step-by-step run, and batches with sparse annotations (encoded on the GPU) give the same run as
+    batches with the host-encoded dense gt."""
+    from squeezedet_pytorch_amd.trainer import Trainer
+    size = (64, 96)
+    logs = {}
+    for mode in ("dense", "sparse"):
+        cfg, m, sd = _train_model('squeezedet', size)
+        cfg.num_iters, cfg.print_interval, cfg.grad_norm, cfg.device = -1, 1000, 5.0, 'cuda'
+        cfg.gpus, cfg.chunk_sizes = [0], [2]
+        opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        sched = torch.optim.lr_scheduler.StepLR(opt, 60, gamma=0.5)
+        tr = Trainer(m, opt, sched, cfg)
+        loader = []
+        for it in range(3):
+            x = synthetic.make_images(2, size, seed=3 + it)
+            cls_list, box_list = synthetic.make_gt_boxes(2, size, seed=20 + it, min_boxes=2, max_boxes=3)
+            if mode == "dense":
+                gt = torch.from_numpy(np.stack([oracle.encode_gt(c, b, cfg.anchors, 3, ties="lowest") for c, b in zip(cls_list, box_list)]))
+                loader.append({'image': x, 'gt': gt, 'image_meta': {}})
+            else:
+                loader.append({'image': x, 'gt_boxes': box_list, 'gt_class_ids': cls_list, 'image_meta': {}})
+        stats = tr.train_epoch(1, loader)
+        vstats = tr.val_epoch(1, loader[:1])
+        logs[mode] = (stats, vstats, [p.detach().clone() for p in m.parameters()])
+        assert set(stats) == {'loss', 'class_loss', 'score_loss', 'bbox_loss', 'epoch_time'}
+        assert m.training is False                       # val_epoch leaves the model in eval mode like the reference
+    for k in ('loss', 'class_loss', 'score_loss', 'bbox_loss'):
+        assert abs(logs['dense'][0][k] - logs['sparse'][0][k]) <= 1e-6 * abs(logs['dense'][0][k])
+        assert abs(logs['dense'][1][k] - logs['sparse'][1][k]) <= 1e-6 * abs(logs['dense'][1][k])
+    for a, b in zip(logs['dense'][2], logs['sparse'][2]):
+        assert torch.equal(a, b)
+    # the oracle's functional train step over the same three batches
+    params = {k: v.clone() for k, v in sd.items()}
+    mom = None
+    losses = []
+    for it in range(3):
+        x = synthetic.make_images(2, size, seed=3 + it)
+        cls_list, box_list = synthetic.make_gt_boxes(2, size, seed=20 + it, min_boxes=2, max_boxes=3)
+        gt = torch.from_numpy(np.stack([oracle.encode_gt(c, b, cfg.anchors, 3, ties="lowest") for c, b in zip(cls_list, box_list)]))
+        params, mom, _, _, loss_vec, _ = oracle.train_step_reference(params, mom, x, gt, cfg.anchors, size, arch='squeezedet')
+        losses.append(float(loss_vec.mean()))
+    assert abs(logs['dense'][0]['loss'] - np.mean(losses)) <= 2e-3 * abs(np.mean(losses))
