@@ -295,55 +295,72 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
   if (tile >= ntiles) return;
 
-  // tile-independent part of every lane's DMA slots
-  int a_v[A_IT], a_r[A_IT], a_c[A_IT];                  // plane, tile row / col (3x3) or flat pixel (1x1, in a_c)
+  const int wm_s = __builtin_amdgcn_readfirstlane(wm);  // wave index as a scalar: the LDS-DMA destinations stay in SGPRs
+
+  // Tile-independent part of every lane's DMA slots.  a_off is the lane's 32-bit element offset from the tile's
+  // origin pointer (3x3: halo pixel (y0-1, x0-1); 1x1: first pixel), so an interior tile issues its DMA with no
+  // per-lane address arithmetic at all: uniform 64-bit base + a_off.  Only edge tiles / a partial last K chunk
+  // look at (a_v, a_r, a_c) to redirect out-of-range slots to the zero page.  Padding slots (never read by the
+  // MFMA loop) carry offset 0 and fetch the origin pixel.
+  int a_off[A_IT], a_key[A_IT];                         // a_key = plane << 16 | tile row << 8 | tile col (1x1: flat pixel), -1 = padding
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int slot = it * NTHR + tid;
     const int v = slot / NPIXP, pix = slot - v * NPIXP;
-    a_v[it] = (v < KV && pix < NPIX) ? v : -1;
-    if (TAPS == 9) { a_r[it] = pix / 18; a_c[it] = pix - a_r[it] * 18; } else { a_r[it] = 0; a_c[it] = pix; }
+    const bool real = v < KV && pix < NPIX;
+    const int r = (TAPS == 9) ? pix / 18 : 0, c = (TAPS == 9) ? pix - r * 18 : pix;
+    a_key[it] = real ? (v << 16 | ((TAPS == 9) ? (r << 8 | c) : c)) : -1;
+    a_off[it] = real ? (r * a.W + c) * a.x_pitch + 4 * v : 0;
   }
-  long long w_off[W_IT];                                // float offset inside one chunk's packed weights, -1 = zero page
+  int w_off[W_IT];                                      // float offset inside one chunk's packed weights (padding slots: 0)
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) {
     const int slot = it * NTHR + tid;
     const int v = slot / WROWS, tn = slot - v * WROWS;
     const int tap = tn / BN, n = tn - tap * BN;
-    w_off[it] = (v < KV) ? (((long long)v * TAPS + tap) * a.Npad + n0 + n) * 4 : -1;
+    w_off[it] = (v < KV) ? ((v * TAPS + tap) * a.Npad + n0 + n) * 4 : 0;
   }
   const long long w_chunk = (long long)KV * TAPS * a.Npad * 4;
 
-  struct TilePos { int b, y0, x0; long long p0; };
+  // All fields are wave-uniform (SGPRs).  p0 = flat index of the tile's first output pixel.
+  struct TilePos { int y0, x0, inner; long long p0; const float* xorg; };
+  auto tp_sel = [](bool c, const TilePos& u, const TilePos& v) {      // field-wise: keeps everything in SGPRs
+    TilePos r; r.y0 = c ? u.y0 : v.y0; r.x0 = c ? u.x0 : v.x0; r.inner = c ? u.inner : v.inner;
+    r.p0 = c ? u.p0 : v.p0; r.xorg = c ? u.xorg : v.xorg;
+    return r;
+  };
   auto tile_pos = [&](int t) {
-    TilePos tp; tp.b = 0; tp.y0 = 0; tp.x0 = 0; tp.p0 = 0;
+    TilePos tp;
     if (TAPS == 9) {
       const int tx = t % a.tiles_x; t /= a.tiles_x;
-      const int ty = t % a.tiles_y; tp.b = t / a.tiles_y;
+      const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
       tp.y0 = ty * TH; tp.x0 = tx * 16;
+      tp.p0 = ((long long)b * a.H + tp.y0) * a.W + tp.x0;
+      tp.xorg = a.x + (tp.p0 - a.W - 1) * a.x_pitch + a.x_coff;          // dereferenced only where the pixel exists
+      tp.inner = tp.y0 >= 1 && tp.y0 + TH + 1 <= a.H && tp.x0 >= 1 && tp.x0 + 17 <= a.W;
     } else {
+      tp.y0 = 0; tp.x0 = 0;
       tp.p0 = (long long)t * (TH * 16);
+      tp.xorg = a.x + tp.p0 * a.x_pitch + a.x_coff;
+      tp.inner = tp.p0 + TH * 16 <= a.total_px;
     }
     return tp;
   };
-  auto dma_act_one = [&](int it, const TilePos& tp, int cc, int buf) {
-    const int c = cc * KC + 4 * a_v[it];
-    bool ok = (a_v[it] >= 0) && (c < a.C);
-    long long gp;
-    if (TAPS == 9) {
-      const int iy = tp.y0 + a_r[it] - 1, ix = tp.x0 + a_c[it] - 1;
-      ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      gp = ((long long)tp.b * a.H + iy) * a.W + ix;
-    } else {
-      gp = tp.p0 + a_c[it];
-      ok = ok && gp < a.total_px;
+  auto dma_act_one = [&](int it, const TilePos tp, int cc, int buf) {
+    const float* base = tp.xorg + cc * KC;                                // uniform
+    const float* src = base + a_off[it];
+    if (!(tp.inner && (cc + 1) * KC <= a.C)) {                            // uniform: edge tile or partial chunk
+      const int key = a_key[it];
+      bool ok = key >= 0 && cc * KC + 4 * (key >> 16) < a.C;
+      if (TAPS == 9) ok = ok && (unsigned)(tp.y0 + ((key >> 8) & 255) - 1) < (unsigned)a.H && (unsigned)(tp.x0 + (key & 255) - 1) < (unsigned)a.W;
+      else ok = ok && tp.p0 + (key & 0xffff) < a.total_px;
+      src = ok ? src : sqd_zero_page;
     }
-    const float* src = ok ? a.x + gp * a.x_pitch + a.x_coff + c : sqd_zero_page;
-    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(actB + (buf * ASLOTS + it * NTHR + wm * 64) * 4), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(actB + (buf * ASLOTS + it * NTHR + wm_s * 64) * 4), 16, 0, 0);
   };
   auto dma_w_one = [&](int it, int cc, int buf) {
-    const float* src = (w_off[it] >= 0) ? a.w + cc * w_chunk + w_off[it] : sqd_zero_page;
-    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(wB + (buf * WSLOTS + it * NTHR + wm * 64) * 4), 16, 0, 0);
+    const float* src = a.w + cc * w_chunk + w_off[it];
+    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(wB + (buf * WSLOTS + it * NTHR + wm_s * 64) * 4), 16, 0, 0);
   };
 
   f32x4 acc[MT][NT], outv[MT][NT];
@@ -352,28 +369,53 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // epilogue constants: the slice's bias in LDS (zeros without bias / beyond N) and the lane's element offset inside
+  // a tile's output window
+  float* const biasL = wB + (w_stationary ? 1 : 2) * WSLOTS * 4;
+  if (tid < BN) biasL[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;   // published by the first stage barrier
+  int o_off[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+    o_off[i] = ((TAPS == 9) ? (wm * MT + i) * a.W + lr : (wm * MT + i) * 16 + lr) * a.y_pitch + 4 * g;
+  const bool plain_epi = !a.accumulate && !a.ymul && !a.ymask;          // forward layers: bias (+ ReLU) only
+
+  TilePos cur = tile_pos(tile);
   // prologue: stage 0 into buffer 0
-  {
-    const TilePos tp = tile_pos(tile);
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) dma_act_one(it, tp, 0, 0);
+  for (int it = 0; it < A_IT; ++it) dma_act_one(it, cur, 0, 0);
 #pragma unroll
-    for (int it = 0; it < W_IT; ++it) dma_w_one(it, 0, 0);
-  }
+  for (int it = 0; it < W_IT; ++it) dma_w_one(it, 0, 0);
   int sbuf = 0, wbuf = 0;              // buffers holding the stage about to be computed
-  int pending = -1;                    // tile whose finished accumulators wait in outv for their store
+  bool pending = false;                // finished accumulators wait in outv for their store
+  TilePos ptp = cur;                   // ... of this tile
 
   // store a finished tile (bias / accumulate / masks / ReLU fused); called right AFTER a stage barrier so the
   // stores drain under the next stage's MFMAs instead of in front of the barrier's vmcnt(0)
-  auto flush = [&](int t) {
-    const TilePos tp = tile_pos(t);
+  auto flush = [&](const TilePos tp) {
+    float* ybase = a.y + tp.p0 * a.y_pitch + a.y_coff + n0;              // uniform
+    const bool whole = ((TAPS == 9) ? (tp.y0 + TH <= a.H && tp.x0 + 16 <= a.W) : (tp.p0 + TH * 16 <= a.total_px)) && n0 + BN <= a.N;
+    if (plain_epi && whole) {                                             // uniform fast path: no bounds checks, no 64-bit math
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          f32x4 v = outv[i][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#ifndef DIAG_NOSTORE
+          *(f32x4*)(ybase + o_off[i] + j * 16) = v;
+#else
+          if (v.x == 123.456f) *(f32x4*)(ybase + o_off[i] + j * 16) = v;
+#endif
+        }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      long long gp; bool valid;
+      bool valid;
+      long long gp;
       if (TAPS == 9) {
-        const int iy = tp.y0 + wm * MT + i, ix = tp.x0 + lr;
-        valid = iy < a.H && ix < a.W;
-        gp = ((long long)tp.b * a.H + iy) * a.W + ix;
+        valid = tp.y0 + wm * MT + i < a.H && tp.x0 + lr < a.W;
+        gp = tp.p0 + (long long)(wm * MT + i) * a.W + lr;
       } else {
         gp = tp.p0 + (wm * MT + i) * 16 + lr;
         valid = gp < a.total_px;
@@ -382,8 +424,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
       for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 16 + 4 * g;
         if (!valid || n >= a.N) continue;
-        f32x4 v = outv[i][j];
-        if (a.bias) v += *(const f32x4*)(a.bias + n);
+        f32x4 v = outv[i][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
         float* dst = a.y + gp * a.y_pitch + a.y_coff + n;
         if (a.accumulate) v += *(const f32x4*)dst;
         if (a.ymul) v *= *(const f32x4*)(a.ymul + gp * a.ymul_pitch + a.ymul_coff + n);
@@ -392,28 +433,30 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-#ifndef DIAG_NOSTORE
         *(f32x4*)dst = v;
-#else
-        if (v.x == 123.456f) *(f32x4*)dst = v;
-#endif
       }
     }
   };
 
   for (;;) {
+    const bool more = tile + tstride < ntiles;
+    const TilePos nxt = tile_pos(more ? tile + tstride : tile);
     for (int cc = 0; cc < nchunks; ++cc) {
       __syncthreads();                 // vmcnt(0): this stage's DMA has landed; all waves left the previous stage
-      if (pending >= 0) { flush(pending); pending = -1; }
-      int ncc = cc + 1, ntile = tile;
-      if (ncc == nchunks) { ncc = 0; ntile = tile + tstride; }
+#ifdef DIAG_NOFLUSH
+      if (pending) { if (outv[0][0].x == 123.456f) flush(ptp); pending = false; }
+#else
+      if (pending) { flush(ptp); pending = false; }
+#endif
+      const bool last = cc == nchunks - 1;
+      const int ncc = last ? 0 : cc + 1;
 #ifdef DIAG_NODMA
       const bool has_next = false;
 #else
-      const bool has_next = ntile < ntiles;
+      const bool has_next = !last || more;
 #endif
       const bool next_w = has_next && !w_stationary;
-      const TilePos ntp = tile_pos(has_next ? ntile : tile);
+      const TilePos ntp = tp_sel(last, nxt, cur);
       const float* actT = actB + sbuf * ASLOTS * 4;
       const float* wT = wB + wbuf * WSLOTS * 4;
 
@@ -435,19 +478,11 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             const int row = (TAPS == 9) ? ((wm * MT + i) + dy) * 18 + lr + dx : (wm * MT + i) * 16 + lr;
-#ifdef DIAG_NOLDS
-            { const float q = (float)(lane + i + tap) * 1e-3f; bf[i] = (f32x4){q, q + 1.f, q + 2.f, q + 3.f}; asm volatile("" : "+v"(bf[i])); }
-#else
             bf[i] = *(const f32x4*)(actT + ((4 * s + g) * NPIXP + row) * 4);
-#endif
           }
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-#ifdef DIAG_NOLDS
-            { const float q = (float)(lane + j + s) * 1e-3f; af[j] = (f32x4){q, q - 1.f, q - 2.f, q - 3.f}; asm volatile("" : "+v"(af[j])); }
-#else
             af[j] = *(const f32x4*)(wT + ((4 * s + g) * WROWS + tap * BN + j * 16 + lr) * 4);
-#endif
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -457,20 +492,21 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
         }
       }
 
-      if (cc == nchunks - 1) {         // tile finished: park the result, store it after the next barrier
+      if (last) {                      // tile finished: park the result, store it after the next barrier
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) { outv[i][j] = acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        pending = tile;
+        pending = true; ptp = cur;
       }
       sbuf ^= 1;
       if (!w_stationary) wbuf ^= 1;
     }
+    if (!more) break;
     tile += tstride;
-    if (tile >= ntiles) break;
+    cur = nxt;
   }
-  if (pending >= 0) flush(pending);
+  if (pending) flush(ptp);
 }
 
 static int sqd_num_cus() {
@@ -532,14 +568,14 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   constexpr int NPIXP = (NPIX + 15) & ~15;
   constexpr int KV = KC / 4;
   constexpr int ASLOTS = (KV * NPIXP + NTHR - 1) / NTHR * NTHR, WSLOTS = (KV * TAPS * BN + NTHR - 1) / NTHR * NTHR;
-  constexpr size_t lds_max = (size_t)(2 * ASLOTS + 2 * WSLOTS) * 16;
+  constexpr size_t lds_max = (size_t)(2 * ASLOTS + 2 * WSLOTS) * 16 + BN * sizeof(float);
   static_assert(lds_max <= 160 * 1024, "LDS budget");
   if (a.xmask) return SQD_ERR_UNSUPPORTED;               // input-side mask needs register staging (v3 path)
   const int stationary = (a.C <= KC) ? 1 : 0;            // one K chunk: a single weight buffer suffices
-  const size_t lds = (size_t)(2 * ASLOTS + (stationary ? 1 : 2) * WSLOTS) * 16;
+  const size_t lds = (size_t)(2 * ASLOTS + (stationary ? 1 : 2) * WSLOTS) * 16 + BN * sizeof(float);
   // waves per SIMD the register allocator must leave room for: workgroups per CU (by LDS) x waves per SIMD of one
-  constexpr int REGW = (MT * NT <= 4) ? 4 : ((MT * NT <= 6) ? 3 : 2);
-  constexpr int LDSW = (int)((160 * 1024) / ((size_t)(2 * ASLOTS + WSLOTS) * 16)) * (WM / 4);
+  constexpr int REGW = (MT * NT <= 4) ? 4 : ((MT * NT <= 6) ? 3 : ((MT * NT <= 12) ? 2 : 1));
+  constexpr int LDSW = (int)((160 * 1024) / ((size_t)(2 * ASLOTS + WSLOTS) * 16 + BN * sizeof(float))) * (WM / 4);
   constexpr int MINW0 = LDSW < REGW ? (LDSW < 1 ? 1 : LDSW) : REGW;
   constexpr int MINW = (MINW0 < WM / 4) ? WM / 4 : MINW0;
   auto kern = conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW>;

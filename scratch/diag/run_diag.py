@@ -3,9 +3,9 @@ sys.path.insert(0, '/root/repo')
 here = os.path.dirname(os.path.abspath(__file__))
 import squeezedet_pytorch_amd as sqd
 from squeezedet_pytorch_amd import ops, _native as nat
-shapes = [(9, 16, 64, 96, 312, (38, 42, 44)), (9, 96, 384, 24, 78, (43, 42, 44)), (9, 64, 256, 24, 78, (42, 38))]
+shapes = [(9, 16, 64, 96, 312, (42,)), (9, 32, 128, 48, 156, (42, 71)), (9, 96, 384, 24, 78, (39,)), (9, 64, 256, 24, 78, (42,)), (9, 768, 72, 24, 78, (41,))]
 B = 20
-for v in ['base', 'nostore_nodma', 'nostore_nodma_nolds']:
+for v in ['base', 'nostore', 'noflush', 'noflush_nodma']:
     lib = ctypes.CDLL(os.path.join(here, f'libdiag_{v}.so'))
     lib.sqd_conv_fwd.argtypes = nat._SIGNATURES['sqd_conv_fwd']; lib.sqd_conv_fwd.restype = ctypes.c_int
     for taps, C, N, h, w, cfgs in shapes:

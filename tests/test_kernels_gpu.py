@@ -137,3 +137,19 @@ def test_fused_stem_pool(k, N, H, W):
     p2 = ops.maxpool(y2, argmax=am2)
     assert torch.equal(p2, y)
     assert (am == am2).float().mean().item() > 0.999
+    # inference instantiation (no argmax, v_max3 pooling): same bits
+    assert torch.equal(ops.stem_pool(x.cuda(), w.cuda(), b.cuda()), y)
+
+
+def test_fused_stem_pool_kitti_size_both_paths_agree():
+    ops = _ops()
+    x = _rand(3, 3, 384, 1248, seed=31).cuda()
+    w = _rand(64, 3, 3, 3, seed=32, scale=(2.0 / 27) ** 0.5).cuda()
+    b = _rand(64, seed=33, scale=0.1).cuda()
+    y_inf = ops.stem_pool(x, w, b)
+    am = torch.empty(*y_inf.shape, dtype=torch.uint8, device='cuda')
+    y_tr = ops.stem_pool(x, w, b, argmax=am)
+    assert torch.equal(y_inf, y_tr)
+    ref = F.max_pool2d(F.relu(F.conv2d(x[:1].cpu(), w.cpu(), b.cpu(), stride=2, padding=1)), 3, 2, ceil_mode=True)
+    assert (y_inf[:1].cpu() - _nhwc(ref)).abs().max().item() <= _tol(ref)
+    assert int(am.max()) <= 8
