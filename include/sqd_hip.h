@@ -134,6 +134,15 @@ int sqd_preprocess_u8_fwd(const unsigned char* src, const long long* offsets, co
 int sqd_encode_gt_fwd(const float* boxes, const int* class_ids, const int* box_offsets, const double* anchors,
                       float* gt, int* anchor_idx, float* deltas, int B, int A, int num_classes, void* stream);
 
+/* KITTI 2D detection AP, host code: what KITTI.evaluate (src/datasets/kitti.py:99-124)
+ * obtains from the evaluate_object binary (src/utils/kitti-eval/cpp/evaluate_object.cpp:281-571).  n_images frames;
+ * gt_off / det_off [n+1]; gt_kind: 0 car, 1 pedestrian, 2 cyclist, 3 van, 4 person_sitting, 5 DontCare, 6 other;
+ * boxes x1,y1,x2,y2 (float64); det_cls 0..2 (else not evaluated).  ap [3][3] = class x (easy, moderate, hard);
+ * precision [3][3][41] or NULL; evaluated [3].  All pointers are HOST pointers. */
+int sqd_kitti_ap(int n_images, const int* gt_off, const int* gt_kind, const double* gt_box, const double* gt_trunc,
+                 const int* gt_occ, const int* det_off, const int* det_cls, const double* det_box,
+                 const double* det_score, double* ap, double* precision, int* evaluated);
+
 /* Multi-task loss (Loss.forward, src/model/squeezedet.py:133-174; compute_overlaps, modules.py:48-63).
  * pred [B][A][C+5], gt [B][A][C+9] = (mask, x1,y1,x2,y2, dx,dy,dw,dh, onehot[C]), anchors [A][4].
  * workspace: B*16*5 floats.  losses: [4][B] = (class, score = pos+neg, bbox, total); nobj: [B]. */

@@ -1,0 +1,126 @@
+"""Checkpoints.
+
+``load_model`` / ``load_official_model`` / ``save_model`` keep the reference's file format and behaviour
+(src/utils/model.py:5-71): a checkpoint is ``{'epoch': int, 'state_dict': {...}}`` with canonical OIHW fp32 tensors
+under the keys ``base.features.N.*`` / ``base.convdet.*``; ``module.`` prefixes of DataParallel checkpoints are
+stripped, shape-mismatched / missing / unknown parameters are reported and skipped (never fatal), torchvision
+SqueezeNet weights map by ``'base.' + key``.  Files written here load in the reference and vice versa.
+
+``save_checkpoint`` / ``load_checkpoint`` add what the reference lacks for restarting a (multi-GPU) run exactly:
+optimizer state (momentum buffers), LR-scheduler state and the RNG streams, under extra top-level keys that the
+reference's ``load_model`` simply ignores.  One process per GPU: rank 0 writes, every rank reads.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+
+def _strip_module_prefix(sd):
+    out = {}
+    for k, v in sd.items():
+        if k.startswith('module') and not k.startswith('module_list'):
+            out[k[7:]] = v
+        else:
+            out[k] = v
+    return out
+
+
+def _reconcile(model, state_dict, verbose=True):
+    """The reference's tolerant matching (model.py:17-37).  Returns (state_dict to load, fully_loaded flag)."""
+    model_sd = model.state_dict()
+    ok = True
+    for layer in list(state_dict):
+        if layer in model_sd:
+            if state_dict[layer].shape != model_sd[layer].shape:
+                ok = False
+                if verbose:
+                    print('Skip loading param {}, required shape{}, loaded shape{}.'.format(
+                        layer, model_sd[layer].shape, state_dict[layer].shape))
+                state_dict[layer] = model_sd[layer]
+        else:
+            ok = False
+            if verbose:
+                print('Drop param {} in pre-trained model.'.format(layer))
+    for layer in model_sd:
+        if layer not in state_dict:
+            ok = False
+            if verbose:
+                print('Param {} not found in pre-trained model.'.format(layer))
+            state_dict[layer] = model_sd[layer]
+    return state_dict, ok
+
+
+def load_model(model, model_path, verbose=True):
+    checkpoint = torch.load(model_path, map_location='cpu', weights_only=False)
+    if verbose:
+        print('loaded model {}, epoch {}'.format(model_path, checkpoint['epoch']))
+    state_dict, ok = _reconcile(model, _strip_module_prefix(checkpoint['state_dict']), verbose)
+    model.load_state_dict(state_dict, strict=False)
+    if verbose:
+        print('Model successfully loaded.' if ok else 'The model does not fully load the pre-trained weight.')
+    return model
+
+
+def load_official_model(model, model_path, verbose=True):
+    """torchvision SqueezeNet state_dict (``features.N...``) -> ``base.features.N...`` (model.py:42-62); writes the
+    converted checkpoint next to the original like the reference does."""
+    state_dict = torch.load(model_path, map_location='cpu', weights_only=False)
+    state_dict = {'base.' + k: v for k, v in state_dict.items()}
+    converted = model_path.replace('.pth', '_converted.pth')
+    torch.save({'epoch': 0, 'state_dict': state_dict}, converted)
+    return load_model(model, converted, verbose)
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, 'module') and isinstance(getattr(model, 'module'), torch.nn.Module) else model
+
+
+def save_model(model, path, epoch):
+    torch.save({'epoch': epoch, 'state_dict': _unwrap(model).state_dict()}, path)
+
+
+def _is_rank0():
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, rng=True, extra=None):
+    """Reference-compatible file plus optimizer / scheduler / RNG state.  Tensors are moved to the CPU; written
+    atomically (tmp + rename) by rank 0 only."""
+    if not _is_rank0():
+        return
+    data = {'epoch': epoch,
+            'state_dict': {k: v.detach().cpu() for k, v in _unwrap(model).state_dict().items()}}
+    if optimizer is not None:
+        data['optimizer'] = optimizer.state_dict()
+    if lr_scheduler is not None:
+        data['lr_scheduler'] = lr_scheduler.state_dict()
+    if rng:
+        data['rng'] = {'torch': torch.get_rng_state(),
+                       'cuda': torch.cuda.get_rng_state_all() if torch.cuda.is_available() else []}
+    if extra:
+        data['extra'] = extra
+    tmp = path + '.tmp'
+    torch.save(data, tmp)
+    os.replace(tmp, path)
+
+
+def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, restore_rng=True, verbose=False):
+    """Inverse of ``save_checkpoint``; also accepts plain reference checkpoints (then only the weights and the
+    epoch come back).  Returns the epoch stored in the file."""
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
+    state_dict, _ = _reconcile(model, _strip_module_prefix(ckpt['state_dict']), verbose)
+    _unwrap(model).load_state_dict(state_dict, strict=False)
+    if optimizer is not None and 'optimizer' in ckpt:
+        optimizer.load_state_dict(ckpt['optimizer'])            # torch casts the state to each parameter's device
+    if lr_scheduler is not None and 'lr_scheduler' in ckpt:
+        lr_scheduler.load_state_dict(ckpt['lr_scheduler'])
+    if restore_rng and 'rng' in ckpt:
+        torch.set_rng_state(ckpt['rng']['torch'])
+        if torch.cuda.is_available() and ckpt['rng']['cuda']:
+            states = ckpt['rng']['cuda']
+            if len(states) == torch.cuda.device_count():
+                torch.cuda.set_rng_state_all(states)
+    return ckpt['epoch']

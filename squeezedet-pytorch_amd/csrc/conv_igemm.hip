@@ -38,6 +38,7 @@ struct ConvArgs {
   int relu, accumulate;
   int tiles_x, tiles_y, ntiles;
   int nslices, gx;                           // persistent grid: gx tile streams x nslices channel slices (1-D launch)
+  int wg_cap;                                // host only: cap on resident workgroups per CU (0 = occupancy)
   int xmask_pitch, xmask_coff;
   const float* ymask; const float* ymul;      // epilogue: zero where ymask <= 0 (ReLU backward), multiply by ymul (dropout)
   int ymask_pitch, ymask_coff, ymul_pitch, ymul_coff;
@@ -542,7 +543,7 @@ static int launch_conv(ConvArgs a, hipStream_t stream) {
   const int nslices = sqd_cdiv(a.N, BN);
   if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;     // packed weights too short for this slice width
   // persistent grid: at most one resident wave of workgroups, pixel tiles dealt evenly
-  const int slots = sqd_num_cus() * wgs_per_cu;
+  const int slots = sqd_num_cus() * ((a.wg_cap > 0 && a.wg_cap < wgs_per_cu) ? a.wg_cap : wgs_per_cu);
   int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
   const int per_wg = sqd_cdiv(a.ntiles, gx_max);
   const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;        // tile streams, a multiple of 8 (one per XCD lane)
@@ -587,7 +588,7 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   }
   const int nslices = sqd_cdiv(a.N, BN);
   if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;
-  const int slots = sqd_num_cus() * wgs_per_cu[stationary];
+  const int slots = sqd_num_cus() * ((a.wg_cap > 0 && a.wg_cap < wgs_per_cu[stationary]) ? a.wg_cap : wgs_per_cu[stationary]);
   int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
   const int per_wg = sqd_cdiv(a.ntiles, gx_max);
   const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;        // tile streams, a multiple of 8 (one per XCD lane)
@@ -708,7 +709,11 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
                             int ymul_pitch, int ymul_coff, int cfg_id, void* stream) {
   SQD_CHECK_ARG(x && w_packed && y);
   SQD_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && N > 0);
-  SQD_CHECK_ARG(cfg_id >= 0 && cfg_id < kNumConvCfgs);
+  // cfg_id = tile configuration + 1000 * k: k > 0 caps the persistent grid at k workgroups per CU (fewer, longer tile
+  // streams balance better on small layers; the tuner measures it), k = 0 fills the occupancy
+  const int wg_cap = cfg_id >= 0 ? cfg_id / 1000 : 0;
+  if (cfg_id >= 0) cfg_id %= 1000;
+  SQD_CHECK_ARG(cfg_id >= 0 && cfg_id < kNumConvCfgs && wg_cap <= 8);
   SQD_CHECK_ARG((C & 3) == 0 && (N & 3) == 0);
   SQD_CHECK_ARG((x_pitch & 3) == 0 && (x_coff & 3) == 0 && (y_pitch & 3) == 0 && (y_coff & 3) == 0);
   SQD_CHECK_ARG(x_coff + C <= x_pitch && y_coff + N <= y_pitch);
@@ -722,7 +727,7 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.xmask = xmask;
   a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff;
-  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8;
+  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8; a.wg_cap = wg_cap;
   a.xmask_pitch = xmask_pitch; a.xmask_coff = xmask_coff;
   a.total_px = (long long)B * H * W;
   hipStream_t s = (hipStream_t)stream;

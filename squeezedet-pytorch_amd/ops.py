@@ -91,11 +91,12 @@ _CFG_DMA = {}
 
 def cfg_is_dma(cfg_id):
     cfg_table()
-    return _CFG_DMA[cfg_id] != 0
+    return _CFG_DMA[cfg_id % 1000] != 0
 
 
 def cfg_kernel_name(cfg_id):
     """Canonical kernel name of a configuration: conv_igemm<TAPS,KC,MT,NT> or conv_dma<TAPS,KC,MT,NT,WAVES>."""
+    cfg_id %= 1000                            # + 1000 * k = workgroups-per-CU cap (see sqd_conv_fwd)
     taps, kc, px, bn = cfg_table()[cfg_id]
     d = _CFG_DMA[cfg_id]
     waves = 8 if d == 2 else 4
@@ -126,7 +127,7 @@ def choose_cfg(taps, C, N, npix):
     (least channel padding, 128-pixel tiles when that still yields >= 4 workgroups per CU)."""
     tab = cfg_table()
     hit = _tuning().get(f'{taps}:{C}:{N}:{npix}')
-    if hit is not None and hit in tab and tab[hit][0] == taps:
+    if hit is not None and hit % 1000 in tab and tab[hit % 1000][0] == taps:
         return hit
     want_kc = 16 if (taps == 9 or C <= 128 and C % 32 != 0 or C < 64) else 32
     best = None
@@ -157,7 +158,7 @@ class ConvPlan:
     __slots__ = ('cfg_id', 'taps', 'kc', 'bn', 'C', 'N', 'Npad', 'w', 'bias')
 
     def __init__(self, w_oihw, bias, cfg_id, dgrad=False):
-        taps_cfg, kc, _px, bn = cfg_table()[cfg_id]
+        taps_cfg, kc, _px, bn = cfg_table()[cfg_id % 1000]
         No, Ci, kh, kw = w_oihw.shape
         taps = kh * kw
         if taps != taps_cfg or kh != kw or taps not in (1, 9):

@@ -1,0 +1,141 @@
+"""Checkpoint compatibility and exact resume (reference: src/utils/model.py:5-71)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import squeezedet_pytorch_amd as sqd
+from squeezedet_pytorch_amd import checkpoint as ck
+from squeezedet_pytorch_amd import synthetic
+
+
+class _Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.base = nn.Sequential(nn.Conv2d(3, 4, 3), nn.ReLU(), nn.Conv2d(4, 2, 1))
+
+    def forward(self, x):
+        return self.base(x)
+
+
+def test_reference_format_roundtrip_and_tolerant_loading(tmp_path, capsys):
+    torch.manual_seed(0)
+    m = _Tiny()
+    p = str(tmp_path / "m.pth")
+    ck.save_model(m, p, 7)
+    raw = torch.load(p, weights_only=False)
+    assert set(raw) == {"epoch", "state_dict"} and raw["epoch"] == 7                 # the reference's file format
+    assert list(raw["state_dict"]) == list(m.state_dict())
+    m2 = ck.load_model(_Tiny(), p)
+    for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
+    assert "Model successfully loaded." in capsys.readouterr().out
+    # DataParallel-style 'module.' prefix, one wrong shape, one unknown and one missing parameter
+    sd = {"module." + k: v.clone() for k, v in m.state_dict().items()}
+    sd["module.base.0.weight"] = torch.zeros(5, 3, 3, 3)
+    sd["module.extra.weight"] = torch.zeros(1)
+    del sd["module.base.2.bias"]
+    torch.save({"epoch": 1, "state_dict": sd}, p)
+    fresh = _Tiny()
+    before = {k: v.clone() for k, v in fresh.state_dict().items()}
+    ck.load_model(fresh, p)
+    out = capsys.readouterr().out
+    assert "Skip loading param base.0.weight" in out and "Drop param extra.weight" in out
+    assert "Param base.2.bias not found" in out and "does not fully load" in out
+    assert torch.equal(fresh.state_dict()["base.0.weight"], before["base.0.weight"])   # kept its own value
+    assert torch.equal(fresh.state_dict()["base.0.bias"], m.state_dict()["base.0.bias"])
+
+
+def test_official_squeezenet_key_mapping(tmp_path):
+    m = _Tiny()
+    tv = {k[len("base."):]: v.clone() + 1 for k, v in m.state_dict().items()}        # torchvision-style keys
+    p = str(tmp_path / "squeezenet1_1-f364aa15.pth")
+    torch.save(tv, p)
+    ck.load_official_model(m, p, verbose=False)
+    assert os.path.exists(p.replace(".pth", "_converted.pth"))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, tv[k[len("base."):]])
+
+
+def test_squeezedet_state_dict_contract_on_cpu(tmp_path):
+    """64 tensors, canonical OIHW fp32, the reference's key names -- file written here has them all."""
+    from squeezedet_pytorch_amd.model import SqueezeDetWithLoss
+    cfg = sqd.make_cfg(arch="squeezedet", device="cpu")
+    m = SqueezeDetWithLoss(cfg)
+    m.load_state_dict(synthetic.make_state_dict("squeezedet", seed=3), strict=True)
+    p = str(tmp_path / "sqd.pth")
+    ck.save_model(m, p, 280)
+    sd = torch.load(p, weights_only=False)["state_dict"]
+    assert len(sd) == 64 and all(v.dtype == torch.float32 for v in sd.values())
+    assert tuple(sd["base.features.0.weight"].shape) == (64, 3, 3, 3)
+    assert tuple(sd["base.convdet.weight"].shape) == (72, 768, 3, 3)
+    assert tuple(sd["base.features.3.expand3x3.weight"].shape) == (64, 16, 3, 3)
+    m2 = ck.load_model(SqueezeDetWithLoss(cfg), p, verbose=False)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_exact_resume_of_optimizer_scheduler_and_rng_cpu(tmp_path):
+    def make():
+        torch.manual_seed(1)
+        m = _Tiny()
+        opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        return m, opt, torch.optim.lr_scheduler.StepLR(opt, 2, gamma=0.5)
+
+    def step(m, opt, sched):
+        x = torch.randn(2, 3, 8, 8)                     # consumes the global RNG stream
+        opt.zero_grad(); m(x).square().mean().backward(); opt.step(); sched.step()
+
+    m, opt, sched = make()
+    for _ in range(3):
+        step(m, opt, sched)
+    p = str(tmp_path / "resume.pth")
+    ck.save_checkpoint(p, m, opt, sched, epoch=3)
+    for _ in range(3):
+        step(m, opt, sched)
+    want = [v.clone() for v in m.state_dict().values()]
+    m2, opt2, sched2 = make()
+    assert ck.load_checkpoint(p, m2, opt2, sched2) == 3
+    assert sched2.get_last_lr() == pytest.approx([0.005])
+    for _ in range(3):
+        step(m2, opt2, sched2)
+    assert all(torch.equal(a, b) for a, b in zip(want, m2.state_dict().values()))
+    # the extended file is still a valid reference checkpoint
+    ck.load_model(_Tiny(), p, verbose=False)
+
+
+@pytest.mark.gpu
+def test_exact_resume_squeezedet_training_gpu(tmp_path):
+    from squeezedet_pytorch_amd.model import SqueezeDetWithLoss
+    size = (64, 96)
+
+    def make():
+        cfg = sqd.make_cfg(arch="squeezedet", input_size=size, dropout_prob=0.5)
+        m = SqueezeDetWithLoss(cfg)
+        m.load_state_dict(synthetic.make_state_dict("squeezedet", seed=1234), strict=True)
+        m = m.cuda().train()
+        opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        return cfg, m, opt, torch.optim.lr_scheduler.StepLR(opt, 2, gamma=0.5)
+
+    def step(cfg, m, opt, sched, it):
+        x = synthetic.make_images(2, size, seed=10 + it).cuda()
+        gt = synthetic.make_gt(2, cfg.anchors, size, seed=30 + it, min_boxes=2, max_boxes=3).cuda()
+        loss, _ = m({"image": x, "gt": gt})               # dropout draws from the CUDA RNG stream
+        opt.zero_grad(); loss.mean().backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0); opt.step(); sched.step()
+        return float(loss.mean())
+
+    torch.manual_seed(5); torch.cuda.manual_seed_all(5)
+    cfg, m, opt, sched = make()
+    for it in range(2):
+        step(cfg, m, opt, sched, it)
+    p = str(tmp_path / "sqd_resume.pth")
+    ck.save_checkpoint(p, m, opt, sched, epoch=2)
+    tail = [step(cfg, m, opt, sched, it) for it in range(2, 4)]
+    want = [v.clone() for v in m.state_dict().values()]
+    cfg2, m2, opt2, sched2 = make()
+    assert ck.load_checkpoint(p, m2, opt2, sched2) == 2
+    tail2 = [step(cfg2, m2, opt2, sched2, it) for it in range(2, 4)]
+    assert tail == tail2                                                         # bitwise: same losses ...
+    assert all(torch.equal(a, b) for a, b in zip(want, m2.state_dict().values()))   # ... and same weights
