@@ -264,6 +264,14 @@ __device__ __attribute__((aligned(16))) float sqd_zero_page[4] = {0.f, 0.f, 0.f,
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// ReLU as ONE v_max_f32 per element.  fmaxf(v, 0) compiles to two (a canonicalising max in front of the real one);
+// on gfx950 every VALU instruction delays the fp32 MFMA stream of the SIMD (DESIGN.md cost model), so it matters.
+__device__ __forceinline__ f32x4 sqd_relu4(f32x4 v, float lo) {      // lo (wave-uniform): 0 = ReLU, -inf = identity
+  asm volatile("v_max_f32 %0, %4, %0\n\tv_max_f32 %1, %4, %1\n\tv_max_f32 %2, %4, %2\n\tv_max_f32 %3, %4, %3"
+               : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : "s"(lo));
+  return v;
+}
+
 template <int TAPS, int KC, int MT, int NT, int WM, int MINW>
 __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   constexpr int NTHR = WM * 64;              // 4 or 8 waves; with 8, two waves per SIMD share one staged tile
@@ -292,6 +300,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   const int tstride = a.gx;
   const int nchunks = (a.C + KC - 1) / KC;
   const bool w_stationary = (nchunks == 1);
+  const int w_stat_i = (int)((unsigned)(nchunks - 2) >> 31);              // nchunks == 1 (nchunks >= 1)
   const int ntiles = a.ntiles;
   int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
   if (tile >= ntiles) return;
@@ -338,19 +347,22 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
       tp.y0 = ty * TH; tp.x0 = tx * 16;
       tp.p0 = ((long long)b * a.H + tp.y0) * a.W + tp.x0;
       tp.xorg = a.x + (tp.p0 - a.W - 1) * a.x_pitch + a.x_coff;          // dereferenced only where the pixel exists
-      tp.inner = tp.y0 >= 1 && tp.y0 + TH + 1 <= a.H && tp.x0 >= 1 && tp.x0 + 17 <= a.W;
+      // sign-bit arithmetic keeps the flag a plain SGPR integer (y0 >= 1, y0 + TH + 1 <= H, x0 >= 1, x0 + 17 <= W)
+      tp.inner = (int)(((unsigned)(-tp.y0) & (unsigned)(tp.y0 + TH - a.H) & (unsigned)(-tp.x0) & (unsigned)(tp.x0 + 16 - a.W)) >> 31);
     } else {
       tp.y0 = 0; tp.x0 = 0;
       tp.p0 = (long long)t * (TH * 16);
       tp.xorg = a.x + tp.p0 * a.x_pitch + a.x_coff;
-      tp.inner = tp.p0 + TH * 16 <= a.total_px;
+      tp.inner = (int)((unsigned long long)(tp.p0 + TH * 16 - a.total_px - 1) >> 63);      // p0 + TH*16 <= total_px
     }
     return tp;
   };
   auto dma_act_one = [&](int it, const TilePos tp, int cc, int buf) {
     const float* base = tp.xorg + cc * KC;                                // uniform
     const float* src = base + a_off[it];
-    if (!(tp.inner && (cc + 1) * KC <= a.C)) {                            // uniform: edge tile or partial chunk
+    const int fast = tp.inner & (int)((unsigned)((cc + 1) * KC - a.C - 1) >> 31);   // uniform: interior tile, full chunk
+    if (!fast) {
+      asm volatile("" ::: "memory");                                      // keep this a real (scalar) branch: no if-conversion
       const int key = a_key[it];
       bool ok = key >= 0 && cc * KC + 4 * (key >> 16) < a.C;
       if (TAPS == 9) ok = ok && (unsigned)(tp.y0 + ((key >> 8) & 255) - 1) < (unsigned)a.H && (unsigned)(tp.x0 + (key & 255) - 1) < (unsigned)a.W;
@@ -379,6 +391,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   for (int i = 0; i < MT; ++i)
     o_off[i] = ((TAPS == 9) ? (wm * MT + i) * a.W + lr : (wm * MT + i) * 16 + lr) * a.y_pitch + 4 * g;
   const bool plain_epi = !a.accumulate && !a.ymul && !a.ymask;          // forward layers: bias (+ ReLU) only
+  const float relu_lo = a.relu ? 0.f : -__builtin_inff();             // branch-free ReLU switch (one v_max per element)
 
   TilePos cur = tile_pos(tile);
   // prologue: stage 0 into buffer 0
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           f32x4 v = outv[i][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
-          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          v = sqd_relu4(v, relu_lo);
           *(f32x4*)(ybase + o_off[i] + j * 16) = v;
         }
       return;
@@ -436,16 +449,18 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   };
 
   for (;;) {
-    const bool more = tile + tstride < ntiles;
+    const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);     // tile + tstride < ntiles
+    const bool more = more_i != 0;
     const TilePos nxt = tile_pos(more ? tile + tstride : tile);
     for (int cc = 0; cc < nchunks; ++cc) {
       __syncthreads();                 // vmcnt(0): this stage's DMA has landed; all waves left the previous stage
       if (pending) { flush(ptp); pending = false; }
-      const bool last = cc == nchunks - 1;
+      const int last_i = 1 - (int)((unsigned)(cc + 1 - nchunks) >> 31);      // cc == nchunks - 1
+      const bool last = last_i != 0;
       const int ncc = last ? 0 : cc + 1;
-      // forced into SGPR integers: as i1 values the compiler round-trips them through VGPRs (v_cndmask + v_cmp per use)
-      const int has_next = __builtin_amdgcn_readfirstlane((!last || more) ? 1 : 0);
-      const int next_w = __builtin_amdgcn_readfirstlane((has_next && !w_stationary) ? 1 : 0);
+      // plain SALU integers (sign-bit arithmetic): as i1 values the compiler round-trips them through VGPRs
+      const int has_next = (last_i ^ 1) | more_i;
+      const int next_w = has_next & (w_stat_i ^ 1);
       const TilePos ntp = tp_sel(last, nxt, cur);
       // per-lane LDS bases of this stage (one VALU add each per stage); every read below is base + immediate
       const float* actL = actB + sbuf * ASLOTS * 4 + (g * NPIXP + ((TAPS == 9) ? wm * MT * 18 : wm * MT * 16) + lr) * 4;
