@@ -468,6 +468,255 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem weight gradient behind the FUSED forward (conv + ReLU + MaxPool(3,2,ceil)), second generation.
+// On gfx950 every VALU instruction delays the fp32 MFMA stream (DESIGN.md cost model), and the first version spent
+// 13.8 VALU per MFMA routing dPool through the argmax.  Here:
+//  * the routing is a scatter by pooled item with everything tile-invariant precomputed once per thread: for each
+//    of the four (row parity, column parity) phases a thread owns at most SL (window, channel quad) items whose global
+//    offset, LDS base and border class are fixed; same-parity windows never overlap, so the read-modify-write of the
+//    conv-gradient tile needs no atomics and its summation order is fixed (bitwise reproducible);
+//  * argmax code -> (LDS offset, 0/1 weight) comes from two 9x9 LDS tables indexed by (border class, code): windows
+//    hanging over the tile edge have their outside taps clamped to an inside address with weight 0, so there are no
+//    per-element bounds checks;
+//  * the NCHW image patch goes global -> LDS by 4-byte LDS-DMA into a double buffer (next tile under this tile's
+//    MFMAs), and the dPool / pooled / argmax words of the next tile are prefetched into registers;
+//  * MFMA operand addresses are per-lane bases + compile-time immediates (as before).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
+__device__ __attribute__((aligned(16))) float sqd_wgrad_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int KS, int PAD, int TN>
+__global__ __launch_bounds__(256) void stem_wgrad_pooled_kernel(StemWgradArgs a) {
+  constexpr int TH = 8;
+  constexpr int K = 3 * KS * KS, KT = (K + 15) / 16;
+  constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16);
+  constexpr int IH = 2 * (TH - 1) + KS, IW = 2 * 15 + KS;
+  constexpr int NIN = 3 * IH * IW, IN_IT = (NIN + 255) / 256, INSLOTS = IN_IT * 256;
+  constexpr int TILES = TN * KT, NACC = (TILES + 3) / 4, BACC = (TN + 3) / 4;
+  constexpr int SL = (15 * TN * 4 + 255) / 256;             // item slots per thread and phase
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const dyT = smem;                                  // [128][PN]   conv-output gradient of the tile
+  float* const inB = dyT + 128 * PN;                        // [2][INSLOTS] image patches, flat [ci][r][c]
+  int* const relT = (int*)(inB + 2 * INSLOTS);              // [9 classes][9 codes] byte offset of the (clamped) tap
+  float* const mskT = (float*)(relT + 81);                  // [9][9] 1 = tap inside the tile, 0 = outside
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int NQ = a.N >> 2;
+
+  if (tid < 81) {
+    const int cls = tid / 9, t = tid - cls * 9, rc = cls / 3, cc = cls - rc * 3;
+    const int dy = t / 3, dx = t - dy * 3;
+    // row class 0: window row -1 (only dy = 2 is inside), 1: interior, 2: window row 3 (dy = 0, 1 inside); columns alike
+    const bool oky = rc == 0 ? dy == 2 : (rc == 2 ? dy < 2 : true);
+    const bool okx = cc == 0 ? dx == 2 : (cc == 2 ? dx < 2 : true);
+    const int dyc = rc == 0 ? 2 : (rc == 2 ? (dy < 2 ? dy : 1) : dy);
+    const int dxc = cc == 0 ? 2 : (cc == 2 ? (dx < 2 ? dx : 1) : dx);
+    relT[tid] = (dyc * 16 + dxc) * PN * 4;
+    mskT[tid] = (oky && okx) ? 1.f : 0.f;
+  }
+
+  f32x4 acc[NACC], bacc[BACC];
+  int al[NACC], bl[NACC], abias[BACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int t = wave + 4 * i;
+    if (t >= TILES) t = TILES - 1;
+    const int kt = t % KT, nt = t / KT;
+    const int k = kt * 16 + lr;
+    const int ci = k / (KS * KS), rem = k - ci * (KS * KS), ky = rem / KS, kx = rem - ky * KS;
+    al[i] = kq * PN + nt * 16 + lr;
+    bl[i] = 2 * kq + ((k < K) ? (ci * IH + ky) * IW + kx : 0);
+  }
+#pragma unroll
+  for (int i = 0; i < BACC; ++i) {
+    bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int bt = (wave + 4 * i < TN) ? wave + 4 * i : 0;
+    abias[i] = kq * PN + bt * 16 + lr;
+  }
+
+  // tile-invariant item lists: phase ph = 2 * (window-row parity) + (window-column parity); tile origins are multiples of
+  // (4, 8) in window units, so parity of the absolute window index = parity of the tile-relative one
+  int it_goff[4][SL], it_lds[4][SL], it_key[4][SL];       // key = class * 36 | (wrow + 1) << 16 | (wcol + 1) << 24, -1 = no item
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+    const int odd_r = ph >> 1, odd_c = ph & 1;
+    const int ncols = odd_c ? 5 : 4, nrows = odd_r ? 3 : 2;
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int idx = tid + 256 * sl;
+      const int q = idx % NQ, w = idx / NQ;
+      const int wr = w / ncols, wc = w - wr * ncols;
+      const bool real = w < nrows * ncols;
+      const int pr = odd_r ? 2 * wr - 1 : 2 * wr, pc = odd_c ? 2 * wc - 1 : 2 * wc;      // window index relative to the tile
+      const int rcls = pr < 0 ? 0 : (pr >= 3 ? 2 : 1), ccls = pc < 0 ? 0 : (pc >= 7 ? 2 : 1);
+      it_goff[ph][sl] = real ? (pr * a.Wp + pc) * a.N + 4 * q : 0;
+      it_lds[ph][sl] = real ? ((2 * pr) * 16 + 2 * pc) * PN * 4 + 16 * q : 0;
+      it_key[ph][sl] = real ? ((rcls * 3 + ccls) * 36 | (pr + 1) << 16 | (pc + 1) << 24) : -1;
+    }
+  }
+  // image-patch DMA slots
+  int in_off[IN_IT], in_key[IN_IT];
+#pragma unroll
+  for (int it = 0; it < IN_IT; ++it) {
+    const int idx = tid + it * 256;
+    const int c = idx % IW; int r = idx / IW; const int ci = r / IH; r -= ci * IH;
+    const bool real = idx < NIN;
+    in_off[it] = real ? (ci * a.Hin + r) * a.Win + c : 0;
+    in_key[it] = real ? (r << 8 | c) : -1;
+  }
+
+  struct Tile { int wy0, wx0, iy0, ix0, img_inner, win_inner; long long wbase; const float* xorg; };
+  auto tile_at = [&](int t) {
+    Tile q;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
+    q.wy0 = ty * (TH / 2); q.wx0 = tx * 8;                                   // first window (row, col) owned by the tile
+    q.iy0 = 2 * ty * TH - PAD; q.ix0 = 2 * tx * 16 - PAD;
+    q.xorg = a.img + ((long long)b * 3 * a.Hin + q.iy0) * a.Win + q.ix0;
+    q.img_inner = (int)(((unsigned)(-q.iy0 - 1) & (unsigned)(q.iy0 + IH - a.Hin - 1) & (unsigned)(-q.ix0 - 1) & (unsigned)(q.ix0 + IW - a.Win - 1)) >> 31);
+    // all windows (rows wy0-1 .. wy0+3, cols wx0-1 .. wx0+7) exist
+    q.win_inner = (int)(((unsigned)(-q.wy0) & (unsigned)(q.wy0 + 3 - a.Hp) & (unsigned)(-q.wx0) & (unsigned)(q.wx0 + 7 - a.Wp)) >> 31);
+    q.wbase = (((long long)b * a.Hp + q.wy0) * a.Wp + q.wx0) * a.N;
+    return q;
+  };
+  auto dma_in = [&](const Tile q, int buf) {
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+      const float* src = q.xorg + in_off[it];
+      if (!q.img_inner) {
+        asm volatile("" ::: "memory");
+        const int key = in_key[it];
+        const bool ok = key >= 0 && (unsigned)(q.iy0 + (key >> 8)) < (unsigned)a.Hin && (unsigned)(q.ix0 + (key & 255)) < (unsigned)a.Win;
+        src = ok ? src : sqd_wgrad_zero;
+      }
+      __builtin_amdgcn_global_load_lds(src, (wg_lds_ptr_t)(inB + buf * INSLOTS + it * 256 + wave_s * 64), 4, 0, 0);
+    }
+  };
+  // dPool / pooled / argmax words of a tile's items -> registers
+  unsigned r_am[4][SL]; f32x4 r_dp[4][SL], r_pl[4][SL];
+  auto fetch_items = [&](const Tile q) {
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int key = it_key[ph][sl];
+        bool ok = key >= 0;
+        if (!q.win_inner) {
+          asm volatile("" ::: "memory");
+          const int wy = q.wy0 + ((key >> 16) & 255) - 1, wx = q.wx0 + ((key >> 24) & 255) - 1;
+          ok = ok && (unsigned)wy < (unsigned)a.Hp && (unsigned)wx < (unsigned)a.Wp;
+        }
+        r_am[ph][sl] = 0x09090909u;                                           // code 9 never matches a tap: weight 0 below
+        r_dp[ph][sl] = (f32x4){0.f, 0.f, 0.f, 0.f}; r_pl[ph][sl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const long long o = q.wbase + it_goff[ph][sl];
+          r_am[ph][sl] = *(const unsigned*)(a.amax + o);
+          r_dp[ph][sl] = *(const f32x4*)(a.dy + o);
+          r_pl[ph][sl] = *(const f32x4*)(a.pooled + o);
+        }
+      }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < a.nblocks) {
+    Tile cur = tile_at(tile);
+    dma_in(cur, 0);
+    fetch_items(cur);
+    int buf = 0;
+    for (;;) {
+      const int ntile = tile + (int)gridDim.x;
+      const bool has_next = ntile < a.nblocks;
+      const Tile nxt = tile_at(has_next ? ntile : tile);
+      __syncthreads();                       // previous tile's MFMAs left dyT / inB; this tile's patch has landed (vmcnt(0))
+      for (int idx = tid; idx < 128 * PN / 4; idx += 256) ((f32x4*)dyT)[idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      __syncthreads();
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+          const int key = it_key[ph][sl];
+          if (key < 0) continue;
+          const unsigned am = r_am[ph][sl];
+          const f32x4 dp = r_dp[ph][sl], pl = r_pl[ph][sl];
+          const int cls_off = key & 0xffff;
+          char* const base = (char*)dyT + it_lds[ph][sl];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned code = (am >> (8 * e)) & 255u;
+            const unsigned tix = code < 9u ? code : 0u;                        // out-of-image item: any valid table slot ...
+            const int rel = relT[cls_off / 4 + tix];
+            float w = mskT[cls_off / 4 + tix];
+            float v = pl[e] > 0.f ? dp[e] : 0.f;                               // ... its dp is 0
+            float* dst = (float*)(base + rel) + e;
+            *dst += v * w;
+          }
+        }
+        __syncthreads();
+      }
+      if (has_next) { dma_in(nxt, buf ^ 1); fetch_items(nxt); }
+      const float* inT = inB + buf * INSLOTS;
+#pragma unroll
+      for (int s = 0; s < TH * 4; ++s) {
+        const int r = s >> 2, cq = s & 3;
+        const int immA = (r * 16 + cq * 4) * PN;
+        const int immB = (2 * r) * IW + 8 * cq;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = mfma16(dyT[al[i] + immA], inT[bl[i] + immB], acc[i]);
+#pragma unroll
+        for (int i = 0; i < BACC; ++i) bacc[i] = mfma16(dyT[abias[i] + immA], 1.0f, bacc[i]);
+      }
+      if (!has_next) break;
+      tile = ntile; cur = nxt; buf ^= 1;
+    }
+  }
+  float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int t = wave + 4 * i;
+    if (t >= TILES) continue;
+    const int kt = t % KT, nt = t / KT;
+    const int k = kt * 16 + lr;
+    if (k >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nt * 16 + 4 * kq + r;
+      if (n < a.N) slab[(long long)n * K + k] = acc[i][r];
+    }
+  }
+  if (lr == 0) {
+#pragma unroll
+    for (int i = 0; i < BACC; ++i) {
+      const int bt = wave + 4 * i;
+      if (bt >= TN) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = bt * 16 + 4 * kq + r;
+        if (n < a.N) slab[(long long)a.N * K + n] = bacc[i][r];
+      }
+    }
+  }
+}
+
+template <int KS, int PAD, int TN>
+static int launch_stem_wgrad_pooled(StemWgradArgs a, int S, hipStream_t s) {
+  constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16);
+  constexpr int IH = 14 + KS, IW = 30 + KS;
+  constexpr int INSLOTS = (3 * IH * IW + 255) / 256 * 256;
+  constexpr size_t lds = (size_t)(128 * PN + 2 * INSLOTS + 81 + 81) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "stem wgrad LDS budget");
+  a.tiles_x = sqd_cdiv(a.Wo, 16); a.tiles_y = sqd_cdiv(a.Ho, 8);
+  a.nblocks = a.B * a.tiles_x * a.tiles_y;
+  auto kern = stem_wgrad_pooled_kernel<KS, PAD, TN>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SQD_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(256), lds, s, a);
+  return sqd_launch_status();
+}
+
 template <int KS, int PAD, int TN, bool POOLED>
 static int launch_stem_wgrad(StemWgradArgs a, int S, hipStream_t s) {
   constexpr int PN = TN * 16 + ((TN & 1) ? 0 : 16);
@@ -489,8 +738,8 @@ static int stem_wgrad_common(StemWgradArgs a, int ksize, int S, float* dw, float
   a.Ho = (a.Hin + 2 * pad - ksize) / 2 + 1; a.Wo = (a.Win + 2 * pad - ksize) / 2 + 1;
   a.Hp = (a.Ho - 3 + 1) / 2 + 1; a.Wp = (a.Wo - 3 + 1) / 2 + 1;
   int rc = SQD_ERR_UNSUPPORTED;
-  if (ksize == 3 && a.N == 64) rc = pooled ? launch_stem_wgrad<3, 1, 4, true>(a, S, s) : launch_stem_wgrad<3, 1, 4, false>(a, S, s);
-  else if (ksize == 7 && a.N == 96) rc = pooled ? launch_stem_wgrad<7, 3, 6, true>(a, S, s) : launch_stem_wgrad<7, 3, 6, false>(a, S, s);
+  if (ksize == 3 && a.N == 64) rc = pooled ? launch_stem_wgrad_pooled<3, 1, 4>(a, S, s) : launch_stem_wgrad<3, 1, 4, false>(a, S, s);
+  else if (ksize == 7 && a.N == 96) rc = pooled ? launch_stem_wgrad_pooled<7, 3, 6>(a, S, s) : launch_stem_wgrad<7, 3, 6, false>(a, S, s);
   if (rc != SQD_OK) return rc;
   // slab layout [n][K] is already OIHW-flat: reduce with C := K, TAPS := 1
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.slab_stride + WGR_OUT - 1) / WGR_OUT)), dim3(WGR_OUT * WGR_PARTS), 0, s, a.slab, dw, db, S,
