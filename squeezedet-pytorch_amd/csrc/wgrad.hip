@@ -59,66 +59,77 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int n0 = ng * TN * 16, c0 = cg * TC * 16;
   const bool do_bias = (cg == 0);
 
-  // block-independent decode of this lane's DMA slots
-  int d_pix[D_IT], d_ch[D_IT], x_pix[X_IT], x_ch[X_IT];
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+
+  // Block-independent part of this lane's DMA slots: a 32-bit element offset from the block's origin pointer (dY: its
+  // first pixel; X, 3x3: the halo pixel (y0-1, x0-1)).  Interior blocks issue their DMA as uniform base + offset with
+  // no per-lane arithmetic; only border blocks look at the packed (row, col) key to send out-of-image slots to the
+  // zero page.  Slots of channels beyond N / C and padding slots fetch the origin element: whatever they hold only
+  // reaches accumulator rows / columns that are never stored.
+  int d_off[D_IT], d_key[D_IT], x_off[X_IT], x_key[X_IT];
 #pragma unroll
   for (int it = 0; it < D_IT; ++it) {
     const int slot = it * 256 + tid;
     const int pix = slot / RN, qp = slot - pix * RN;
     const int q = SWN ? (qp ^ ((pix & 1) << 2)) : qp;
-    d_pix[it] = (pix < PB) ? pix : -1;
-    d_ch[it] = n0 + 4 * q;
+    const bool real = pix < PB && n0 + 4 * q < a.N;
+    const int r = (TAPS == 9) ? (pix >> 4) : 0, c = (TAPS == 9) ? (pix & 15) : pix;
+    d_off[it] = real ? (r * a.W + c) * a.dy_pitch + n0 + 4 * q : 0;
+    d_key[it] = real ? (r << 16 | c) : -1;
   }
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
     const int slot = it * 256 + tid;
     const int pix = slot / RC, qp = slot - pix * RC;
     const int q = SWC ? (qp ^ ((pix & 1) << 2)) : qp;
-    x_pix[it] = (pix < XPIX) ? pix : -1;
-    x_ch[it] = c0 + 4 * q;
+    const bool real = pix < XPIX && c0 + 4 * q < a.C;
+    const int r = (TAPS == 9) ? pix / 18 : 0, c = (TAPS == 9) ? pix - r * 18 : pix;
+    x_off[it] = real ? (r * a.W + c) * a.x_pitch + c0 + 4 * q : 0;
+    x_key[it] = real ? (r << 16 | c) : -1;
   }
 
   auto dma_block = [&](int pb, int buf) {
-    int b = 0, y0 = 0, x0 = 0;
-    long long p0 = 0;
+    int y0 = 0, x0 = 0, inner;
+    long long p0;                                          // flat index of the block's first pixel
     if (TAPS == 9) {
       int t = pb;
       const int tx = t % a.tiles_x; t /= a.tiles_x;
-      const int ty = t % a.tiles_y; b = t / a.tiles_y;
+      const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
       y0 = ty * TH; x0 = tx * 16;
+      p0 = ((long long)b * a.H + y0) * a.W + x0;
+      // y0 >= 1, y0 + TH + 1 <= H, x0 >= 1, x0 + 17 <= W (then the dY tile is whole too)
+      inner = (int)(((unsigned)(-y0) & (unsigned)(y0 + TH - a.H) & (unsigned)(-x0) & (unsigned)(x0 + 16 - a.W)) >> 31);
     } else {
       p0 = (long long)pb * PB;
+      inner = (int)((unsigned long long)(p0 + PB - a.total_px - 1) >> 63);
     }
+    const float* dorg = a.dy + p0 * a.dy_pitch + a.dy_coff;
+    const float* xorg = a.x + ((TAPS == 9) ? p0 - a.W - 1 : p0) * a.x_pitch + a.x_coff;   // dereferenced only where valid
 #pragma unroll
     for (int it = 0; it < D_IT; ++it) {
-      const int pix = d_pix[it];
-      bool ok = pix >= 0 && d_ch[it] < a.N;
-      long long gp;
-      if (TAPS == 9) {
-        const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
-        ok = ok && iy < a.H && ix < a.W;
-        gp = ((long long)b * a.H + iy) * a.W + ix;
-      } else {
-        gp = p0 + pix; ok = ok && gp < a.total_px;
+      const float* src = dorg + d_off[it];
+      if (!inner) {
+        asm volatile("" ::: "memory");                     // keep the border path a real scalar branch
+        const int key = d_key[it];
+        bool ok = key >= 0;
+        if (TAPS == 9) ok = ok && y0 + (key >> 16) < a.H && x0 + (key & 0xffff) < a.W;
+        else ok = ok && p0 + (key & 0xffff) < a.total_px;
+        src = ok ? src : sqd_wg_zero_page;
       }
-      const float* src = ok ? a.dy + gp * a.dy_pitch + a.dy_coff + d_ch[it] : sqd_wg_zero_page;
-      __builtin_amdgcn_global_load_lds(src, (wg_lds_ptr_t)(dyB + (buf * DSLOTS + it * 256 + wave * 64) * 4), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, (wg_lds_ptr_t)(dyB + (buf * DSLOTS + it * 256 + wave_s * 64) * 4), 16, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
-      const int pix = x_pix[it];
-      bool ok = pix >= 0 && x_ch[it] < a.C;
-      long long gp;
-      if (TAPS == 9) {
-        const int r = pix / 18, col = pix - r * 18;
-        const int iy = y0 + r - 1, ix = x0 + col - 1;
-        ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        gp = ((long long)b * a.H + iy) * a.W + ix;
-      } else {
-        gp = p0 + pix; ok = ok && gp < a.total_px;
+      const float* src = xorg + x_off[it];
+      if (!inner) {
+        asm volatile("" ::: "memory");
+        const int key = x_key[it];
+        bool ok = key >= 0;
+        if (TAPS == 9) ok = ok && (unsigned)(y0 + (key >> 16) - 1) < (unsigned)a.H && (unsigned)(x0 + (key & 0xffff) - 1) < (unsigned)a.W;
+        else ok = ok && p0 + (key & 0xffff) < a.total_px;
+        src = ok ? src : sqd_wg_zero_page;
       }
-      const float* src = ok ? a.x + gp * a.x_pitch + a.x_coff + x_ch[it] : sqd_wg_zero_page;
-      __builtin_amdgcn_global_load_lds(src, (wg_lds_ptr_t)(xB + (buf * XSLOTS + it * 256 + wave * 64) * 4), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, (wg_lds_ptr_t)(xB + (buf * XSLOTS + it * 256 + wave_s * 64) * 4), 16, 0, 0);
     }
   };
 
@@ -308,7 +319,9 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
     else rc = launch_wgrad<9, 3, 1, 4>(a, S, s);
   } else {
     const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
-#define SQD_WG_CASE(TNv, TCv) if (tn == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, 8>(a, S, s);
+    // pixels per block sized so the double-buffered LDS image stays <= 40 KB: 4-5 workgroups per CU instead of one
+    // (the late 24x78 layers have only ~300 blocks of 128 pixels: with one resident workgroup per CU nothing overlapped)
+#define SQD_WG_CASE(TNv, TCv) if (tn == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, ((TNv + TCv >= 6) ? 2 : ((TNv + TCv >= 3) ? 4 : 8))>(a, S, s);
     SQD_WG_CASE(1, 1) SQD_WG_CASE(1, 2) SQD_WG_CASE(1, 3) SQD_WG_CASE(1, 4)
     SQD_WG_CASE(2, 1) SQD_WG_CASE(2, 2) SQD_WG_CASE(2, 3) SQD_WG_CASE(2, 4)
     SQD_WG_CASE(3, 1) SQD_WG_CASE(3, 2) SQD_WG_CASE(3, 3) SQD_WG_CASE(3, 4)

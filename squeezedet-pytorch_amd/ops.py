@@ -453,7 +453,8 @@ def filter_dense(class_ids, scores, boxes, num_classes, keep_top_k=64, nms_thres
 # ---------------------------------------------------------------------------------------------
 # training-side ops
 # ---------------------------------------------------------------------------------------------
-_TARGET_WGS = 1536
+_TARGET_WGS = 1536          # workgroups a 3x3 weight-gradient launch aims for (measured sweep 768 / 1536 / 3072)
+_TARGET_WGS_1X1 = 1024      # 1x1: fewer, longer pixel streams (less slab traffic per MFMA)
 
 
 def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps):
@@ -482,7 +483,7 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps):
         tc = 4 if C >= 64 else -(-C // 16)
         nblocks = -(-(B * H * W) // 128)
     groups = -(-N // (tn * 16)) * -(-C // (tc * 16))
-    S = max(1, min(nblocks, _TARGET_WGS // groups, 256))
+    S = max(1, min(nblocks, (_TARGET_WGS if taps == 9 else _TARGET_WGS_1X1) // groups, 256))
     stride = N * taps * C + N
     slab = torch.empty(S * stride, device=dy.device, dtype=torch.float32)
     dw = torch.empty(N, C, k, k, device=dy.device, dtype=torch.float32)
