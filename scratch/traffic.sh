@@ -24,8 +24,10 @@ for k, v in res.items():
     fetch_kb, write_kb = v["FETCH_SIZE"] / nf, v["WRITE_SIZE"] / nw
     m = re.match(r"void (\w+)<([^>]*)>", k)
     short = k.split("(")[0].replace("void ", "").strip()
-    m = re.match(r"conv_(dma|igemm)_kernel<(\d+), (\d+), (\d+), (\d+), \d+>", short)
-    if m: short = f"conv_{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>"
+    m = re.match(r"conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), \d+>", short)
+    if m: short = f"conv_igemm<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)}>"
+    m = re.match(r"conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), \d+>", short)      # <TAPS,KC,MT,NT,WAVES,MINW>
+    if m: short = f"conv_dma<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>"
     m = re.match(r"(stem_pool|stem_conv|stem_wgrad)_kernel<(\d+),", short)
     if m: short = f"{m.group(1)}<{m.group(2)}>"
     short = {"maxpool_fwd_kernel": "maxpool_fwd", "maxpool_bwd_kernel": "maxpool_bwd", "detect_kernel": "detect"}.get(short, short)

@@ -390,7 +390,11 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < MT; ++i)
     o_off[i] = ((TAPS == 9) ? (wm * MT + i) * a.W + lr : (wm * MT + i) * 16 + lr) * a.y_pitch + 4 * g;
-  const bool plain_epi = !a.accumulate && !a.ymul && !a.ymask;          // forward layers: bias (+ ReLU) only
+  // check-free epilogue: whole tiles whose mask / scale tensors (if any) share the output's geometry, so one per-lane
+  // offset addresses all of them (forward layers: bias + ReLU; dgrads: accumulate, ReLU-backward mask, dropout scale)
+  const bool plain_epi = (!a.ymul || (a.ymul_pitch == a.y_pitch && a.ymul_coff == a.y_coff)) &&
+                         (!a.ymask || (a.ymask_pitch == a.y_pitch && a.ymask_coff == a.y_coff));
+  const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
   const float relu_lo = a.relu ? 0.f : -__builtin_inff();             // branch-free ReLU switch (one v_max per element)
 
   TilePos cur = tile_pos(tile);
@@ -407,6 +411,8 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   // stores drain under the next stage's MFMAs instead of in front of the barrier's vmcnt(0)
   auto flush = [&](const TilePos tp) {
     float* ybase = a.y + tp.p0 * a.y_pitch + a.y_coff + n0;              // uniform
+    const float* mulbase = a.ymul + tp.p0 * a.y_pitch + a.y_coff + n0;   // (same geometry as y on the fast path)
+    const float* maskbase = a.ymask + tp.p0 * a.y_pitch + a.y_coff + n0;
     const bool whole = ((TAPS == 9) ? (tp.y0 + TH <= a.H && tp.x0 + 16 <= a.W) : (tp.p0 + TH * 16 <= a.total_px)) && n0 + BN <= a.N;
     if (plain_epi && whole) {                                             // uniform fast path: no bounds checks, no 64-bit math
 #pragma unroll
@@ -414,8 +420,15 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           f32x4 v = outv[i][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
+          const int off = o_off[i] + j * 16;
+          if (acc_i) v += *(const f32x4*)(ybase + off);
+          if (has_mul) v *= *(const f32x4*)(mulbase + off);
+          if (has_mask) {
+            const f32x4 m = *(const f32x4*)(maskbase + off);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+          }
           v = sqd_relu4(v, relu_lo);
-          *(f32x4*)(ybase + o_off[i] + j * 16) = v;
+          *(f32x4*)(ybase + off) = v;
         }
       return;
     }

@@ -14,6 +14,9 @@
 // The bias gradient rides along as extra tiles with B = 1.
 #include "sqd_common.h"
 
+#ifndef SQD_WG9_TH
+#define SQD_WG9_TH 4
+#endif
 struct WgradArgs {
   const float* dy; const float* x; float* slab;
   int B, H, W;
@@ -312,7 +315,7 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
   int rc = SQD_ERR_UNSUPPORTED;
   if (taps == 9) {
     if (N > 64 && N <= 80) rc = launch_wgrad<9, 5, 1, 4>(a, S, s);      // ConvDet (N = 72)
-    else if (C % 32 == 0 && tn == 4) rc = launch_wgrad<9, 4, 2, 4>(a, S, s);
+    else if (C % 32 == 0 && tn == 4) rc = launch_wgrad<9, 4, 2, SQD_WG9_TH>(a, S, s);
     else if (tn == 4) rc = launch_wgrad<9, 4, 1, 4>(a, S, s);
     else if (tn == 1) rc = launch_wgrad<9, 1, 2, 4>(a, S, s);
     else if (tn == 2) rc = launch_wgrad<9, 2, 2, 4>(a, S, s);
