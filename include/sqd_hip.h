@@ -124,6 +124,15 @@ int sqd_filter_fwd(const long long* class_ids, const float* scores, const float*
 int sqd_preprocess_u8_fwd(const unsigned char* src, const long long* offsets, const int* sizes, float* out,
                           float* scales, const float* mean3, const float* std3, int B, int H, int W, void* stream);
 
+/* Fused Fire expand (Fire.forward, src/model/squeezedet.py:18-22: expand1x1 and expand3x3 of the squeeze output,
+ * concatenated): y[..., y_coff : y_coff+E] = ReLU(conv1x1(x)), y[..., y_coff+E : y_coff+2E] = ReLU(conv3x3(x)) in ONE
+ * launch.  w_packed / bias: the 2E output channels in alternating 16-channel groups (group 2i = expand1x1 channels
+ * 16i..16i+15 written as a 3x3 kernel whose only non-zero tap is the centre, group 2i+1 = expand3x3 channels
+ * 16i..16i+15), packed by sqd_pack_conv_weight for cfg_id; cfg_id must be a 3x3 LDS-DMA configuration with an even
+ * number of 16-channel groups per slice whose slice width divides 2E (+ 1000 * k = workgroups-per-CU cap). */
+int sqd_fire_expand_fwd(const float* x, const float* w_packed, const float* bias, float* y, int B, int H, int W, int C,
+                        int x_pitch, int x_coff, int E, int Npad, int y_pitch, int y_coff, int cfg_id, void* stream);
+
 /* On-device GT encoding: compute_deltas (src/utils/boxes.py:84-135: greedy unique
  * anchor assignment by free-anchor IoU, nearest free anchor by squared (cx,cy,w,h) distance when no free anchor
  * overlaps) + BaseDataset.prepare_annotations (src/datasets/base.py:61-76: dense gt row = mask, xyxy, deltas,

@@ -66,8 +66,14 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
             sq = torch.empty(Bq, H, W, s, device=a.device, dtype=torch.float32)
             ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
             out = torch.empty(Bq, H, W, e1 + e3, device=a.device, dtype=torch.float32)
-            ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, s, e1, npix)), out, 0, relu=True)
-            ops.conv(sq, 0, base.plan(f'{i}.expand3x3', fire.expand3x3, ops.choose_cfg(9, s, e3, npix)), out, e1, relu=True)
+            fcfg = ops.choose_fused_cfg(s, e1, npix) if (not save and base.fuse_expand and e1 == e3) else None
+            if fcfg is not None:
+                # inference: both expands in one launch (they read the same squeeze tile; the 1x1 rides along as extra
+                # channel groups that only run the centre tap)
+                ops.fire_expand(sq, 0, base.fused_expand_plan(i, fire, fcfg), out, 0)
+            else:
+                ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, s, e1, npix)), out, 0, relu=True)
+                ops.conv(sq, 0, base.plan(f'{i}.expand3x3', fire.expand3x3, ops.choose_cfg(9, s, e3, npix)), out, e1, relu=True)
             if save:
                 saved[f'fire{i}'] = (a, sq, out)
             a = out

@@ -39,6 +39,7 @@ struct ConvArgs {
   int tiles_x, tiles_y, ntiles;
   int nslices, gx;                           // persistent grid: gx tile streams x nslices channel slices (1-D launch)
   int wg_cap;                                // host only: cap on resident workgroups per CU (0 = occupancy)
+  int fuse_e;                                // fused Fire expand: E = channels of EACH half (expand1x1 | expand3x3), else 0
   int xmask_pitch, xmask_coff;
   const float* ymask; const float* ymul;      // epilogue: zero where ymask <= 0 (ReLU backward), multiply by ymul (dropout)
   int ymask_pitch, ymask_coff, ymul_pitch, ymul_coff;
@@ -272,8 +273,16 @@ __device__ __forceinline__ f32x4 sqd_relu4(f32x4 v, float lo) {      // lo (wave
   return v;
 }
 
-template <int TAPS, int KC, int MT, int NT, int WM, int MINW>
+// FUSE = true is the fused Fire expand (reference: Fire.forward, src/model/squeezedet.py:18-22 -- expand1x1 and expand3x3
+// both read the squeeze output and are concatenated): the packed weights hold 2E output channels in 16-channel groups
+// that ALTERNATE between the two convolutions (group 2i = expand1x1 channels 16i.., as a 3x3 whose only non-zero tap
+// is the centre; group 2i+1 = expand3x3 channels 16i..).  With NT even every workgroup slice carries the same mix, the
+// 1x1 groups simply skip the MFMAs (and operand reads) of the 8 outer taps, and the epilogue writes group 2i to
+// channel window [0, E) and group 2i+1 to [E, 2E) of the output -- the concat.  One launch, one staging of the
+// squeeze tile, and the 1x1 outputs' stores drain under the 3x3's matrix work.
+template <int TAPS, int KC, int MT, int NT, int WM, int MINW, bool FUSE>
 __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
+  static_assert(!FUSE || (TAPS == 9 && (NT % 2) == 0), "fused expand: 3x3 tiles with an even number of channel groups");
   constexpr int NTHR = WM * 64;              // 4 or 8 waves; with 8, two waves per SIMD share one staged tile
   constexpr int TH = MT * WM;
   constexpr int BN = 16 * NT;
@@ -410,9 +419,12 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   // store a finished tile (bias / accumulate / masks / ReLU fused); called right AFTER a stage barrier so the
   // stores drain under the next stage's MFMAs instead of in front of the barrier's vmcnt(0)
   auto flush = [&](const TilePos tp) {
-    float* ybase = a.y + tp.p0 * a.y_pitch + a.y_coff + n0;              // uniform
-    const float* mulbase = a.ymul + tp.p0 * a.y_pitch + a.y_coff + n0;   // (same geometry as y on the fast path)
-    const float* maskbase = a.ymask + tp.p0 * a.y_pitch + a.y_coff + n0;
+    // channel of the slice's first group: plain conv n0; fused expand: groups alternate 1x1 / 3x3, both halves advance
+    // by 16 channels per PAIR of groups (n0 is a multiple of 32 there)
+    const int ch0 = FUSE ? (n0 >> 1) : n0;
+    float* ybase = a.y + tp.p0 * a.y_pitch + a.y_coff + ch0;             // uniform
+    const float* mulbase = a.ymul + tp.p0 * a.y_pitch + a.y_coff + ch0;  // (same geometry as y on the fast path)
+    const float* maskbase = a.ymask + tp.p0 * a.y_pitch + a.y_coff + ch0;
     const bool whole = ((TAPS == 9) ? (tp.y0 + TH <= a.H && tp.x0 + 16 <= a.W) : (tp.p0 + TH * 16 <= a.total_px)) && n0 + BN <= a.N;
     if (plain_epi && whole) {                                             // uniform fast path: no bounds checks, no 64-bit math
 #pragma unroll
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           f32x4 v = outv[i][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
-          const int off = o_off[i] + j * 16;
+          const int off = o_off[i] + (FUSE ? ((j >> 1) * 16 + ((j & 1) ? a.fuse_e : 0)) : j * 16);
           if (acc_i) v += *(const f32x4*)(ybase + off);
           if (has_mul) v *= *(const f32x4*)(mulbase + off);
           if (has_mask) {
@@ -445,8 +457,9 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 16 + 4 * g;
-        if (!valid || n >= a.N) continue;
+        const int np = n0 + j * 16 + 4 * g;                                     // channel in packed (interleaved) order
+        if (!valid || np >= a.N) continue;
+        const int n = FUSE ? (((j & 1) ? a.fuse_e : 0) + ((n0 >> 1) + (j >> 1) * 16 + 4 * g)) : np;
         f32x4 v = outv[i][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
         float* dst = a.y + gp * a.y_pitch + a.y_coff + n;
         if (a.accumulate) v += *(const f32x4*)dst;
@@ -500,14 +513,19 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
             bf[i] = *(const f32x4*)(actL + (4 * s * NPIXP + row) * 4);
           }
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
+          for (int j = 0; j < NT; ++j) {
+            if (FUSE && !(j & 1) && tap != 4) continue;                              // 1x1 group: centre tap only
             af[j] = *(const f32x4*)(wL + (4 * s * WROWS + tap * BN + j * 16) * 4);
+          }
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-              for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(af[j][t], bf[i][t], acc[i][j]);
+              for (int j = 0; j < NT; ++j) {
+                if (FUSE && !(j & 1) && tap != 4) continue;
+                acc[i][j] = mfma16(af[j][t], bf[i][t], acc[i][j]);
+              }
         }
       }
 
@@ -580,7 +598,7 @@ static int launch_conv(ConvArgs a, hipStream_t stream) {
   return sqd_launch_status();
 }
 
-template <int TAPS, int KC, int MT, int NT, int WM>
+template <int TAPS, int KC, int MT, int NT, int WM, bool FUSE = false>
 static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   constexpr int TH = MT * WM, BN = 16 * NT, NTHR = WM * 64;
   constexpr int NPIX = (TAPS == 9) ? (TH + 2) * 18 : TH * 16;
@@ -597,7 +615,7 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   constexpr int LDSW = (int)((160 * 1024) / ((size_t)(2 * ASLOTS + WSLOTS) * 16 + BN * sizeof(float))) * (WM / 4);
   constexpr int MINW0 = LDSW < REGW ? (LDSW < 1 ? 1 : LDSW) : REGW;
   constexpr int MINW = (MINW0 < WM / 4) ? WM / 4 : MINW0;
-  auto kern = conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW>;
+  auto kern = conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW, FUSE>;
   static int wgs_per_cu[2] = {0, 0};
   if (wgs_per_cu[stationary] == 0) {
     if (lds_max > 64 * 1024 &&
@@ -755,7 +773,7 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.xmask = xmask;
   a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff;
-  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8; a.wg_cap = wg_cap;
+  a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8; a.wg_cap = wg_cap; a.fuse_e = 0;
   a.xmask_pitch = xmask_pitch; a.xmask_coff = xmask_coff;
   a.total_px = (long long)B * H * W;
   hipStream_t s = (hipStream_t)stream;
@@ -820,5 +838,44 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   SQD_CONV_CASE(1, 64, 2, 1)
   SQD_CONV_CASE(1, 64, 2, 2)
 #undef SQD_CONV_CASE
+  return SQD_ERR_UNSUPPORTED;
+}
+
+// Fused Fire expand: y[..., y_coff : y_coff+E] = ReLU(conv1x1(x)), y[..., y_coff+E : y_coff+2E] = ReLU(conv3x3(x)) in one
+// launch (reference: Fire.forward src/model/squeezedet.py:18-22).  w_packed / bias hold the 2E channels in the
+// alternating 16-channel-group order described at conv_dma_kernel (built by the host from the two modules' weights:
+// group 2i = expand1x1[16i:16i+16] as centre-tap-only 3x3, group 2i+1 = expand3x3[16i:16i+16]), packed with
+// sqd_pack_conv_weight for a 3x3 LDS-DMA configuration with an even number of channel groups per slice.
+// E must be a multiple of 16 * (NT / 2) ... i.e. 2E a multiple of the slice width; Npad >= 2E rounded up to it.
+extern "C" int sqd_fire_expand_fwd(const float* x, const float* w_packed, const float* bias, float* y, int B, int H, int W,
+                                   int C, int x_pitch, int x_coff, int E, int Npad, int y_pitch, int y_coff, int cfg_id,
+                                   void* stream) {
+  SQD_CHECK_ARG(x && w_packed && y && B > 0 && H > 0 && W > 0 && C > 0 && E > 0);
+  const int wg_cap = cfg_id >= 0 ? cfg_id / 1000 : 0;
+  if (cfg_id >= 0) cfg_id %= 1000;
+  SQD_CHECK_ARG(cfg_id >= 0 && cfg_id < kNumConvCfgs && wg_cap <= 8);
+  SQD_CHECK_ARG((C & 3) == 0 && (E & 15) == 0);
+  SQD_CHECK_ARG((x_pitch & 3) == 0 && (x_coff & 3) == 0 && (y_pitch & 3) == 0 && (y_coff & 3) == 0);
+  SQD_CHECK_ARG(x_coff + C <= x_pitch && y_coff + 2 * E <= y_pitch);
+  SQD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)w_packed & 15) == 0);
+  SQD_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0);
+  const ConvCfg& c = kConvCfgs[cfg_id];
+  SQD_CHECK_ARG(c.taps == 9 && c.dma != 0 && (c.nt & 1) == 0);
+  SQD_CHECK_ARG((2 * E) % (16 * c.nt) == 0);               // whole slices: every slice carries nt/2 groups of each half
+  ConvArgs a;
+  a.ymask = nullptr; a.ymul = nullptr; a.ymask_pitch = a.ymask_coff = a.ymul_pitch = a.ymul_coff = 0;
+  a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.xmask = nullptr;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.N = 2 * E; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff;
+  a.relu = 1; a.accumulate = 0; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8; a.wg_cap = wg_cap;
+  a.fuse_e = E;
+  a.xmask_pitch = a.xmask_coff = 0;
+  a.total_px = (long long)B * H * W;
+  hipStream_t s = (hipStream_t)stream;
+#define SQD_FUSE_CASE(M, Nn, Wv) \
+  if (c.dma == ((Wv) == 8 ? 2 : 1) && c.kc == 16 && c.mt == M && c.nt == Nn) return launch_conv_dma<9, 16, M, Nn, Wv, true>(a, s);
+  SQD_FUSE_CASE(1, 2, 4) SQD_FUSE_CASE(1, 4, 4) SQD_FUSE_CASE(2, 2, 4) SQD_FUSE_CASE(2, 4, 4) SQD_FUSE_CASE(4, 2, 4)
+  SQD_FUSE_CASE(1, 2, 8) SQD_FUSE_CASE(1, 4, 8) SQD_FUSE_CASE(2, 2, 8) SQD_FUSE_CASE(2, 4, 8)
+#undef SQD_FUSE_CASE
   return SQD_ERR_UNSUPPORTED;
 }

@@ -89,6 +89,8 @@ class SqueezeDetBase(nn.Module):
         self.dropout = nn.Dropout(cfg.dropout_prob, inplace=True) if cfg.dropout_prob > 0 else None
         self.convdet = _ConvParams(convdet_in_channels(cfg.arch), cfg.anchors_per_grid * (cfg.num_classes + 5), 3, padding=1)
         self._plans = {}
+        self._fused_plans = {}
+        self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
         self._pack_table_keepalive = None
         self._forced_drop_mask = None       # tests: NCHW mask (already scaled by 1/(1-p)) instead of RNG
         self.init_weights()
@@ -109,6 +111,20 @@ class SqueezeDetBase(nn.Module):
             return hit[1]
         p = ops.ConvPlan(mod.weight, mod.bias, cfg_id, dgrad=(direction != 'fwd'))
         self._plans[key] = (ver, p)
+        return p
+
+    def fused_expand_plan(self, idx, fire, cfg_id):
+        """Packed weights of ``fire``'s expand pair for the one-launch fused expand (inference forward).  Rebuilt when
+        either module's parameters change; not part of ``refresh_plans`` (training keeps the two separate kernels, whose
+        per-layer activations and packed weights the backward needs anyway)."""
+        key = ('fused', idx, cfg_id)
+        mods = (fire.expand1x1, fire.expand3x3)
+        ver = tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()))
+        hit = self._fused_plans.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        p = ops.FusedExpandPlan(fire.expand1x1.weight, fire.expand1x1.bias, fire.expand3x3.weight, fire.expand3x3.bias, cfg_id)
+        self._fused_plans[key] = (ver, p)
         return p
 
     def refresh_plans(self):

@@ -116,7 +116,8 @@ def _tuning():
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning.json')
         try:
             with open(path) as f:
-                _TUNING = {k: int(v['cfg']) for k, v in json.load(f).items()}
+                _TUNING = {k: (int(v['cfg']) if not (k.startswith('F:') and v.get('separate_us', 0) and v['us'] >= v['separate_us']) else -1)
+                           for k, v in json.load(f).items()}
         except (OSError, ValueError, KeyError):
             _TUNING = {}
     return _TUNING
@@ -249,6 +250,64 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
                                 int(relu), int(accumulate), mp, xmask_coff, ymp, ymask_coff, ylp, ymul_coff,
                                 plan.cfg_id, nat.stream_handle(x.device))
     nat.check(rc, 'sqd_conv_fwd')
+    if br is not None:
+        br.done()
+    return y
+
+
+def fused_expand_cfgs(E):
+    """3x3 LDS-DMA configurations usable by the fused Fire expand for half-width E: even number of 16-channel groups
+    per slice, slice width dividing 2E."""
+    tab = cfg_table()
+    return [c for c, (t, kc, px, bn) in tab.items() if t == 9 and _CFG_DMA.get(c, 0) and (bn // 16) % 2 == 0 and (2 * E) % bn == 0]
+
+
+def choose_fused_cfg(C, E, npix):
+    """Configuration for ``fire_expand``: measured table key ``F:C:E:npix`` if present, else 64-channel slices."""
+    ok = fused_expand_cfgs(E)
+    if not ok:
+        return None
+    hit = _tuning().get(f'F:{C}:{E}:{npix}')
+    if hit is not None:
+        return hit if (hit >= 0 and hit % 1000 in ok) else None      # -1: measured slower than the two separate launches
+    tab = cfg_table()
+    pref = [c for c in ok if tab[c][3] == 64 and _CFG_DMA[c] == 1 and tab[c][2] == 64]
+    return (pref or ok)[0]
+
+
+class FusedExpandPlan(object):
+    """Packed weights of one Fire's expand pair for ``fire_expand``: the 2E output channels in alternating 16-channel
+    groups (expand1x1 group as a centre-tap-only 3x3, then the expand3x3 group), packed like any 3x3 conv."""
+
+    def __init__(self, w1, b1, w3, b3, cfg_id):
+        E, C = w1.shape[0], w1.shape[1]
+        if tuple(w1.shape) != (E, C, 1, 1) or tuple(w3.shape) != (E, C, 3, 3) or E % 16:
+            raise ValueError(f'fused expand: need expand1x1 [E,C,1,1] and expand3x3 [E,C,3,3] with E % 16 == 0, got {tuple(w1.shape)}, {tuple(w3.shape)}')
+        if cfg_id % 1000 not in fused_expand_cfgs(E):
+            raise ValueError(f'conv cfg {cfg_id} cannot run the fused expand with E={E}')
+        w1 = w1.detach(); w3 = w3.detach()
+        wf = torch.zeros(E // 16, 2, 16, C, 3, 3, device=w3.device, dtype=torch.float32)
+        wf[:, 0, :, :, 1, 1] = w1.reshape(E // 16, 16, C)
+        wf[:, 1] = w3.reshape(E // 16, 16, C, 3, 3)
+        bf = torch.stack([b1.detach().reshape(E // 16, 16), b3.detach().reshape(E // 16, 16)], 1).reshape(-1)
+        self.plan = ConvPlan(wf.reshape(2 * E, C, 3, 3), bf, cfg_id)
+        self.E, self.C, self.cfg_id = E, C, cfg_id
+
+
+def fire_expand(x, x_coff, fplan, y, y_coff):
+    """y[..., y_coff:y_coff+E] = relu(expand1x1(x)), y[..., y_coff+E:y_coff+2E] = relu(expand3x3(x)), one launch."""
+    _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
+    B, H, W, xp = x.shape
+    if tuple(y.shape[:3]) != (B, H, W):
+        raise ValueError('fire_expand: x and y disagree on B,H,W')
+    p = fplan.plan
+    if x_coff + fplan.C > xp or y_coff + 2 * fplan.E > y.shape[3]:
+        raise ValueError('fire_expand: channel window out of range')
+    br = _Bracket(cfg_kernel_name(fplan.cfg_id).replace('conv_dma', 'fire_expand'), f'expand C{fplan.C} E{fplan.E} {H}x{W}',
+                  2.0 * B * H * W * fplan.E * fplan.C * 10, 4.0 * B * H * W * (fplan.C + 2 * fplan.E)) if _timer is not None else None
+    rc = nat.lib().sqd_fire_expand_fwd(nat.ptr(x), nat.ptr(p.w), nat.ptr(p.bias), nat.ptr(y), B, H, W, fplan.C, xp, x_coff, fplan.E,
+                                       p.Npad, y.shape[3], y_coff, fplan.cfg_id, nat.stream_handle(x.device))
+    nat.check(rc, 'sqd_fire_expand_fwd')
     if br is not None:
         br.done()
     return y

@@ -153,3 +153,27 @@ def test_fused_stem_pool_kitti_size_both_paths_agree():
     ref = F.max_pool2d(F.relu(F.conv2d(x[:1].cpu(), w.cpu(), b.cpu(), stride=2, padding=1)), 3, 2, ceil_mode=True)
     assert (y_inf[:1].cpu() - _nhwc(ref)).abs().max().item() <= _tol(ref)
     assert int(am.max()) <= 8
+
+
+@pytest.mark.parametrize("C,E,H,W", [(16, 64, 40, 70), (32, 128, 24, 78), (48, 192, 13, 29), (96, 384, 24, 78), (64, 256, 9, 17)])
+def test_fused_fire_expand_equals_separate_kernels(C, E, H, W):
+    """fire_expand (one launch) == expand1x1 + expand3x3 launches, bit for bit, for every usable tile configuration."""
+    ops = _ops()
+    x = F.relu(_rand(2, C, H, W, seed=41)).cuda()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    w1 = _rand(E, C, 1, 1, seed=42, scale=(2.0 / C) ** 0.5).cuda(); b1 = _rand(E, seed=43, scale=0.1).cuda()
+    w3 = _rand(E, C, 3, 3, seed=44, scale=(2.0 / (9 * C)) ** 0.5).cuda(); b3 = _rand(E, seed=45, scale=0.1).cuda()
+    npix = 2 * H * W
+    ref = torch.empty(2, H, W, 2 * E + 8, device='cuda').fill_(7.0)          # wider pitch + channel offset 4: window writes
+    ops.conv(xn, 0, ops.ConvPlan(w1, b1, ops.choose_cfg(1, C, E, npix)), ref, 4, relu=True)
+    ops.conv(xn, 0, ops.ConvPlan(w3, b3, ops.choose_cfg(9, C, E, npix)), ref, 4 + E, relu=True)
+    want = torch.cat([F.relu(F.conv2d(x.cpu(), w1.cpu(), b1.cpu())), F.relu(F.conv2d(x.cpu(), w3.cpu(), b3.cpu(), padding=1))], 1)
+    assert (ref[..., 4:4 + 2 * E].cpu() - _nhwc(want)).abs().max().item() <= _tol(want)
+    cfgs = ops.fused_expand_cfgs(E)
+    assert cfgs
+    for cid in cfgs + [cfgs[0] + 2000]:
+        out = torch.empty_like(ref).fill_(7.0)
+        ops.fire_expand(xn, 0, ops.FusedExpandPlan(w1, b1, w3, b3, cid), out, 4)
+        assert torch.equal(out, ref), f'cfg {cid}'
+    with pytest.raises(ValueError):
+        ops.FusedExpandPlan(w1, b1, w3, b3, ops.choose_cfg(1, C, E, npix))

@@ -56,6 +56,38 @@ def time_cfg(taps, C, N, B, h, w, cid, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3      # us
 
 
+def fused_shapes(arch, B, H, W):
+    """[(C, E, h, w)] of every Fire expand pair (inference forward, fused launch)."""
+    out = set()
+    layers = layer_table(arch)
+    h, w = ops.stem_out_size(H, W, layers[0][3])
+    for l in layers[2:]:
+        if l[0] == 'pool':
+            h, w = ops.pool_out_size(h, w)
+            continue
+        _, cin, s, e1, e3 = l
+        if e1 == e3 and e1 % 16 == 0:
+            out.add((s, e1, h, w))
+    return sorted(out)
+
+
+def time_fused(C, E, B, h, w, cid, reps=10):
+    w1 = torch.randn(E, C, 1, 1, device='cuda') * 0.05; b1 = torch.randn(E, device='cuda')
+    w3 = torch.randn(E, C, 3, 3, device='cuda') * 0.05; b3 = torch.randn(E, device='cuda')
+    plan = ops.FusedExpandPlan(w1, b1, w3, b3, cid)
+    x = torch.randn(B, h, w, C, device='cuda')
+    y = torch.empty(B, h, w, 2 * E, device='cuda')
+    for _ in range(2):
+        ops.fire_expand(x, 0, plan, y, 0)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.fire_expand(x, 0, plan, y, 0)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--arch', default='squeezedet')
@@ -96,6 +128,26 @@ def main():
                       'all': {str(c): round(u, 1) for u, c in res}}
         print(f'{key:24s} best cfg {best:4d} {tab[best % 1000]}  {best_us:8.1f} us  {gf / (best_us * 1e-6) / 1e3:6.1f} TF/s   '
               + ' '.join(f'{c}:{u:.0f}' for u, c in res[:5]), flush=True)
+    # fused Fire expand (key F:C:E:npix): compared with the sum of the two separate launches of the same layer
+    for C, E, h, w in fused_shapes(args.arch, B, *args.size):
+        res = []
+        for cid in ops.fused_expand_cfgs(E):
+            for cap in (0, 2, 3):
+                try:
+                    res.append((time_fused(C, E, B, h, w, cid + 1000 * cap), cid + 1000 * cap))
+                except Exception as e:  # noqa: BLE001
+                    print('skip fused', (C, E, h, w), cid, e)
+        if not res:
+            continue
+        res.sort()
+        best_us, best = res[0]
+        npix = B * h * w
+        sep = table.get(f'1:{C}:{E}:{npix}', {}).get('us', 0) + table.get(f'9:{C}:{E}:{npix}', {}).get('us', 0)
+        gf = 2.0 * npix * E * C * 10 / 1e9
+        table[f'F:{C}:{E}:{npix}'] = {'cfg': best, 'us': round(best_us, 1), 'tflops': round(gf / (best_us * 1e-6) / 1e3, 1),
+                                     'separate_us': round(sep, 1), 'all': {str(c): round(u, 1) for u, c in res}}
+        print(f'F:{C}:{E}:{npix:<14d} best cfg {best:4d} {tab[best % 1000]}  {best_us:8.1f} us  {gf / (best_us * 1e-6) / 1e3:6.1f} TF/s  (separate {sep:.1f} us)  '
+              + ' '.join(f'{c}:{u:.0f}' for u, c in res[:6]), flush=True)
     json.dump(table, open(args.out, 'w'), indent=1, sort_keys=True)
     print('wrote', args.out)
 
