@@ -366,17 +366,35 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     }
     return tp;
   };
-  auto dma_act_one = [&](int it, const TilePos tp, int cc, int buf) {
-    const float* base = tp.xorg + cc * KC;                                // uniform
-    const float* src = base + a_off[it];
-    const int fast = tp.inner & (int)((unsigned)((cc + 1) * KC - a.C - 1) >> 31);   // uniform: interior tile, full chunk
-    if (!fast) {
-      asm volatile("" ::: "memory");                                      // keep this a real (scalar) branch: no if-conversion
+  // Border tiles: which of this lane's slots point at existing pixels depends on the tile only, not on the K chunk, so it
+  // is evaluated ONCE per tile into wave-wide lane masks (SGPR pairs) and every chunk's DMA just selects between the
+  // source and the zero page with them (2 VALU per DMA instead of ~10; ConvDet walks 48 chunks per tile).
+  const int has_partial = (a.C % KC) != 0;
+  auto pix_masks = [&](const TilePos tp, unsigned long long (&m)[A_IT]) {
+    if (tp.inner && !has_partial) return;                                 // uniform: never consulted
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
       const int key = a_key[it];
-      bool ok = key >= 0 && cc * KC + 4 * (key >> 16) < a.C;
+      bool ok = key >= 0;
       if (TAPS == 9) ok = ok && (unsigned)(tp.y0 + ((key >> 8) & 255) - 1) < (unsigned)a.H && (unsigned)(tp.x0 + (key & 255) - 1) < (unsigned)a.W;
       else ok = ok && tp.p0 + (key & 0xffff) < a.total_px;
-      src = ok ? src : sqd_zero_page;
+      m[it] = __builtin_amdgcn_ballot_w64(ok);
+    }
+  };
+  const unsigned long long zp = (unsigned long long)(const void*)sqd_zero_page;
+  const unsigned zp_lo = (unsigned)zp, zp_hi = (unsigned)(zp >> 32);
+  auto dma_act_one = [&](int it, const TilePos tp, unsigned long long okmask, int cc, int buf) {
+    const float* base = tp.xorg + cc * KC;                                // uniform
+    const float* src = base + a_off[it];
+    const int full = (int)((unsigned)((cc + 1) * KC - a.C - 1) >> 31);    // uniform: chunk entirely inside C
+    if (!(tp.inner & full)) {
+      asm volatile("" ::: "memory");                                      // keep this a real (scalar) branch: no if-conversion
+      unsigned long long m = okmask;
+      if (!full) m &= __builtin_amdgcn_ballot_w64(cc * KC + 4 * (a_key[it] >> 16) < a.C);
+      const unsigned long long p = (unsigned long long)(const void*)src;
+      unsigned lo = (unsigned)p, hi = (unsigned)(p >> 32);
+      asm volatile("v_cndmask_b32 %0, %2, %0, %4\n\tv_cndmask_b32 %1, %3, %1, %4" : "+v"(lo), "+v"(hi) : "v"(zp_lo), "v"(zp_hi), "s"(m));
+      src = (const float*)(const void*)(((unsigned long long)hi << 32) | lo);
     }
     __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(actB + (buf * ASLOTS + it * NTHR + wm_s * 64) * 4), 16, 0, 0);
   };
@@ -407,9 +425,13 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   const float relu_lo = a.relu ? 0.f : -__builtin_inff();             // branch-free ReLU switch (one v_max per element)
 
   TilePos cur = tile_pos(tile);
+  unsigned long long okc[A_IT], okn[A_IT];                                // slot validity masks of the current / next tile
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) { okc[it] = 0; okn[it] = 0; }
+  pix_masks(cur, okc);
   // prologue: stage 0 into buffer 0
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) dma_act_one(it, cur, 0, 0);
+  for (int it = 0; it < A_IT; ++it) dma_act_one(it, cur, okc[it], 0, 0);
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) dma_w_one(it, 0, 0);
   int sbuf = 0, wbuf = 0;              // buffers holding the stage about to be computed
@@ -478,6 +500,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);     // tile + tstride < ntiles
     const bool more = more_i != 0;
     const TilePos nxt = tile_pos(more ? tile + tstride : tile);
+    if (more) pix_masks(nxt, okn);
     for (int cc = 0; cc < nchunks; ++cc) {
       __syncthreads();                 // vmcnt(0): this stage's DMA has landed; all waves left the previous stage
       if (pending) { flush(ptp); pending = false; }
@@ -503,7 +526,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
           for (int q = 0; q < A_IT + W_IT; ++q) {
             if (q * STEPS / (A_IT + W_IT) != step) continue;
-            if (q < A_IT) { if (has_next) dma_act_one(q, ntp, ncc, sbuf ^ 1); }
+            if (q < A_IT) { if (has_next) dma_act_one(q, ntp, last ? okn[q < A_IT ? q : 0] : okc[q < A_IT ? q : 0], ncc, sbuf ^ 1); }
             else { if (next_w) dma_w_one(q - A_IT, ncc, wbuf ^ 1); }
           }
           f32x4 bf[MT], af[NT];
@@ -542,6 +565,8 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     if (!more) break;
     tile += tstride;
     cur = nxt;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) okc[it] = okn[it];
   }
   if (pending) flush(ptp);
 }
