@@ -139,18 +139,27 @@ def main():
         step()
     torch.cuda.synchronize()
     graph = None
-    if args.mode == 'infer' and not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()                                   # allocations of the capture stream's pool
+    # inference: always a hipGraph of the step.  training: the whole step (fwd, loss, bwd, clip, SGD, weight re-pack) is
+    # captured too on one GPU; with an RCCL all-reduce in the step (world > 1) it stays eager
+    if not args.no_graph and (args.mode == 'infer' or world == 1):
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                   # allocations of the capture stream's pool
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph.replay(); graph.replay()
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph.replay(); graph.replay()
-        torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            if args.mode == 'infer':
+                raise
+            print(f'[bench] training step not captured ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
     run = graph.replay if graph is not None else step
 
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----

@@ -180,6 +180,9 @@ class ConvPlan:
         self.bias = None if (bias is None or dgrad) else bias.detach().contiguous()
 
 
+_PACK_TABLES = {}
+
+
 def repack_batched(plans_and_weights, is_dgrad):
     """Refresh many packed weight copies with ONE kernel launch.  plans_and_weights: [(ConvPlan, weight)],
     is_dgrad: parallel list of bools."""
@@ -192,7 +195,15 @@ def repack_batched(plans_and_weights, is_dgrad):
         rows.append([w.data_ptr(), plan.w.data_ptr(), w.shape[0], w.shape[1], plan.taps, plan.kc, plan.Npad, plan.w.shape[0],
                      int(dg), plan.w.numel()])
     dev = plans_and_weights[0][1].device
-    table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
+    # the descriptor table only holds pointers and shapes: after the first optimizer step it is the same every step, so the
+    # device copy is cached (no host-to-device copy per step; also what makes the training step hipGraph-capturable)
+    key = (str(dev), tuple(tuple(r) for r in rows))
+    table = _PACK_TABLES.get(key)
+    if table is None:
+        if len(_PACK_TABLES) > 16:
+            _PACK_TABLES.clear()
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _PACK_TABLES[key] = table
     rc = nat.lib().sqd_pack_conv_weights_batched(nat.ptr(table), len(rows), 16, nat.stream_handle(dev))
     nat.check(rc, 'sqd_pack_conv_weights_batched')
     return table
