@@ -1,0 +1,75 @@
+"""Randomised parity sweep of sqd_conv_fwd / sqd_fire_expand_fwd / sqd_conv_wgrad against torch (CPU fp32):
+every compiled tile configuration x random shapes (tiny maps, widths off the 16-pixel grid, partial K chunks,
+channel windows inside wider buffers), with the epilogue options the backward uses.  usage: fuzz_conv.py [seconds]"""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np, torch, torch.nn.functional as F
+from squeezedet_pytorch_amd import ops
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+tab = ops.cfg_table()
+t0 = time.time(); n_ok = 0; worst = 0.0
+def nhwc(t): return t.permute(0, 2, 3, 1).contiguous()
+while time.time() - t0 < budget:
+    cid = int(rs.choice(list(tab)))
+    taps, kc, px, bn = tab[cid]
+    B = int(rs.randint(1, 4)); H = int(rs.choice([1, 2, 3, 5, 8, 9, 16, 17, 24, 31])); W = int(rs.choice([1, 3, 7, 15, 16, 17, 33, 47, 78]))
+    C = int(rs.choice([4, 8, 12, 16, 20, 32, 40, 48, 64, 96])); N = int(rs.choice([4, 8, 16, 24, 32, 48, 64, 72, 80, 96]))
+    k = 3 if taps == 9 else 1
+    x = torch.randn(B, C, H, W); w = torch.randn(N, C, k, k) * (1.0 / (C * taps)) ** 0.5; b = torch.randn(N) * 0.1
+    xp, xo = C + 4 * int(rs.randint(0, 3)), 0
+    xo = 4 * int(rs.randint(0, (xp - C) // 4 + 1))
+    yp = N + 4 * int(rs.randint(0, 3)); yo = 4 * int(rs.randint(0, (yp - N) // 4 + 1))
+    xb = torch.randn(B, H, W, xp); xb[..., xo:xo + C] = nhwc(x)
+    mode = int(rs.randint(0, 4))
+    relu = bool(rs.randint(0, 2))
+    ref = F.conv2d(x, w, b, padding=k // 2)
+    y0 = torch.randn(B, H, W, yp)
+    yb = y0.clone().cuda()
+    kw = {}
+    refn = nhwc(ref)
+    dma = ops.cfg_is_dma(cid)
+    if mode == 1:                      # accumulate
+        kw['accumulate'] = True; refn = refn + y0[..., yo:yo + N]
+    if mode == 2:                      # ReLU-backward mask with the output's geometry
+        m = torch.randn(B, H, W, yp); kw['ymask'] = m.cuda(); kw['ymask_coff'] = yo
+        refn = torch.where(m[..., yo:yo + N] > 0, refn, torch.zeros(()))
+    if mode == 3:                      # dropout scale with a different geometry (slow epilogue path)
+        m = torch.rand(B, H, W, N + 4); kw['ymul'] = m.cuda(); kw['ymul_coff'] = 4
+        refn = refn * m[..., 4:4 + N]
+    if relu: refn = torch.relu(refn)
+    cap = int(rs.choice([0, 0, 1, 2]))
+    plan = ops.ConvPlan(w.cuda(), b.cuda(), cid + 1000 * cap)
+    ops.conv(xb.cuda(), xo, plan, yb, yo, relu=relu, **kw)
+    out = yb.cpu()
+    err = (out[..., yo:yo + N] - refn).abs().max().item()
+    tol = 2e-5 * max(1.0, refn.abs().max().item()) + 1e-5
+    untouched = torch.equal(out[..., :yo], y0[..., :yo]) and torch.equal(out[..., yo + N:], y0[..., yo + N:])
+    if not (err <= tol and untouched):
+        print('MISMATCH', dict(cid=cid, cfg=tab[cid], dma=dma, B=B, H=H, W=W, C=C, N=N, xp=xp, xo=xo, yp=yp, yo=yo, mode=mode, relu=relu, cap=cap, err=err, tol=tol, untouched=untouched))
+        sys.exit(1)
+    worst = max(worst, err / tol); n_ok += 1
+    # fused expand on the same input when the shape allows
+    if taps == 9 and N % 16 == 0 and (cid in ops.fused_expand_cfgs(N)):
+        w1 = torch.randn(N, C, 1, 1) * (1.0 / C) ** 0.5; b1 = torch.randn(N) * 0.1
+        want = torch.cat([torch.relu(F.conv2d(x, w1, b1)), torch.relu(ref)], 1)
+        yf = torch.randn(B, H, W, 2 * N + 8).cuda(); keep = yf.clone()
+        ops.fire_expand(xb.cuda(), xo, ops.FusedExpandPlan(w1.cuda(), b1.cuda(), w.cuda(), b.cuda(), cid), yf, 4)
+        e2 = (yf[..., 4:4 + 2 * N].cpu() - nhwc(want)).abs().max().item()
+        if not (e2 <= tol and torch.equal(yf[..., :4], keep[..., :4]) and torch.equal(yf[..., 4 + 2 * N:], keep[..., 4 + 2 * N:])):
+            print('FUSED MISMATCH', dict(cid=cid, B=B, H=H, W=W, C=C, E=N, err=e2, tol=tol)); sys.exit(1)
+        n_ok += 1
+    # weight gradient of the same layer
+    if rs.rand() < 0.3:
+        dy = torch.randn(B, N, H, W)
+        xg = x.clone().requires_grad_(True); wg = w.clone().requires_grad_(True); bg = b.clone().requires_grad_(True)
+        F.conv2d(xg, wg, bg, padding=k // 2).backward(dy)
+        dyb = torch.randn(B, H, W, yp); dyb[..., yo:yo + N] = nhwc(dy)
+        dw, db = ops.conv_wgrad(dyb.cuda(), yo, N, xb.cuda(), xo, C, taps)
+        sc = max(1.0, wg.grad.abs().max().item())
+        e3 = (dw.cpu() - wg.grad).abs().max().item(); e4 = (db.cpu() - bg.grad).abs().max().item()
+        if not (e3 <= 1e-4 * sc and e4 <= 1e-4 * max(1.0, bg.grad.abs().max().item())):
+            print('WGRAD MISMATCH', dict(taps=taps, B=B, H=H, W=W, C=C, N=N, e3=e3, e4=e4, sc=sc)); sys.exit(1)
+        n_ok += 1
+print(f'fuzz ok: {n_ok} cases in {time.time() - t0:.0f} s, worst err/tol {worst:.2f}')
