@@ -208,3 +208,36 @@ def test_prediction_resolver_five_outputs_vs_golden(golden_dir):
     np.testing.assert_allclose(boxes.cpu().numpy()[:, sel], g["boxes"], atol=1e-3, rtol=0)
     assert torch.equal(deltas.cpu(), pred[..., 4:])
     assert PredictionResolver(cfg, log_softmax=False)(pred.cuda())[1] is None
+
+
+def test_eval_flow_images_to_ap(tmp_path):
+    """The reference's eval flow end to end on the device path: raw uint8 images -> Detector.detect_images (GPU
+    pre-processing, backbone, fused NMS) -> results.save_results (KITTI text files) -> results.evaluate (native AP).
+    Ground truth = the detections themselves, so every evaluated class must come out with AP 1 (n_gt permitting)."""
+    import os
+    from squeezedet_pytorch_amd import results as R
+    from squeezedet_pytorch_amd.detector import Detector
+    from squeezedet_pytorch_amd.model import SqueezeDet
+    cfg = sqd.make_cfg(arch='squeezedet', device='cuda')
+    m = SqueezeDet(cfg); m.load_state_dict(synthetic.make_state_dict('squeezedet', seed=1234))
+    det = Detector(m, cfg)
+    rs = np.random.RandomState(3)
+    n = 6
+    imgs = [rs.randint(0, 256, (375, 1242, 3), dtype=np.uint8) for _ in range(n)]
+    ids = ['%06d' % i for i in range(n)]
+    res = det.detect_images(imgs, image_ids=ids)
+    assert len(res) == n and all(r['image_meta']['image_id'] == i for r, i in zip(res, ids))
+    assert sum(len(r.get('class_ids', [])) for r in res) > 0
+    R.save_results(res, str(tmp_path / 'results'))
+    lab = tmp_path / 'training' / 'label_2'
+    os.makedirs(lab)
+    for r, i in zip(res, ids):
+        with open(lab / (i + '.txt'), 'w') as f:
+            for c, b in zip(r.get('class_ids', []), r.get('boxes', [])):
+                # label = the detection as written to the results file (2 decimals), tall enough for every difficulty
+                f.write('{} 0.00 0 0.00 {:.2f} {:.2f} {:.2f} {:.2f} 1.5 1.6 3.9 1.0 1.5 20.0 0.1\n'.format(R.KITTI_CLASS_NAMES[int(c)], *[float(v) for v in b]))
+    with open(tmp_path / 'set.txt', 'w') as f:
+        f.write('\n'.join(ids) + '\n')
+    aps = R.evaluate(str(tmp_path / 'results'), str(lab), str(tmp_path / 'set.txt'))
+    assert set(aps) == {f'{c}_{d}' for c in R.KITTI_CLASS_NAMES for d in ('easy', 'moderate', 'hard')} | {'mAP'}
+    assert all(0.0 <= v <= 1.0 for v in aps.values()) and aps['mAP'] > 0.0
