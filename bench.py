@@ -223,7 +223,7 @@ def main():
                        'gbs': round(v['bytes'] / (v['ms'] / 1e3) / 1e9, 1) if v['ms'] > 0 else 0}
                    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
         cpu = None
-        if not args.no_cpu_baseline and args.mode == 'infer':
+        if not args.no_cpu_baseline and args.mode == 'infer' and world == 1:      # rank 0 at N = 1 only (bounded sample)
             cpu = cpu_baseline(cfg, sd, B)
         line = {
             'metric': f'images/sec {"SqueezeDet" if args.arch == "squeezedet" else "SqueezeDet+"} 1248x384 bs={B} ' + ('inference' if args.mode == 'infer' else 'training'),
