@@ -280,8 +280,10 @@ __device__ __forceinline__ f32x4 sqd_relu4(f32x4 v, float lo) {      // lo (wave
 // 1x1 groups simply skip the MFMAs (and operand reads) of the 8 outer taps, and the epilogue writes group 2i to
 // channel window [0, E) and group 2i+1 to [E, 2E) of the output -- the concat.  One launch, one staging of the
 // squeeze tile, and the 1x1 outputs' stores drain under the 3x3's matrix work.
-template <int TAPS, int KC, int MT, int NT, int WM, int MINW, bool FUSE>
+template <int TAPS, int KC, int MT, int NT, int WM, int MINW, bool FUSE, bool WSTAT>
 __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
+  // WSTAT: the whole K fits one chunk (C <= KC), the weight slice is loaded once and stays in LDS (launch-time property
+  // made a template flag so that the tap loop below contains no branch at all)
   static_assert(!FUSE || (TAPS == 9 && (NT % 2) == 0), "fused expand: 3x3 tiles with an even number of channel groups");
   constexpr int NTHR = WM * 64;              // 4 or 8 waves; with 8, two waves per SIMD share one staged tile
   constexpr int TH = MT * WM;
@@ -308,8 +310,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   const int n0 = (wgq % a.nslices) * BN;
   const int tstride = a.gx;
   const int nchunks = (a.C + KC - 1) / KC;
-  const bool w_stationary = (nchunks == 1);
-  const int w_stat_i = (int)((unsigned)(nchunks - 2) >> 31);              // nchunks == 1 (nchunks >= 1)
+  constexpr bool w_stationary = WSTAT;
   const int ntiles = a.ntiles;
   int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
   if (tile >= ntiles) return;
@@ -371,7 +372,11 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   // source and the zero page with them (2 VALU per DMA instead of ~10; ConvDet walks 48 chunks per tile).
   const int has_partial = (a.C % KC) != 0;
   auto pix_masks = [&](const TilePos tp, unsigned long long (&m)[A_IT]) {
-    if (tp.inner && !has_partial) return;                                 // uniform: never consulted
+    if (tp.inner) {                                                       // uniform: every real slot exists (padding slots fetch the origin)
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) m[it] = ~0ull;
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int key = a_key[it];
@@ -383,20 +388,25 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   };
   const unsigned long long zp = (unsigned long long)(const void*)sqd_zero_page;
   const unsigned zp_lo = (unsigned)zp, zp_hi = (unsigned)(zp >> 32);
+  // Straight-line DMA issue (no branch: the tap loop must stay ONE basic block so the compiler can hoist the next
+  // tap's LDS reads above this tap's MFMAs): source = uniform base + lane offset, replaced by the zero page where the
+  // stage's lane mask says the slot does not exist (2 v_cndmask with an SGPR-pair mask).
   auto dma_act_one = [&](int it, const TilePos tp, unsigned long long okmask, int cc, int buf) {
-    const float* base = tp.xorg + cc * KC;                                // uniform
-    const float* src = base + a_off[it];
-    const int full = (int)((unsigned)((cc + 1) * KC - a.C - 1) >> 31);    // uniform: chunk entirely inside C
-    if (!(tp.inner & full)) {
-      asm volatile("" ::: "memory");                                      // keep this a real (scalar) branch: no if-conversion
-      unsigned long long m = okmask;
-      if (!full) m &= __builtin_amdgcn_ballot_w64(cc * KC + 4 * (a_key[it] >> 16) < a.C);
-      const unsigned long long p = (unsigned long long)(const void*)src;
-      unsigned lo = (unsigned)p, hi = (unsigned)(p >> 32);
-      asm volatile("v_cndmask_b32 %0, %2, %0, %4\n\tv_cndmask_b32 %1, %3, %1, %4" : "+v"(lo), "+v"(hi) : "v"(zp_lo), "v"(zp_hi), "s"(m));
-      src = (const float*)(const void*)(((unsigned long long)hi << 32) | lo);
-    }
+    const float* src = tp.xorg + cc * KC + a_off[it];
+    const unsigned long long p = (unsigned long long)(const void*)src;
+    unsigned lo = (unsigned)p, hi = (unsigned)(p >> 32);
+    asm volatile("v_cndmask_b32 %0, %2, %0, %4\n\tv_cndmask_b32 %1, %3, %1, %4" : "+v"(lo), "+v"(hi) : "v"(zp_lo), "v"(zp_hi), "s"(okmask));
+    src = (const float*)(const void*)(((unsigned long long)hi << 32) | lo);
     __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(actB + (buf * ASLOTS + it * NTHR + wm_s * 64) * 4), 16, 0, 0);
+  };
+  // lane masks of one stage's activation slots: the tile's pixel masks, minus channels beyond C in a partial last chunk
+  auto stage_masks = [&](const unsigned long long (&pm)[A_IT], int cc, unsigned long long (&m)[A_IT]) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) m[it] = pm[it];
+    if (has_partial && (cc + 1) * KC > a.C) {                             // uniform, outside the tap loop
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) m[it] &= __builtin_amdgcn_ballot_w64(a_key[it] >= 0 && cc * KC + 4 * (a_key[it] >> 16) < a.C);
+    }
   };
   auto dma_w_one = [&](int it, int cc, int buf) {
     const float* src = a.w + cc * w_chunk + w_off[it];
@@ -429,9 +439,11 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) { okc[it] = 0; okn[it] = 0; }
   pix_masks(cur, okc);
+  unsigned long long dm[A_IT];                                            // masks of the stage being fetched
+  stage_masks(okc, 0, dm);
   // prologue: stage 0 into buffer 0
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) dma_act_one(it, cur, okc[it], 0, 0);
+  for (int it = 0; it < A_IT; ++it) dma_act_one(it, cur, dm[it], 0, 0);
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) dma_w_one(it, 0, 0);
   int sbuf = 0, wbuf = 0;              // buffers holding the stage about to be computed
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);     // tile + tstride < ntiles
     const bool more = more_i != 0;
     const TilePos nxt = tile_pos(more ? tile + tstride : tile);
-    if (more) pix_masks(nxt, okn);
+    pix_masks(nxt, okn);
     for (int cc = 0; cc < nchunks; ++cc) {
       __syncthreads();                 // vmcnt(0): this stage's DMA has landed; all waves left the previous stage
       if (pending) { flush(ptp); pending = false; }
@@ -509,46 +521,69 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
       const int ncc = last ? 0 : cc + 1;
       // plain SALU integers (sign-bit arithmetic): as i1 values the compiler round-trips them through VGPRs
       const int has_next = (last_i ^ 1) | more_i;
-      const int next_w = has_next & (w_stat_i ^ 1);
       const TilePos ntp = tp_sel(last, nxt, cur);
+      // The next stage's DMA is issued unconditionally: after the very last stage it re-fetches this workgroup's last tile
+      // into the idle buffer (never read; retired by the vmcnt(0) before the kernel ends) -- cheaper than a branch per tap
+      if (last) stage_masks(okn, ncc, dm); else stage_masks(okc, ncc, dm);
+      (void)has_next;
       // per-lane LDS bases of this stage (one VALU add each per stage); every read below is base + immediate
       const float* actL = actB + sbuf * ASLOTS * 4 + (g * NPIXP + ((TAPS == 9) ? wm * MT * 18 : wm * MT * 16) + lr) * 4;
       const float* wL = wB + wbuf * WSLOTS * 4 + (g * WROWS + lr) * 4;
 
-      // ---- MFMA over (tap, k); one DMA instruction of the next stage is issued per MFMA group ----
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
+      // ---- MFMA over (tap, k), software-pipelined over two operand register sets (the loop is fully unrolled and
+      // branch-free); one DMA instruction of the next stage is issued per step ----
+      auto load_ops = [&](int step, f32x4 (&bfr)[MT], f32x4 (&afr)[NT]) {
+        const int tap = step / (KC / 16), sk = step - tap * (KC / 16);
         const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
 #pragma unroll
-        for (int s = 0; s < KC / 16; ++s) {
-          const int step = tap * (KC / 16) + s;
-          // spread A_IT + W_IT DMA instructions over STEPS groups (the first groups take the remainder)
+        for (int i = 0; i < MT; ++i) {
+          const int row = (TAPS == 9) ? (i + dy) * 18 + dx : i * 16;                 // compile-time
+          bfr[i] = *(const f32x4*)(actL + (4 * sk * NPIXP + row) * 4);
+        }
 #pragma unroll
-          for (int q = 0; q < A_IT + W_IT; ++q) {
-            if (q * STEPS / (A_IT + W_IT) != step) continue;
-            if (q < A_IT) { if (has_next) dma_act_one(q, ntp, last ? okn[q < A_IT ? q : 0] : okc[q < A_IT ? q : 0], ncc, sbuf ^ 1); }
-            else { if (next_w) dma_w_one(q - A_IT, ncc, wbuf ^ 1); }
-          }
-          f32x4 bf[MT], af[NT];
+        for (int j = 0; j < NT; ++j) {
+          if (FUSE && !(j & 1) && tap != 4) continue;                              // 1x1 group: centre tap only
+          afr[j] = *(const f32x4*)(wL + (4 * sk * WROWS + tap * BN + j * 16) * 4);
+        }
+      };
+      auto mfma_half = [&](int step, const f32x4 (&bfr)[MT], const f32x4 (&afr)[NT], int half) {
+        const int tap = step / (KC / 16);
 #pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            const int row = (TAPS == 9) ? (i + dy) * 18 + dx : i * 16;                 // compile-time
-            bf[i] = *(const f32x4*)(actL + (4 * s * NPIXP + row) * 4);
-          }
+        for (int t = 2 * half; t < 2 * half + 2; ++t)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            if (FUSE && !(j & 1) && tap != 4) continue;                              // 1x1 group: centre tap only
-            af[j] = *(const f32x4*)(wL + (4 * s * WROWS + tap * BN + j * 16) * 4);
-          }
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+            for (int j = 0; j < NT; ++j) {
+              if (FUSE && !(j & 1) && tap != 4) continue;
+              acc[i][j] = mfma16(afr[j][t], bfr[i][t], acc[i][j]);
+            }
+      };
+      f32x4 bf0[MT], af0[NT], bf1[MT], af1[NT];
+      load_ops(0, bf0, af0);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+      for (int step = 0; step < STEPS; ++step) {
+        // spread A_IT + W_IT DMA instructions over STEPS steps (the first steps take the remainder)
 #pragma unroll
-              for (int j = 0; j < NT; ++j) {
-                if (FUSE && !(j & 1) && tap != 4) continue;
-                acc[i][j] = mfma16(af[j][t], bf[i][t], acc[i][j]);
-              }
+        for (int q = 0; q < A_IT + W_IT; ++q) {
+          if (q * STEPS / (A_IT + W_IT) != step) continue;
+          if (q < A_IT) dma_act_one(q, ntp, dm[q < A_IT ? q : 0], ncc, sbuf ^ 1);
+          else if (!WSTAT) dma_w_one(q - A_IT, ncc, wbuf ^ 1);
+        }
+        // The next step's reads go out in the MIDDLE of this step's MFMAs: when the next step starts (and the compiler's
+        // wait -- always lgkmcnt(0), it does not count LDS returns past an LDS-DMA -- is reached) they were issued half a
+        // step of MFMAs ago and nothing newer is outstanding, so the wait costs nothing.
+        if (step & 1) {
+          mfma_half(step, bf1, af1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (step + 1 < STEPS) load_ops(step + 1, bf0, af0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_half(step, bf1, af1, 1);
+        } else {
+          mfma_half(step, bf0, af0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (step + 1 < STEPS) load_ops(step + 1, bf1, af1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_half(step, bf0, af0, 1);
         }
       }
 
@@ -569,6 +604,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     for (int it = 0; it < A_IT; ++it) okc[it] = okn[it];
   }
   if (pending) flush(ptp);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may still be in flight when the LDS is released
 }
 
 static int sqd_num_cus() {
@@ -636,11 +672,12 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   const int stationary = (a.C <= KC) ? 1 : 0;            // one K chunk: a single weight buffer suffices
   const size_t lds = (size_t)(2 * ASLOTS + (stationary ? 1 : 2) * WSLOTS) * 16 + BN * sizeof(float);
   // waves per SIMD the register allocator must leave room for: workgroups per CU (by LDS) x waves per SIMD of one
-  constexpr int REGW = (MT * NT <= 4) ? 4 : ((MT * NT <= 6) ? 3 : ((MT * NT <= 12) ? 2 : 1));
+  // (the software-pipelined operand sets cost (MT + NT) * 4 more VGPRs than the accumulators alone)
+  constexpr int REGW = (MT * NT <= 2) ? 4 : ((MT * NT <= 4) ? 3 : ((MT * NT <= 8) ? 2 : 1));
   constexpr int LDSW = (int)((160 * 1024) / ((size_t)(2 * ASLOTS + WSLOTS) * 16 + BN * sizeof(float))) * (WM / 4);
   constexpr int MINW0 = LDSW < REGW ? (LDSW < 1 ? 1 : LDSW) : REGW;
   constexpr int MINW = (MINW0 < WM / 4) ? WM / 4 : MINW0;
-  auto kern = conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW, FUSE>;
+  auto kern = stationary ? conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW, FUSE, true> : conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW, FUSE, false>;
   static int wgs_per_cu[2] = {0, 0};
   if (wgs_per_cu[stationary] == 0) {
     if (lds_max > 64 * 1024 &&
