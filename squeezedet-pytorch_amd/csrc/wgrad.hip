@@ -166,6 +166,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int bt = (wave + 4 * i < TN) ? wave + 4 * i : 0;
     abias[i] = kq * (RN * 4) + ((bt * 16 + lr) ^ swA);
   }
+  // SHARED path: the distinct lane-dependent parts only -- out-channel tile u of this wave, and per in-channel tile the two
+  // swizzle parities a tap's column shift can produce; everything else of an operand address is a compile-time immediate
+  int aS[NU], bS[2][TC];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) aS[u] = kq * (RN * 4) + (((wave + 4 * u) * 16 + lr) ^ swA);
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int ct = 0; ct < TC; ++ct) bS[par][ct] = kq * (RC * 4) + ((ct * 16 + lr) ^ (SWC ? (((kq + par) & 1) << 4) : 0));
 
   int pb = blockIdx.x, buf = 0;
   if (pb < a.nblocks) dma_block(pb, 0);
@@ -175,29 +184,65 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     if (nxt < a.nblocks) dma_block(nxt, buf ^ 1);
     const float* dyT = dyB + buf * DSLOTS * 4;
     const float* xT = xB + buf * XSLOTS * 4;
+    if (SHARED) {
+      // k-step loop, branch-free and software-pipelined over two operand sets: the reads of step s+1 are issued in the
+      // middle of step s's MFMAs (the compiler's wait in front of step s+1 is then free), LDS addresses are per-lane
+      // bases + compile-time immediates (tap shifts folded into the immediate), the bias tile always rides along
+      // (one extra MFMA per step; stored only by the workgroups that own it) so no branch splits the schedule.
+      constexpr int NB = TC * TAPS, STEPS = TH * 4, HALF = (NB + 1) / 2;
+      auto load_step = [&](int st, float (&av)[NU], float (&bv)[NB], float (&ab)[BACC]) {
+        const int r = st >> 2, cq = st & 3;
+        const int immA = (r * 16 + cq * 4) * (RN * 4);
+        const int immB = ((TAPS == 9) ? (r * 18 + cq * 4) : (r * 16 + cq * 4)) * (RC * 4);
 #pragma unroll
-    for (int s = 0; s < TH * 4; ++s) {
-      constexpr int dummy = 0; (void)dummy;
-      const int r = s >> 2, cq = s & 3;
-      const int immA = (r * 16 + cq * 4) * (RN * 4);           // compile-time after unrolling
-      const int immB = ((TAPS == 9) ? (r * 18 + cq * 4) : (r * 16 + cq * 4)) * (RC * 4);
-      if (SHARED) {
-        float av[NU];
+        for (int u = 0; u < NU; ++u) av[u] = dyT[aS[u] + immA];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) av[u] = dyT[al[u * TC * TAPS] + immA];
-#pragma unroll
-        for (int j = 0; j < TC * TAPS; ++j) {
-          const float bv = xT[bl[j] + immB];
-#pragma unroll
-          for (int u = 0; u < NU; ++u) acc[u * TC * TAPS + j] = mfma16(av[u], bv, acc[u * TC * TAPS + j]);
+        for (int j = 0; j < NB; ++j) {
+          const int tap = j / TC, ct = j - tap * TC;
+          const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+          bv[j] = xT[bS[dx & 1][ct] + immB + (dy * 18 + dx) * (RC * 4)];
         }
-      } else {
+#pragma unroll
+        for (int i = 0; i < BACC; ++i) ab[i] = dyT[abias[i] + immA];
+      };
+      auto mfma_part = [&](const float (&av)[NU], const float (&bv)[NB], const float (&ab)[BACC], int part) {
+#pragma unroll
+        for (int j = part * HALF; j < (part ? NB : HALF); ++j)
+#pragma unroll
+          for (int u = 0; u < NU; ++u) acc[u * NB + j] = mfma16(av[u], bv[j], acc[u * NB + j]);
+        if (part) {
+#pragma unroll
+          for (int i = 0; i < BACC; ++i) bacc[i] = mfma16(ab[i], 1.0f, bacc[i]);
+        }
+      };
+      float av0[NU], bv0[NB], ab0[BACC], av1[NU], bv1[NB], ab1[BACC];
+      load_step(0, av0, bv0, ab0);
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        if (st & 1) {
+          mfma_part(av1, bv1, ab1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < STEPS) load_step(st + 1, av0, bv0, ab0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_part(av1, bv1, ab1, 1);
+        } else {
+          mfma_part(av0, bv0, ab0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < STEPS) load_step(st + 1, av1, bv1, ab1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_part(av0, bv0, ab0, 1);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < TH * 4; ++s) {
+        const int r = s >> 2, cq = s & 3;
+        const int immA = (r * 16 + cq * 4) * (RN * 4);           // compile-time after unrolling
+        const int immB = ((TAPS == 9) ? (r * 18 + cq * 4) : (r * 16 + cq * 4)) * (RC * 4);
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = mfma16(dyT[al[i] + immA], xT[bl[i] + immB], acc[i]);
-      }
-      if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < BACC; ++i) bacc[i] = mfma16(dyT[abias[i] + immA], 1.0f, bacc[i]);
+        for (int i = 0; i < BACC; ++i) bacc[i] = mfma16(dyT[abias[i] + immA], 1.0f, bacc[i]);   // always (stored by cg == 0 only)
       }
     }
     buf ^= 1;
