@@ -341,8 +341,12 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : 1) void stem_po
       for (int j = 0; j < NT; ++j) {
         const int n = j * 16 + 4 * g;
         f32x4 v = acc[i][j] + *(const f32x4*)(biasL + n);
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // ReLU as ONE v_max per element (fmaxf costs a canonicalising max in front; every VALU op delays the MFMAs)
+        asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
+                     : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        if (!conv_inner) {                                            // uniform: only border tiles mask per lane
+          if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         *(f32x4*)(convT + p * CP + n) = v;
       }
     }
