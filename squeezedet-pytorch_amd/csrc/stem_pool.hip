@@ -465,39 +465,41 @@ extern "C" int sqd_stem_conv_relu_pool_fwd(const float* x, const float* w, const
 // maximum in row-major window order, as PyTorch's CPU kernel scans it) is optionally recorded
 // for the backward pass.
 // ---------------------------------------------------------------------------------------------
+template <bool ARGMAX>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ amax, int B, int H, int W, int C,
                                                           int Ho, int Wo) {
+  // one thread = one output pixel x 4 channels; blockIdx.y = (b, oy) so no 64-bit divisions per element
   const int cv = C >> 2;
-  const long long total = (long long)B * Ho * Wo * cv;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % cv); long long p = idx / cv;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho); const int b = (int)(p / Ho);
-    f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int ax = 0, ay = 0, az = 0, aw = 0;
+  const int t = blockIdx.x * 256 + threadIdx.x;            // index inside the output row: ox * cv + c4
+  if (t >= Wo * cv) return;
+  const int ox = t / cv, c4 = t - ox * cv;
+  const int oy = blockIdx.y % Ho, b = blockIdx.y / Ho;
+  const float* row = x + ((long long)b * H + 2 * oy) * W * C + (long long)(2 * ox) * C + 4 * c4;
+  const int ny = (2 * oy + 3 <= H) ? 3 : H - 2 * oy, nx = (2 * ox + 3 <= W) ? 3 : W - 2 * ox;   // clipped windows (ceil mode)
+  f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int ax = 0, ay = 0, az = 0, aw = 0;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int iy = 2 * oy + dy;
-      if (iy >= H) break;
+  for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int ix = 2 * ox + dx;
-        if (ix >= W) break;
-        const f32x4 v = *(const f32x4*)(x + (((long long)b * H + iy) * W + ix) * C + 4 * c4);
-        const int t = dy * 3 + dx;
+    for (int dx = 0; dx < 3; ++dx) {
+      if (dy >= ny || dx >= nx) continue;                            // clipped part of a border window
+      const f32x4 v = *(const f32x4*)(row + ((long long)dy * W + dx) * C);
+      if (ARGMAX) {
+        const int tt = dy * 3 + dx;
         // NaN propagates like PyTorch: (v > m) || isnan(v)
-        if (v.x > m.x || v.x != v.x) { m.x = v.x; ax = t; }
-        if (v.y > m.y || v.y != v.y) { m.y = v.y; ay = t; }
-        if (v.z > m.z || v.z != v.z) { m.z = v.z; az = t; }
-        if (v.w > m.w || v.w != v.w) { m.w = v.w; aw = t; }
+        if (v.x > m.x || v.x != v.x) { m.x = v.x; ax = tt; }
+        if (v.y > m.y || v.y != v.y) { m.y = v.y; ay = tt; }
+        if (v.z > m.z || v.z != v.z) { m.z = v.z; az = tt; }
+        if (v.w > m.w || v.w != v.w) { m.w = v.w; aw = tt; }
+      } else {
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + 4 * c4;
-    *(f32x4*)(y + o) = m;
-    if (amax) *(uint32_t*)(amax + o) = (uint32_t)ax | ((uint32_t)ay << 8) | ((uint32_t)az << 16) | ((uint32_t)aw << 24);
   }
+  const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + 4 * c4;
+  *(f32x4*)(y + o) = m;
+  if (ARGMAX) *(uint32_t*)(amax + o) = (uint32_t)ax | ((uint32_t)ay << 8) | ((uint32_t)az << 16) | ((uint32_t)aw << 24);
 }
 
 extern "C" int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char* argmax, int B, int H, int W,
@@ -505,9 +507,10 @@ extern "C" int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char
   SQD_CHECK_ARG(x && y && B > 0 && H >= 3 && W >= 3 && C > 0 && (C & 3) == 0);
   SQD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)argmax & 3) == 0);
   const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
-  const long long total = (long long)B * Ho * Wo * (C >> 2);
-  const int blocks = (int)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
+  SQD_CHECK_ARG((long long)B * Ho <= 65535);
+  const dim3 grid((unsigned)sqd_cdiv(Wo * (C >> 2), 256), (unsigned)(B * Ho));
+  if (argmax) hipLaunchKernelGGL(maxpool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
   return sqd_launch_status();
 }
 
