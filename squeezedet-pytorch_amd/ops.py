@@ -123,11 +123,27 @@ def _tuning():
     return _TUNING
 
 
+def _nearest_tuned(prefix, npix):
+    """Measured configuration of the same (taps, C, N) layer at the pixel count closest (in ratio) to ``npix``, if the
+    table has one within a factor of 4: other batch sizes / resolutions then run the LDS-DMA tilings chosen on hardware
+    instead of the generic heuristic below."""
+    import math
+    best = None
+    for k, v in _tuning().items():
+        if k.startswith(prefix) and v is not None and v >= 0:
+            d = abs(math.log(max(int(k[len(prefix):]), 1) / max(npix, 1)))
+            if d <= math.log(4.0) and (best is None or d < best[0]):
+                best = (d, v)
+    return None if best is None else best[1] % 1000             # drop the workgroup cap: it was measured for that grid size
+
+
 def choose_cfg(taps, C, N, npix):
     """Tile configuration for a conv layer: the measured table if it has this shape, else a heuristic
     (least channel padding, 128-pixel tiles when that still yields >= 4 workgroups per CU)."""
     tab = cfg_table()
     hit = _tuning().get(f'{taps}:{C}:{N}:{npix}')
+    if hit is None:
+        hit = _nearest_tuned(f'{taps}:{C}:{N}:', npix)          # same layer at another batch size / resolution
     if hit is not None and hit % 1000 in tab and tab[hit % 1000][0] == taps:
         return hit
     want_kc = 16 if (taps == 9 or C <= 128 and C % 32 != 0 or C < 64) else 32
@@ -281,6 +297,9 @@ def choose_fused_cfg(C, E, npix):
     hit = _tuning().get(f'F:{C}:{E}:{npix}')
     if hit is not None:
         return hit if (hit >= 0 and hit % 1000 in ok) else None      # -1: measured slower than the two separate launches
+    if any(k.startswith(f'F:{C}:{E}:') for k in _tuning()):
+        near = _nearest_tuned(f'F:{C}:{E}:', npix)                   # only entries where fusing won are >= 0
+        return near if (near is not None and near in ok) else None
     tab = cfg_table()
     pref = [c for c in ok if tab[c][3] == 64 and _CFG_DMA[c] == 1 and tab[c][2] == 64]
     return (pref or ok)[0]
