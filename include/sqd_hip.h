@@ -133,6 +133,13 @@ int sqd_preprocess_u8_fwd(const unsigned char* src, const long long* offsets, co
 int sqd_fire_expand_fwd(const float* x, const float* w_packed, const float* bias, float* y, int B, int H, int W, int C,
                         int x_pitch, int x_coff, int E, int Npad, int y_pitch, int y_coff, int cfg_id, void* stream);
 
+/* Fused MaxPool2d(3, 2, ceil_mode) + Fire squeeze 1x1 + ReLU, inference forward (src/model/squeezedet.py:39,42 followed
+ * by :12,18): y[..., y_coff : y_coff+N] = ReLU(conv1x1(pool(x[..., x_coff : x_coff+C])) + bias); the pooled tensor is never
+ * materialised.  x NHWC [B][H][W][x_pitch], y NHWC [B][Ho][Wo][y_pitch]; w_packed = sqd_pack_conv_weight output for a 1x1
+ * configuration whose KC divides C with Npad = N rounded up to 16 (Npad <= 96). */
+int sqd_pool_squeeze_fwd(const float* x, const float* w_packed, const float* bias, float* y, int B, int H, int W, int C,
+                         int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, void* stream);
+
 /* On-device GT encoding: compute_deltas (src/utils/boxes.py:84-135: greedy unique
  * anchor assignment by free-anchor IoU, nearest free anchor by squared (cx,cy,w,h) distance when no free anchor
  * overlaps) + BaseDataset.prepare_annotations (src/datasets/base.py:61-76: dense gt row = mask, xyxy, deltas,

@@ -42,6 +42,7 @@ _SIGNATURES = {
     'sqd_detect_fwd': [c_p] * 9 + [c_i] * 6 + [c_f, c_f, c_p],
     'sqd_filter_fwd': [c_p] * 9 + [c_i] * 4 + [c_f, c_f, c_p],
     'sqd_preprocess_u8_fwd': [c_p] * 5 + [ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i, c_i, c_p],
+    'sqd_pool_squeeze_fwd': [c_p] * 4 + [c_i] * 10 + [c_p],
     'sqd_fire_expand_fwd': [c_p] * 4 + [c_i] * 11 + [c_p],
     'sqd_kitti_ap': [c_i] + [c_p] * 12,
     'sqd_encode_gt_fwd': [c_p] * 7 + [c_i, c_i, c_i, c_p],

@@ -48,10 +48,15 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
             saved['stem_out'] = a
     if save:
         saved['image'] = image
+    unpooled = None                            # inference: a pool whose output only feeds the next squeeze is folded into it
     for i in range(first, len(layers)):
         l = layers[i]
         if l[0] == 'pool':
             Bq, H, W, C = a.shape
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            if (not save and base.fuse_pool_squeeze and nxt is not None and nxt[0] == 'fire' and ops.pool_squeeze_ok(C, nxt[2])):
+                unpooled = a
+                continue
             am = torch.empty(Bq, *ops.pool_out_size(H, W), C, device=a.device, dtype=torch.uint8) if save else None
             y = ops.maxpool(a, argmax=am)
             if save:
@@ -60,11 +65,19 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
         else:
             _, cin, s, e1, e3 = l
             fire = feats[i]
-            Bq, H, W, C = a.shape
+            if unpooled is not None:
+                Bq, Hu, Wu, C = unpooled.shape
+                H, W = ops.pool_out_size(Hu, Wu)
+            else:
+                Bq, H, W, C = a.shape
             assert C == cin, f'layer {i}: expected {cin} channels, got {C}'
             npix = Bq * H * W
             sq = torch.empty(Bq, H, W, s, device=a.device, dtype=torch.float32)
-            ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
+            if unpooled is not None:
+                ops.pool_squeeze(unpooled, 0, cin, base.plan(f'{i}.squeeze@pool', fire.squeeze, ops.POOL_SQUEEZE_CFG), sq, 0)
+                unpooled = None
+            else:
+                ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
             out = torch.empty(Bq, H, W, e1 + e3, device=a.device, dtype=torch.float32)
             fcfg = ops.choose_fused_cfg(s, e1, npix) if (not save and base.fuse_expand and e1 == e3) else None
             if fcfg is not None:

@@ -469,37 +469,55 @@ template <bool ARGMAX>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ amax, int B, int H, int W, int C,
                                                           int Ho, int Wo) {
-  // one thread = one output pixel x 4 channels; blockIdx.y = (b, oy) so no 64-bit divisions per element
-  const int cv = C >> 2;
-  const int t = blockIdx.x * 256 + threadIdx.x;            // index inside the output row: ox * cv + c4
-  if (t >= Wo * cv) return;
-  const int ox = t / cv, c4 = t - ox * cv;
+  // One thread = TWO horizontally adjacent output pixels x 4 channels: the windows share a column, so 15 loads serve 2
+  // outputs (the kernel is bound by the L2 read amplification of the window gather, 9 loads per output otherwise).
+  // blockIdx.y = (b, oy): no 64-bit divisions per element.  Clipped border windows (ceil mode) clamp their tap offsets
+  // to the last valid row / column for the value; the argmax only ever considers in-range taps.
+  const int cv = C >> 2, Wp = (Wo + 1) >> 1;
+  const int t = blockIdx.x * 256 + threadIdx.x;            // index inside the output row: oxp * cv + c4
+  if (t >= Wp * cv) return;
+  const int oxp = t / cv, c4 = t - oxp * cv;
   const int oy = blockIdx.y % Ho, b = blockIdx.y / Ho;
-  const float* row = x + ((long long)b * H + 2 * oy) * W * C + (long long)(2 * ox) * C + 4 * c4;
-  const int ny = (2 * oy + 3 <= H) ? 3 : H - 2 * oy, nx = (2 * ox + 3 <= W) ? 3 : W - 2 * ox;   // clipped windows (ceil mode)
-  f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  int ax = 0, ay = 0, az = 0, aw = 0;
+  const int ox0 = 2 * oxp, ix0 = 4 * oxp;
+  const float* row = x + ((long long)b * H + 2 * oy) * W * C + (long long)ix0 * C + 4 * c4;
+  const int ny = (2 * oy + 3 <= H) ? 3 : H - 2 * oy;                               // rows of the (clipped) windows
+  const int ncol = (ix0 + 5 <= W) ? 5 : W - ix0;                                    // columns available to the pair
+  f32x4 v[3][5];
 #pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
+  for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      if (dy >= ny || dx >= nx) continue;                            // clipped part of a border window
-      const f32x4 v = *(const f32x4*)(row + ((long long)dy * W + dx) * C);
-      if (ARGMAX) {
-        const int tt = dy * 3 + dx;
-        // NaN propagates like PyTorch: (v > m) || isnan(v)
-        if (v.x > m.x || v.x != v.x) { m.x = v.x; ax = tt; }
-        if (v.y > m.y || v.y != v.y) { m.y = v.y; ay = tt; }
-        if (v.z > m.z || v.z != v.z) { m.z = v.z; az = tt; }
-        if (v.w > m.w || v.w != v.w) { m.w = v.w; aw = tt; }
-      } else {
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-      }
+    for (int dx = 0; dx < 5; ++dx) {
+      const int ry = dy < ny ? dy : ny - 1, cx = dx < ncol ? dx : ncol - 1;
+      v[dy][dx] = *(const f32x4*)(row + ((long long)ry * W + cx) * C);
     }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int ox = ox0 + u;
+    if (ox >= Wo) break;
+    const int nx = (2 * ox + 3 <= W) ? 3 : W - 2 * ox;
+    f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int ax = 0, ay = 0, az = 0, aw = 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (ARGMAX && (dy >= ny || dx >= nx)) continue;                              // clipped tap: not a candidate
+        const f32x4 w = v[dy][2 * u + dx];
+        if (ARGMAX) {
+          const int tt = dy * 3 + dx;
+          // NaN propagates like PyTorch: (v > m) || isnan(v)
+          if (w.x > m.x || w.x != w.x) { m.x = w.x; ax = tt; }
+          if (w.y > m.y || w.y != w.y) { m.y = w.y; ay = tt; }
+          if (w.z > m.z || w.z != w.z) { m.z = w.z; az = tt; }
+          if (w.w > m.w || w.w != w.w) { m.w = w.w; aw = tt; }
+        } else {
+          m.x = fmaxf(m.x, w.x); m.y = fmaxf(m.y, w.y); m.z = fmaxf(m.z, w.z); m.w = fmaxf(m.w, w.w);
+        }
+      }
+    const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + 4 * c4;
+    *(f32x4*)(y + o) = m;
+    if (ARGMAX) *(uint32_t*)(amax + o) = (uint32_t)ax | ((uint32_t)ay << 8) | ((uint32_t)az << 16) | ((uint32_t)aw << 24);
   }
-  const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + 4 * c4;
-  *(f32x4*)(y + o) = m;
-  if (ARGMAX) *(uint32_t*)(amax + o) = (uint32_t)ax | ((uint32_t)ay << 8) | ((uint32_t)az << 16) | ((uint32_t)aw << 24);
 }
 
 extern "C" int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char* argmax, int B, int H, int W,
@@ -508,7 +526,7 @@ extern "C" int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char
   SQD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)argmax & 3) == 0);
   const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
   SQD_CHECK_ARG((long long)B * Ho <= 65535);
-  const dim3 grid((unsigned)sqd_cdiv(Wo * (C >> 2), 256), (unsigned)(B * Ho));
+  const dim3 grid((unsigned)sqd_cdiv(((Wo + 1) / 2) * (C >> 2), 256), (unsigned)(B * Ho));
   if (argmax) hipLaunchKernelGGL(maxpool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
   else hipLaunchKernelGGL(maxpool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
   return sqd_launch_status();

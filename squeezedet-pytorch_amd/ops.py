@@ -343,6 +343,35 @@ def fire_expand(x, x_coff, fplan, y, y_coff):
     return y
 
 
+POOL_SQUEEZE_CFG = 28        # 1x1 tiling with KC = 32, 16-channel slices: its packed weights are [C/4][ceil16(N)][4]
+
+
+def pool_squeeze_ok(C, N):
+    """Whether ``pool_squeeze`` can run a (C -> N) squeeze behind a pool: KC | C, N <= 96, weights + one 128-channel
+    activation chunk fit the LDS with room for two workgroups per CU."""
+    return C % 32 == 0 and N % 4 == 0 and N <= 96 and (C // 4) * (-(-N // 16) * 16) * 16 + 32 * 1024 <= 80 * 1024
+
+
+def pool_squeeze(x, x_coff, C, plan, y, y_coff):
+    """y[..., y_coff:y_coff+N] = relu(squeeze1x1(maxpool3x3s2_ceil(x[..., x_coff:x_coff+C]))) without materialising the
+    pooled tensor (inference).  ``plan``: ConvPlan of the squeeze packed for POOL_SQUEEZE_CFG."""
+    _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
+    B, H, W, xp = x.shape
+    Ho, Wo = pool_out_size(H, W)
+    if tuple(y.shape[:3]) != (B, Ho, Wo) or plan.taps != 1 or plan.C != C or plan.kc != 32 or plan.Npad != -(-plan.N // 16) * 16:
+        raise ValueError('pool_squeeze: geometry / plan mismatch')
+    if x_coff + C > xp or y_coff + plan.N > y.shape[3] or not pool_squeeze_ok(C, plan.N):
+        raise ValueError('pool_squeeze: unsupported channel configuration')
+    br = _Bracket('pool_squeeze', f'pool+squeeze C{C} N{plan.N} {H}x{W}', 2.0 * B * Ho * Wo * plan.N * C,
+                  4.0 * B * (H * W * C + Ho * Wo * plan.N)) if _timer is not None else None
+    rc = nat.lib().sqd_pool_squeeze_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), B, H, W, C, xp, x_coff, plan.N, plan.Npad,
+                                        y.shape[3], y_coff, nat.stream_handle(x.device))
+    nat.check(rc, 'sqd_pool_squeeze_fwd')
+    if br is not None:
+        br.done()
+    return y
+
+
 def stem_out_size(h, w, ksize):
     pad = 1 if ksize == 3 else 3
     return (h + 2 * pad - ksize) // 2 + 1, (w + 2 * pad - ksize) // 2 + 1

@@ -177,3 +177,25 @@ def test_fused_fire_expand_equals_separate_kernels(C, E, H, W):
         assert torch.equal(out, ref), f'cfg {cid}'
     with pytest.raises(ValueError):
         ops.FusedExpandPlan(w1, b1, w3, b3, ops.choose_cfg(1, C, E, npix))
+
+
+@pytest.mark.parametrize("C,N,H,W", [(128, 32, 96, 312), (256, 48, 48, 156), (128, 16, 7, 9), (64, 96, 12, 13), (32, 20, 3, 3)])
+def test_fused_pool_squeeze_vs_separate(C, N, H, W):
+    """pool_squeeze == maxpool kernel followed by the 1x1 conv kernel (pooled values are exact; the 1x1 sums in the same
+    ascending-k order), also against torch."""
+    ops = _ops()
+    B = 2
+    x = F.relu(_rand(B, C, H, W, seed=51)).cuda()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    w = _rand(N, C, 1, 1, seed=52, scale=(2.0 / C) ** 0.5).cuda(); b = _rand(N, seed=53, scale=0.1).cuda()
+    assert ops.pool_squeeze_ok(C, N)
+    Ho, Wo = ops.pool_out_size(H, W)
+    out = torch.empty(B, Ho, Wo, N + 8, device='cuda').fill_(3.0)
+    ops.pool_squeeze(xn, 0, C, ops.ConvPlan(w, b, ops.POOL_SQUEEZE_CFG), out, 4)
+    pooled = ops.maxpool(xn)
+    sep = torch.empty_like(out).fill_(3.0)
+    ops.conv(pooled, 0, ops.ConvPlan(w, b, ops.POOL_SQUEEZE_CFG), sep, 4, relu=True)
+    assert torch.equal(out, sep)
+    ref = F.relu(F.conv2d(F.max_pool2d(x.cpu(), 3, 2, ceil_mode=True), w.cpu(), b.cpu()))
+    assert (out[..., 4:4 + N].cpu() - _nhwc(ref)).abs().max().item() <= _tol(ref)
+    assert not ops.pool_squeeze_ok(256, 192)
