@@ -377,21 +377,26 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : 1) void stem_po
         m.w = fmaxf(fmaxf(fmaxf(fmaxf(w[0].w, w[1].w), w[2].w), fmaxf(fmaxf(w[3].w, w[4].w), w[5].w)), fmaxf(fmaxf(w[6].w, w[7].w), w[8].w));
         *(f32x4*)(a.y + o) = m;
       } else {
-        const int py = py0 + pr, px = px0 + pc;
-        f32x4 m = (f32x4){-1.f, -1.f, -1.f, -1.f};
-        int ax = 0, ay = 0, az = 0, aw = 0;
+        // max by v_max3, then the FIRST window position holding it (scan t = 8..0, the smallest match written last).
+        // Taps outside the conv map hold 0 (epilogue) and sit after tap 0 in scan order, and a maximum of 0 means every
+        // tap is 0, so a clipped tap is never reported.  NaN cannot occur here: the epilogue's ReLU maps it to 0.
+        f32x4 w[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            if (2 * py + dy >= a.Ho || 2 * px + dx >= a.Wo) continue;      // clipped window: not a candidate
-            const f32x4 v = *(const f32x4*)(cv + (dy * CW + dx) * CP);
-            const int tt = dy * 3 + dx;
-            if (v.x > m.x || v.x != v.x) { m.x = v.x; ax = tt; }
-            if (v.y > m.y || v.y != v.y) { m.y = v.y; ay = tt; }
-            if (v.z > m.z || v.z != v.z) { m.z = v.z; az = tt; }
-            if (v.w > m.w || v.w != v.w) { m.w = v.w; aw = tt; }
-          }
+          for (int dx = 0; dx < 3; ++dx) w[dy * 3 + dx] = *(const f32x4*)(cv + (dy * CW + dx) * CP);
+        f32x4 m;
+        m.x = fmaxf(fmaxf(fmaxf(fmaxf(w[0].x, w[1].x), w[2].x), fmaxf(fmaxf(w[3].x, w[4].x), w[5].x)), fmaxf(fmaxf(w[6].x, w[7].x), w[8].x));
+        m.y = fmaxf(fmaxf(fmaxf(fmaxf(w[0].y, w[1].y), w[2].y), fmaxf(fmaxf(w[3].y, w[4].y), w[5].y)), fmaxf(fmaxf(w[6].y, w[7].y), w[8].y));
+        m.z = fmaxf(fmaxf(fmaxf(fmaxf(w[0].z, w[1].z), w[2].z), fmaxf(fmaxf(w[3].z, w[4].z), w[5].z)), fmaxf(fmaxf(w[6].z, w[7].z), w[8].z));
+        m.w = fmaxf(fmaxf(fmaxf(fmaxf(w[0].w, w[1].w), w[2].w), fmaxf(fmaxf(w[3].w, w[4].w), w[5].w)), fmaxf(fmaxf(w[6].w, w[7].w), w[8].w));
+        int ax = 0, ay = 0, az = 0, aw = 0;
+#pragma unroll
+        for (int tt = 8; tt >= 1; --tt) {
+          ax = (w[tt].x == m.x) ? tt : ax; ay = (w[tt].y == m.y) ? tt : ay;
+          az = (w[tt].z == m.z) ? tt : az; aw = (w[tt].w == m.w) ? tt : aw;
+        }
+        ax = (w[0].x == m.x) ? 0 : ax; ay = (w[0].y == m.y) ? 0 : ay; az = (w[0].z == m.z) ? 0 : az; aw = (w[0].w == m.w) ? 0 : aw;
         *(f32x4*)(a.y + o) = m;
         *(uint32_t*)(a.amax + o) = (uint32_t)ax | ((uint32_t)ay << 8) | ((uint32_t)az << 16) | ((uint32_t)aw << 24);
       }
