@@ -137,19 +137,20 @@ def _nearest_tuned(prefix, npix):
     return None if best is None else best[1] % 1000             # drop the workgroup cap: it was measured for that grid size
 
 
-def choose_cfg(taps, C, N, npix):
+def choose_cfg(taps, C, N, npix, staged=False):
     """Tile configuration for a conv layer: the measured table if it has this shape, else a heuristic
-    (least channel padding, 128-pixel tiles when that still yields >= 4 workgroups per CU)."""
+    (least channel padding, 128-pixel tiles when that still yields >= 4 workgroups per CU).  ``staged=True`` asks for a
+    register-staged tiling (the only family that supports the input-side ``xmask``)."""
     tab = cfg_table()
-    hit = _tuning().get(f'{taps}:{C}:{N}:{npix}')
-    if hit is None:
+    hit = None if staged else _tuning().get(f'{taps}:{C}:{N}:{npix}')
+    if hit is None and not staged:
         hit = _nearest_tuned(f'{taps}:{C}:{N}:', npix)          # same layer at another batch size / resolution
     if hit is not None and hit % 1000 in tab and tab[hit % 1000][0] == taps:
         return hit
     want_kc = 16 if (taps == 9 or C <= 128 and C % 32 != 0 or C < 64) else 32
     best = None
     for cid, (t, kc, px, bn) in tab.items():
-        if t != taps or _CFG_DMA.get(cid, False):
+        if t != taps or _CFG_DMA.get(cid, 0) != (0 if staged else 1):     # default: LDS-DMA 4-wave tilings (fastest family measured)
             continue
         slices = -(-N // bn)
         pad = slices * bn / N

@@ -68,7 +68,7 @@ def test_conv_channel_windows_accumulate_mask():
     y0 = _rand(B, 96, H, W, seed=7)                    # write channels [16, 80) of a 96-wide buffer, accumulate
     exp = y0.clone()
     exp[:, 16:80] += ref
-    plan = ops.ConvPlan(w.cuda(), None, ops.choose_cfg(9, C, N, B * H * W))
+    plan = ops.ConvPlan(w.cuda(), None, ops.choose_cfg(9, C, N, B * H * W, staged=True))   # xmask: register-staged family
     y = _nhwc(y0).cuda()
     ops.conv(_nhwc(xfull).cuda(), 8, plan, y, 16, relu=False, accumulate=True, xmask=_nhwc(mask_src).cuda(), xmask_coff=8)
     got = y.cpu().permute(0, 3, 1, 2)
