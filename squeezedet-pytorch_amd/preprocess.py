@@ -20,6 +20,30 @@ KITTI_RGB_MEAN = np.array([93.877, 98.801, 95.923], dtype=np.float32)      # src
 KITTI_RGB_STD = np.array([78.782, 80.130, 81.200], dtype=np.float32)       # src/datasets/kitti.py:18
 
 
+_STAGE = [None, None]        # two pinned staging buffers used alternately: the H2D copy of the previous batch may still run
+
+
+def _staging(nbytes):
+    _STAGE.reverse()
+    buf = _STAGE[0]
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        _STAGE[0] = buf
+    return buf[:nbytes]
+
+
+_POOL = None
+
+
+def _pack_pool():
+    global _POOL
+    if _POOL is None:
+        import concurrent.futures
+        import os
+        _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1), thread_name_prefix='sqd-pack')
+    return _POOL
+
+
 def preprocess_batch(images, input_size, device='cuda', rgb_mean=KITTI_RGB_MEAN, rgb_std=KITTI_RGB_STD, out=None):
     """images: list of uint8 numpy arrays [H0, W0, 3] (RGB, any sizes).  Returns (image fp32 NCHW [B,3,H,W] on
     ``device``, scales fp32 [B,2] = (H/H0, W/W0) on ``device``, image_meta dict of per-image lists/arrays)."""
@@ -38,10 +62,18 @@ def preprocess_batch(images, input_size, device='cuda', rgb_mean=KITTI_RGB_MEAN,
         sizes[i] = im.shape[:2]
         offsets[i] = total
         total += im.shape[0] * im.shape[1] * 3
-    packed = torch.empty(total, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+    packed = _staging(total)                             # cached pinned host buffer (page-locking costs milliseconds)
     pk = packed.numpy()
-    for i, im in enumerate(images):
+
+    def _copy(i):
+        im = images[i]
         pk[offsets[i]:offsets[i] + im.size] = np.ascontiguousarray(im).reshape(-1)
+
+    if B >= 4 and total >= (1 << 22):                    # numpy releases the GIL while copying: pack in parallel
+        list(_pack_pool().map(_copy, range(B)))
+    else:
+        for i in range(B):
+            _copy(i)
     dev = torch.device(device)
     src = packed.to(dev, non_blocking=True)
     d_off = torch.from_numpy(offsets).to(dev, non_blocking=True)
