@@ -1,0 +1,74 @@
+"""Host logic around the measured tile table (no GPU needed: the configuration list comes from host-side entry points of
+the C-ABI library)."""
+import json
+import os
+
+import pytest
+
+from squeezedet_pytorch_amd import ops
+from squeezedet_pytorch_amd.synthetic import layer_table
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def table():
+    with open(os.path.join(ROOT, "squeezedet-pytorch_amd", "tuning.json")) as f:
+        return json.load(f)
+
+
+def test_every_tuned_entry_names_a_compiled_configuration(table):
+    tab = ops.cfg_table()
+    assert len(tab) >= 70
+    for key, v in table.items():
+        cid = int(v["cfg"])
+        assert 0 <= cid % 1000 < len(tab) and cid // 1000 <= 8, key
+        taps = tab[cid % 1000][0]
+        if key.startswith("F:"):
+            _, C, E, npix = key.split(":")
+            assert cid % 1000 in ops.fused_expand_cfgs(int(E)), key          # 3x3 LDS-DMA tiling, even group count, slice | 2E
+            assert v["us"] > 0 and "separate_us" in v
+        else:
+            t, C, N, npix = (int(x) for x in key.split(":"))
+            assert taps == t, key
+            assert v["us"] > 0 and v["tflops"] > 0
+
+
+def test_headline_workload_is_fully_tuned(table):
+    """Every conv of SqueezeDet at bs=20, 1248x384 (forward and data-gradient orientation) has a measured entry."""
+    B, h, w = 20, 192, 624                 # after the stride-2 stem
+    layers = layer_table("squeezedet")
+    missing = []
+    for l in layers[2:]:
+        if l[0] == "pool":
+            h, w = ops.pool_out_size(h, w)
+            continue
+        _, cin, s, e1, e3 = l
+        npix = B * h * w
+        for taps, C, N in ((1, cin, s), (1, s, e1), (9, s, e3), (1, s, cin), (1, e1, s), (9, e3, s)):
+            if f"{taps}:{C}:{N}:{npix}" not in table:
+                missing.append((taps, C, N, npix))
+    assert not missing, missing
+    assert f"9:768:72:{20 * 24 * 78}" in table and f"9:72:768:{20 * 24 * 78}" in table
+
+
+def test_choose_cfg_fallbacks():
+    tab = ops.cfg_table()
+    # exact hit
+    exact = ops.choose_cfg(9, 96, 384, 20 * 24 * 78)
+    assert tab[exact % 1000][0] == 9
+    # same layer at bs=16: nearest measured shape, without the workgroup cap that was measured for the other grid size
+    near = ops.choose_cfg(9, 96, 384, 16 * 24 * 78)
+    assert near < 1000 and tab[near][0] == 9 and ops.cfg_is_dma(near)
+    # unknown layer: heuristic over the LDS-DMA 4-wave family; staged=True asks for the register-staged family
+    h = ops.choose_cfg(9, 20, 40, 5000)
+    assert ops.cfg_is_dma(h) and tab[h][0] == 9
+    st = ops.choose_cfg(9, 20, 40, 5000, staged=True)
+    assert not ops.cfg_is_dma(st) and tab[st][0] == 9
+    assert ops.cfg_kernel_name(h).startswith("conv_dma<9,") and ops.cfg_kernel_name(st).startswith("conv_igemm<9,")
+    # fused expand: measured slower on this shape -> None (two separate launches); unknown half-width not a multiple of 16 -> None
+    assert ops.choose_fused_cfg(96, 384, 20 * 24 * 78) is None
+    assert ops.choose_fused_cfg(16, 24, 1000) is None
+    f = ops.choose_fused_cfg(64, 256, 20 * 24 * 78)
+    assert f is not None and f % 1000 in ops.fused_expand_cfgs(256)
+    assert ops.pool_squeeze_ok(128, 32) and ops.pool_squeeze_ok(256, 48) and not ops.pool_squeeze_ok(256, 192)
