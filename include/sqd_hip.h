@@ -146,9 +146,11 @@ int sqd_pool_squeeze_fwd(const float* x, const float* w_packed, const float* bia
  * one-hot).  boxes [total][4] xyxy fp32, class_ids [total] int32, box_offsets [B+1] int32, anchors [A][4] FLOAT64
  * (cx,cy,w,h; the reference keeps them in float64 and the overlaps are float64 arithmetic).  Outputs, each may be
  * NULL: gt [B][A][C+9] (fully overwritten), anchor_idx [total] int32 (A = unassigned), deltas [total][4] fp32.
- * Ties in overlap / distance -> lowest anchor index (the reference leaves them to numpy's unstable argsort). */
+ * Ties in overlap / distance -> lowest anchor index (the reference leaves them to numpy's unstable argsort).
+ * workspace: 16 * total_boxes bytes (device) or NULL: enables the parallel first-choice pass (same results). */
 int sqd_encode_gt_fwd(const float* boxes, const int* class_ids, const int* box_offsets, const double* anchors,
-                      float* gt, int* anchor_idx, float* deltas, int B, int A, int num_classes, void* stream);
+                      float* gt, int* anchor_idx, float* deltas, void* workspace, int total_boxes, int B, int A,
+                      int num_classes, void* stream);
 
 /* KITTI 2D detection AP, host code: what KITTI.evaluate (src/datasets/kitti.py:99-124)
  * obtains from the evaluate_object binary (src/utils/kitti-eval/cpp/evaluate_object.cpp:281-571).  n_images frames;

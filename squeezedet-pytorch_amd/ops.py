@@ -716,7 +716,7 @@ def loss_bwd(pred, gt, anchors, nobj, coef, input_size, num_classes, weights):
     return dpred
 
 
-def encode_gt(boxes, class_ids, box_offsets, anchors64, num_classes, dense=True):
+def encode_gt(boxes, class_ids, box_offsets, anchors64, num_classes, dense=True, parallel=True):
     """On-device GT encoding (compute_deltas + prepare_annotations, src/utils/boxes.py:84-135,
     src/datasets/base.py:61-76).  boxes [total,4] fp32 xyxy, class_ids [total] i32, box_offsets [B+1] i32,
     anchors64 [A,4] float64 -- all on the GPU.  -> (gt [B,A,C+9] or None, anchor_idx [total] i32, deltas [total,4])."""
@@ -735,9 +735,11 @@ def encode_gt(boxes, class_ids, box_offsets, anchors64, num_classes, dense=True)
     idx = torch.empty(max(total, 1), device=dev, dtype=torch.int32)
     deltas = torch.empty(max(total, 1), 4, device=dev, dtype=torch.float32)
     br = _Bracket('encode_gt', f'gt A{A}', 0.0, 4.0 * B * A * (num_classes + 9)) if _timer is not None else None
+    ws = torch.empty(max(total, 1) * 2, device=dev, dtype=torch.float64)       # 16 bytes per box: first-choice candidates
     rc = nat.lib().sqd_encode_gt_fwd(nat.ptr(boxes) if total else None, nat.ptr(class_ids) if total else nat.ptr(idx),
                                      nat.ptr(box_offsets), nat.ptr(anchors64), nat.ptr(gt) if dense else None, nat.ptr(idx),
-                                     nat.ptr(deltas), B, A, int(num_classes), nat.stream_handle(dev))
+                                     nat.ptr(deltas), nat.ptr(ws) if (total and parallel) else None, int(total), B, A,
+                                     int(num_classes), nat.stream_handle(dev))
     nat.check(rc, 'sqd_encode_gt_fwd')
     if br is not None:
         br.done()

@@ -193,6 +193,25 @@ def test_gpu_encoder_more_boxes_than_anchors_and_other_shapes():
 
 
 @pytest.mark.gpu
+def test_gpu_encoder_parallel_first_choice_equals_serial(gold, anchors):
+    """The parallel first-choice pass (+ serial conflict resolution) and the all-serial path give identical tensors, on the
+    golden sets (ties, crowds, fallbacks) and on a heavily conflicting batch."""
+    from squeezedet_pytorch_amd import ops
+    from squeezedet_pytorch_amd.annotations import anchors_f64_on, pack_annotations
+    sets = list(_sets(gold))
+    same = np.tile(np.array([[400., 100., 520., 190.]], np.float32), (120, 1))
+    box_list = [s[1] for s in sets] + [same]
+    cls_list = [s[2] for s in sets] + [np.zeros(120, np.int32)]
+    boxes, cls, offs = pack_annotations(cls_list, box_list)
+    dev = torch.device("cuda")
+    d = [torch.from_numpy(v).to(dev) for v in (boxes, cls, offs)]
+    a64 = anchors_f64_on(anchors, dev)
+    gt_p, idx_p, del_p = ops.encode_gt(d[0], d[1], d[2], a64, 3, parallel=True)
+    gt_s, idx_s, del_s = ops.encode_gt(d[0], d[1], d[2], a64, 3, parallel=False)
+    assert torch.equal(idx_p, idx_s) and torch.equal(del_p, del_s) and torch.equal(gt_p, gt_s)
+
+
+@pytest.mark.gpu
 def test_gpu_encoded_gt_feeds_the_loss(anchors):
     """loss on the device-encoded gt == loss on the host-encoded gt (same picks wherever ties do not interfere)."""
     from squeezedet_pytorch_amd import ops
