@@ -126,8 +126,9 @@ def main():
 
         def step():
             return det.detect_device(x, out=out_bufs)
-        describe = ('SqueezeDet KITTI 1248x384 bs=20 inference on 1 MI355X (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
-                    else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on 1 MI355X')
+        where = '1 MI355X' if world == 1 else f'each of {world} MI355X (independent replicas, no data-path collective)'
+        describe = (f'SqueezeDet KITTI 1248x384 bs={B} inference on {where} (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
+                    else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on {where}')
 
     def barrier():
         if dist is not None:
