@@ -52,7 +52,7 @@ def test_conv_fwd_all_cfgs(taps, C, N, B, H, W):
         err = (y.cpu() - ref).abs().max().item()
         assert err <= _tol(ref), f'cfg {cid}: max err {err}'
     # automatic choice is one of them
-    assert ops.choose_cfg(taps, C, N, B * H * W) in cfgs
+    assert ops.choose_cfg(taps, C, N, B * H * W) % 1000 in cfgs          # (+ 1000 * k = workgroup cap)
 
 
 def test_conv_channel_windows_accumulate_mask():
