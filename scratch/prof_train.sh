@@ -1,17 +1,12 @@
 #!/bin/bash
-TAG=${1:-t}
+# usage: scratch/prof_train.sh <tag>   (run on the GPU box from the repo root): kernel trace of the training step
+set -e
+TAG=${1:-r01}
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/prof_$TAG
+OUT=$PWD/gpurun_out/prof_train_$TAG
 mkdir -p $OUT
-REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python3 $REPO/bench.py --mode train --steps 10 --warmup 3 > $OUT/bench_under_prof.json 2> $OUT/stderr.log
-cd $REPO
-python3 - <<PY
-import csv
-rows=list(csv.DictReader(open("$OUT/trace_kernel_stats.csv")))
-tot=sum(float(r["TotalDurationNs"]) for r in rows)
-nsteps=10+3+3+2+1
-print("total GPU kernel time per step ~", tot/1e6/ (10+3+3+2), "ms (approx; steps incl warmup/profile passes)")
-for r in rows[:22]: print(f'{r["Name"][:70]:70s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"])/1e3:8.1f} us  {r["Percentage"]}%')
-PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python3 $OLDPWD/bench.py --mode train --steps 20 --warmup 5 --no-cpu-baseline $SQD_BENCH_ARGS > $OUT/bench_under_prof.json 2> $OUT/stderr.log
+cd $OLDPWD
+find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats_train_$TAG.csv
+head -45 gpurun_out/kernel_stats_train_$TAG.csv

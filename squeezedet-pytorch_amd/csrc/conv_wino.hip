@@ -1,0 +1,435 @@
+// Winograd F(2x2, 3x3) convolution (3x3 / pad 1 / stride 1) on the gfx950 fp32 matrix cores.
+//
+// Serves the same layers as the 3x3 implicit-GEMM kernel of conv_igemm.hip (reference: Fire expand3x3,
+// src/model/squeezedet.py:14,20-22, and ConvDet, :73-75,83) where the host's measured table says it is faster: the
+// 3x3 convolution over a 2x2 output tile is evaluated as 16 element-wise products in the transformed domain,
+//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A ,
+// i.e. 16 independent [tiles x C] x [C x N] GEMMs -- 2.25x fewer multiply-adds than the direct form.  fp32 throughout
+// (the transforms only add, subtract and halve: measured error vs an fp64 convolution is the same ~2e-7 relative as the
+// direct kernel's, scratch/wino_numerics.py), so the 1e-4 parity bound is untouched.
+//
+// Decomposition: a GROUP is 4 rows x 16 columns of output = 16 Winograd tiles (one MFMA column block); each WAVE owns
+// one group and all 16 transform positions for a slice of 16*NT output channels (16*NT f32x4 accumulators).  A
+// workgroup is WV waves working on WV consecutive groups of the flattened (image, row-group, column-group) list --
+// they need not be adjacent, so the only padding is the 16-column / 4-row granularity (78 -> 80 columns) -- and shares
+// the transformed weights U of the slice through LDS.  Per K chunk of 8 channels:
+//   * the wave's 6x18-pixel input patch arrives by LDS-DMA into a wave-private raw buffer (zero page outside the image),
+//   * every lane transforms one (tile, channel pair): 16 ds_read_b64, 32 packed adds, 16 ds_write_b64 into the
+//     wave-private V[pos][tile][8] image,
+//   * 16 positions x 2 k-steps x NT MFMAs read V and U (both as conflict-free contiguous ds_read_b64),
+//   * the next chunk's patch and U slice are fetched by LDS-DMA during the MFMA phase (U double-buffered; the patch
+//     buffer is wave-private and dead once the wave has transformed it, so it needs no second copy).
+// Workgroups are persistent (strided super-group list); the inverse transform runs in registers after the last chunk
+// and the stores drain behind the next stage's barrier.
+//
+// Packed weights: U[C/8][8 position pairs][Npad/16][4 channel pairs][16 n][position parity][2 channels] -- the LDS image
+// of a slice is a set of contiguous runs (sqd_pack_wino_weight; host: ops.WinoPlan).
+#include "sqd_common.h"
+
+struct WinoArgs {
+  const float* x; const float* u; const float* bias; float* y;
+  int B, H, W;
+  int C, x_pitch, x_coff;
+  int N, Npad, y_pitch, y_coff;
+  int relu;
+  int gxn, gyn;                 // column / row groups per image
+  int ngroups, ntiles;          // B*gyn*gxn groups; ntiles = super-groups of WV groups
+  int nslices, gx;              // persistent grid: gx tile streams x nslices channel slices
+  int wg_cap;
+};
+
+__device__ __attribute__((aligned(16))) float wino_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+typedef __attribute__((address_space(3))) void* lds_ptr_w_t;
+
+__device__ __forceinline__ f32x4 wino_relu4(f32x4 v, float lo) {
+  asm volatile("v_max_f32 %0, %4, %0\n\tv_max_f32 %1, %4, %1\n\tv_max_f32 %2, %4, %2\n\tv_max_f32 %3, %4, %3"
+               : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : "s"(lo));
+  return v;
+}
+
+template <int NT, int WV>
+__global__ __launch_bounds__(WV * 64, 1) void conv_wino_kernel(WinoArgs a) {
+  constexpr int NTHR = WV * 64;
+  constexpr int BN = 16 * NT;
+  constexpr int RP = 113;                     // slots per k-quad plane of the raw patch (108 used): 113*16 B = 16 mod 256, so the
+                                              // two planes interleave in the LDS bank row and the transform's reads do not collide
+  constexpr int RAW_IT = 4;                   // 256 slots per wave (226 used)
+  constexpr int USLOTS = 32 * BN;             // 16 pos x BN channels x 2 halves of 16 B
+  static_assert(USLOTS % NTHR == 0, "U slice must be whole workgroup passes");
+  constexpr int U_IT = USLOTS / NTHR;
+  constexpr int NDMA = RAW_IT + U_IT;
+  constexpr int NSTEP = 8;                    // MFMA steps of 2 positions
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const rawB = smem;                                 // [WV][256][4]
+  float* const VB = rawB + WV * 256 * 4;                    // [WV][16][16][8]
+  float* const UB = VB + WV * 2048;                         // [2][USLOTS][4]
+  float* const biasL = UB + 2 * USLOTS * 4;                 // [BN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int wgq = (int)blockIdx.x >> 3;
+  const int n0 = (wgq % a.nslices) * BN;
+  const int tstride = a.gx;
+  const int nchunks = a.C >> 3;
+  const int ntiles = a.ntiles;
+  int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
+  if (tile >= ntiles) return;
+  const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+
+  // ---- per-lane DMA slots ----
+  int r_off[RAW_IT], r_key[RAW_IT];
+#pragma unroll
+  for (int it = 0; it < RAW_IT; ++it) {
+    const int slot = it * 64 + lane;
+    const int kq = slot / RP, pix = slot - kq * RP;
+    const bool real = kq < 2 && pix < 108;
+    const int r = pix / 18, c = pix - r * 18;
+    r_key[it] = real ? (r << 8 | c) : -1;
+    r_off[it] = real ? (r * a.W + c) * a.x_pitch + 4 * kq : 0;
+  }
+  int u_off[U_IT];
+#pragma unroll
+  for (int it = 0; it < U_IT; ++it) {
+    const int slot = it * NTHR + tid;
+    const int pp = slot / (4 * BN), rem = slot - pp * (4 * BN);     // position pair, 16-byte slot inside the slice's run
+    u_off[it] = (pp * a.Npad + n0) * 16 + rem * 4;
+  }
+  const long long u_chunk = (long long)16 * a.Npad * 8;
+
+  struct GPos { int y0, x0, inner, valid; long long p0; const float* xorg; };
+  auto gp_sel = [](bool c, const GPos& u, const GPos& v) {
+    GPos r; r.y0 = c ? u.y0 : v.y0; r.x0 = c ? u.x0 : v.x0; r.inner = c ? u.inner : v.inner; r.valid = c ? u.valid : v.valid;
+    r.p0 = c ? u.p0 : v.p0; r.xorg = c ? u.xorg : v.xorg;
+    return r;
+  };
+  auto group_pos = [&](int t) {                              // this wave's group of super-group t (all wave-uniform)
+    GPos gp;
+    int q = t * WV + wv_s;
+    gp.valid = (int)((unsigned)(q - a.ngroups) >> 31);       // q < ngroups
+    q = gp.valid ? q : a.ngroups - 1;                        // idle waves of the last super-group redo the last group (not stored)
+    const int gxi = q % a.gxn; q /= a.gxn;
+    const int gyi = q % a.gyn; const int b = q / a.gyn;
+    gp.y0 = gyi * 4; gp.x0 = gxi * 16;
+    gp.p0 = ((long long)b * a.H + gp.y0) * a.W + gp.x0;
+    gp.xorg = a.x + (gp.p0 - a.W - 1) * a.x_pitch + a.x_coff;
+    gp.inner = (int)(((unsigned)(-gp.y0) & (unsigned)(gp.y0 + 4 - a.H) & (unsigned)(-gp.x0) & (unsigned)(gp.x0 + 16 - a.W)) >> 31);
+    return gp;
+  };
+  auto pix_masks = [&](const GPos gp, unsigned long long (&m)[RAW_IT]) {
+    if (gp.inner) {
+#pragma unroll
+      for (int it = 0; it < RAW_IT; ++it) m[it] = ~0ull;
+      return;
+    }
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+      const int key = r_key[it];
+      const bool ok = key >= 0 && (unsigned)(gp.y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(gp.x0 + (key & 255) - 1) < (unsigned)a.W;
+      m[it] = __builtin_amdgcn_ballot_w64(ok);
+    }
+  };
+  const unsigned long long zp = (unsigned long long)(const void*)wino_zero_page;
+  const unsigned zp_lo = (unsigned)zp, zp_hi = (unsigned)(zp >> 32);
+  float* const rawW = rawB + wv_s * 256 * 4;                 // this wave's raw patch / V image
+  float* const VW = VB + wv_s * 2048;
+  auto dma_raw_one = [&](int it, const GPos gp, unsigned long long okmask, int cc) {
+    const float* src = gp.xorg + cc * 8 + r_off[it];
+    const unsigned long long p = (unsigned long long)(const void*)src;
+    unsigned lo = (unsigned)p, hi = (unsigned)(p >> 32);
+    asm volatile("v_cndmask_b32 %0, %2, %0, %4\n\tv_cndmask_b32 %1, %3, %1, %4" : "+v"(lo), "+v"(hi) : "v"(zp_lo), "v"(zp_hi), "s"(okmask));
+    src = (const float*)(const void*)(((unsigned long long)hi << 32) | lo);
+    __builtin_amdgcn_global_load_lds(src, (lds_ptr_w_t)(rawW + it * 64 * 4), 16, 0, 0);
+  };
+  auto dma_u_one = [&](int it, int cc, int buf) {
+    const float* src = a.u + cc * u_chunk + u_off[it];
+    __builtin_amdgcn_global_load_lds(src, (lds_ptr_w_t)(UB + (buf * USLOTS + it * NTHR + wv_s * 64) * 4), 16, 0, 0);
+  };
+
+  f32x4 acc[16][NT], outv[4][NT];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (tid < BN) biasL[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
+  const int ty = lr >> 3, tx = lr & 7;
+  int o_off[4];
+#pragma unroll
+  for (int px = 0; px < 4; ++px) o_off[px] = ((2 * ty + (px >> 1)) * a.W + 2 * tx + (px & 1)) * a.y_pitch + 4 * g;
+  const float relu_lo = a.relu ? 0.f : -__builtin_inff();
+
+  // transform unit of this lane: tile tt, channel pair cp of the chunk
+  // (lanes 0-31 = tile row 0, lanes 32-63 = tile row 1; within a half: 8 tiles x (k-quad, channel half) -- the 32 lanes of
+  // a ds_read_b64 half then cover 32 distinct 8-byte units of one 256-byte bank row: conflict-free)
+  const int tt = ((lane >> 5) << 3) | (lane & 7), cp = (lane >> 3) & 3;
+  const float* const rawL = rawW + (((cp >> 1) * RP + (2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 4 + 2 * (cp & 1));
+  // V image: [8 position pairs][4 channel pairs][16 tiles][pos parity][2 channels] -- one ds_read_b128 per lane and
+  // position pair in the k-quad-major (conflict-free) order of the direct kernel; U has the same order per 16 channels
+  float* const vL = VW + cp * 64 + tt * 4;
+  const float* const vR = VW + g * 64 + lr * 4;
+  const float* const uR0 = UB + g * 64 + lr * 4;
+
+  GPos cur = group_pos(tile);
+  unsigned long long okc[RAW_IT], okn[RAW_IT];
+#pragma unroll
+  for (int it = 0; it < RAW_IT; ++it) { okc[it] = 0; okn[it] = 0; }
+  pix_masks(cur, okc);
+#pragma unroll
+  for (int it = 0; it < RAW_IT; ++it) dma_raw_one(it, cur, okc[it], 0);
+#pragma unroll
+  for (int it = 0; it < U_IT; ++it) dma_u_one(it, 0, 0);
+  int ubuf = 0;
+  bool pending = false;
+  GPos ptp = cur;
+
+  auto flush = [&](const GPos gp) {
+    float* ybase = a.y + gp.p0 * a.y_pitch + a.y_coff + n0;
+    const bool whole = gp.y0 + 4 <= a.H && gp.x0 + 16 <= a.W && n0 + BN <= a.N;
+    if (!gp.valid) return;
+    if (whole) {
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          f32x4 v = outv[px][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
+          v = wino_relu4(v, relu_lo);
+          *(f32x4*)(ybase + o_off[px] + j * 16) = v;
+        }
+      return;
+    }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const bool valid = gp.y0 + 2 * ty + (px >> 1) < a.H && gp.x0 + 2 * tx + (px & 1) < a.W;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (!valid || n0 + j * 16 + 4 * g >= a.N) continue;
+        f32x4 v = outv[px][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
+        v = wino_relu4(v, relu_lo);
+        *(f32x4*)(ybase + o_off[px] + j * 16) = v;
+      }
+    }
+  };
+
+  for (;;) {
+    const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);
+    const bool more = more_i != 0;
+    const GPos nxt = group_pos(more ? tile + tstride : tile);
+    pix_masks(nxt, okn);
+    for (int cc = 0; cc < nchunks; ++cc) {
+      __syncthreads();                       // vmcnt(0): this stage's patch and U slice have landed; all waves left the previous U buffer
+      if (pending) { flush(ptp); pending = false; }
+      const int last_i = 1 - (int)((unsigned)(cc + 1 - nchunks) >> 31);
+      const bool last = last_i != 0;
+      const int ncc = last ? 0 : cc + 1;
+      const GPos ntp = gp_sel(last, nxt, cur);
+      unsigned long long dm[RAW_IT];
+#pragma unroll
+      for (int it = 0; it < RAW_IT; ++it) dm[it] = last ? okn[it] : okc[it];
+
+      // ---- input transform: V = B^T d B for (tile tt, channels 2cp, 2cp+1) ----
+      {
+        f32x2 t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * 4), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * 4);
+          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * 4), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * 4);
+          t[0][j] = d0 - d2; t[1][j] = d1 + d2; t[2][j] = d2 - d1; t[3][j] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
+          *(f32x4*)(vL + (i * 2 + 0) * 256) = (f32x4){v0.x, v0.y, v1.x, v1.y};
+          *(f32x4*)(vL + (i * 2 + 1) * 256) = (f32x4){v2.x, v2.y, v3.x, v3.y};
+        }
+      }
+      const float* const uR = uR0 + ubuf * USLOTS * 4;
+
+      // ---- 16 positions x 2 k-steps x NT MFMAs, software-pipelined over two operand sets (steps of 2 positions) ----
+      auto load_ops = [&](int step, f32x4& bfr, f32x4 (&afr)[NT]) {           // step = position pair
+        bfr = *(const f32x4*)(vR + step * 256);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) afr[j] = *(const f32x4*)(uR + (step * NT + j) * 256);
+      };
+      auto mfma_pos = [&](int step, const f32x4& bfr, const f32x4 (&afr)[NT], int h) {
+        const int p = 2 * step + h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[p][j] = mfma16(afr[j][2 * h + t], bfr[2 * h + t], acc[p][j]);
+      };
+      f32x4 bf0, af0[NT], bf1, af1[NT];
+      load_ops(0, bf0, af0);
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) {
+          if (q * NSTEP / NDMA != step) continue;
+          if (q < RAW_IT) dma_raw_one(q, ntp, dm[q < RAW_IT ? q : 0], ncc);
+          else dma_u_one(q - RAW_IT, ncc, ubuf ^ 1);
+        }
+        if (step & 1) {
+          mfma_pos(step, bf1, af1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (step + 1 < NSTEP) load_ops(step + 1, bf0, af0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_pos(step, bf1, af1, 1);
+        } else {
+          mfma_pos(step, bf0, af0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (step + 1 < NSTEP) load_ops(step + 1, bf1, af1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_pos(step, bf0, af0, 1);
+        }
+      }
+
+      if (last) {                            // inverse transform Y = A^T M A in registers; stored after the next barrier
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          f32x4 s[4][2];
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi) {
+            s[xi][0] = acc[xi * 4 + 0][j] + acc[xi * 4 + 1][j] + acc[xi * 4 + 2][j];
+            s[xi][1] = acc[xi * 4 + 1][j] - acc[xi * 4 + 2][j] - acc[xi * 4 + 3][j];
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            outv[0 * 2 + b][j] = s[0][b] + s[1][b] + s[2][b];
+            outv[1 * 2 + b][j] = s[1][b] - s[2][b] - s[3][b];
+          }
+#pragma unroll
+          for (int p = 0; p < 16; ++p) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        pending = true; ptp = cur;
+      }
+      ubuf ^= 1;
+    }
+    if (!more) break;
+    tile += tstride;
+    cur = nxt;
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) okc[it] = okn[it];
+  }
+  if (pending) flush(ptp);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static int wino_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <int NT, int WV>
+static int launch_wino(WinoArgs a, hipStream_t stream) {
+  constexpr int BN = 16 * NT, NTHR = WV * 64;
+  constexpr size_t lds = (size_t)(WV * 256 * 4 + WV * 2048 + 2 * 32 * BN * 4 + BN) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = conv_wino_kernel<NT, WV>;
+  static int wgs_per_cu = 0;
+  if (wgs_per_cu == 0) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SQD_ERR_LAUNCH;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
+    wgs_per_cu = nb > 4 ? 4 : nb;
+  }
+  a.gxn = sqd_cdiv(a.W, 16); a.gyn = sqd_cdiv(a.H, 4);
+  a.ngroups = a.B * a.gxn * a.gyn;
+  a.ntiles = sqd_cdiv(a.ngroups, WV);
+  const int nslices = sqd_cdiv(a.N, BN);
+  if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;
+  const int slots = wino_num_cus() * ((a.wg_cap > 0 && a.wg_cap < wgs_per_cu) ? a.wg_cap : wgs_per_cu);
+  int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
+  const int per_wg = sqd_cdiv(a.ntiles, gx_max);
+  const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;
+  a.nslices = nslices; a.gx = gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx * nslices)), dim3(NTHR), lds, stream, a);
+  return sqd_launch_status();
+}
+
+// U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: one thread per (chunk, n, channel) writes its 16 positions
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int No, int Ci, int Npad, int dgrad) {
+  const int N = dgrad ? Ci : No, C = dgrad ? No : Ci;
+  const long long total = (long long)(C >> 3) * Npad * 8;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = (int)(idx & 7);
+  const int n = (int)((idx >> 3) % Npad);
+  const int chunk = (int)((idx >> 3) / Npad);
+  const int c = chunk * 8 + c8;
+  float gk[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      gk[r][q] = (n >= N) ? 0.f : (dgrad ? w[(((long long)c * Ci + n) * 3 + (2 - r)) * 3 + (2 - q)] : w[(((long long)n * Ci + c) * 3 + r) * 3 + q]);
+  float t[4][3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    t[0][q] = gk[0][q];
+    t[1][q] = 0.5f * (gk[0][q] + gk[1][q] + gk[2][q]);
+    t[2][q] = 0.5f * (gk[0][q] - gk[1][q] + gk[2][q]);
+    t[3][q] = gk[2][q];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float o0 = t[i][0], o1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), o2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), o3 = t[i][2];
+    // [chunk][position pair][Npad/16][channel pair][16 n][position parity][2 channels]
+    float* dst = u + (((((long long)chunk * 8 + i * 2) * (Npad >> 4) + (n >> 4)) * 4 + (c8 >> 1)) * 16 + (n & 15)) * 4 + (c8 & 1);
+    const long long pps = (long long)Npad * 16;                  // floats per position pair
+    dst[0] = o0; dst[2] = o1; dst[pps] = o2; dst[pps + 2] = o3;
+  }
+}
+
+extern "C" int sqd_pack_wino_weight(const float* w_oihw, float* u_packed, int No, int Ci, int Npad, int dgrad, void* stream) {
+  SQD_CHECK_ARG(w_oihw && u_packed && No > 0 && Ci > 0);
+  const int N = dgrad ? Ci : No, C = dgrad ? No : Ci;
+  SQD_CHECK_ARG(C % 8 == 0 && Npad >= N && Npad % 16 == 0);
+  const long long total = (long long)(C >> 3) * Npad * 8;
+  hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, u_packed, No, Ci, Npad, dgrad);
+  return sqd_launch_status();
+}
+
+// Winograd configurations: cfg_id -> (channel blocks per slice NT, waves per workgroup WV)
+struct WinoCfg { int nt, wv; };
+static const WinoCfg kWinoCfgs[] = {{2, 8}, {1, 8}, {2, 4}, {1, 4}};
+static const int kNumWinoCfgs = (int)(sizeof(kWinoCfgs) / sizeof(kWinoCfgs[0]));
+
+extern "C" int sqd_wino_num_cfgs() { return kNumWinoCfgs; }
+
+extern "C" int sqd_wino_cfg_info(int cfg_id, int* bn, int* waves) {
+  if (cfg_id < 0 || cfg_id >= kNumWinoCfgs) return SQD_ERR_BAD_ARG;
+  if (bn) *bn = 16 * kWinoCfgs[cfg_id].nt;
+  if (waves) *waves = kWinoCfgs[cfg_id].wv;
+  return SQD_OK;
+}
+
+extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const float* bias, float* y, int B, int H, int W,
+                                 int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
+                                 int cfg_id, void* stream) {
+  SQD_CHECK_ARG(x && u_packed && y);
+  SQD_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && N > 0);
+  SQD_CHECK_ARG(C % 8 == 0 && N % 4 == 0 && Npad >= N);
+  SQD_CHECK_ARG(x_pitch % 4 == 0 && x_coff % 4 == 0 && y_pitch % 4 == 0 && y_coff % 4 == 0);
+  SQD_CHECK_ARG(x_coff >= 0 && x_coff + C <= x_pitch && y_coff >= 0 && y_coff + N <= y_pitch);
+  SQD_CHECK_ARG((long long)W * 6 * (x_pitch > y_pitch ? x_pitch : y_pitch) < (1ll << 31));    // 32-bit lane offsets inside a group
+  const int cap = cfg_id / 1000; cfg_id %= 1000;
+  SQD_CHECK_ARG(cfg_id >= 0 && cfg_id < kNumWinoCfgs);
+  WinoArgs a{};
+  a.x = x; a.u = u_packed; a.bias = bias; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff; a.relu = relu; a.wg_cap = cap;
+  hipStream_t s = (hipStream_t)stream;
+  switch (cfg_id) {
+    case 0: return launch_wino<2, 8>(a, s);
+    case 1: return launch_wino<1, 8>(a, s);
+    case 2: return launch_wino<2, 4>(a, s);
+    case 3: return launch_wino<1, 4>(a, s);
+  }
+  return SQD_ERR_UNSUPPORTED;
+}

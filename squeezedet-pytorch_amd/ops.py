@@ -344,6 +344,76 @@ def fire_expand(x, x_coff, fplan, y, y_coff):
     return y
 
 
+def wino_cfgs():
+    """{cfg_id: (slice width, waves per workgroup)} of the Winograd F(2x2,3x3) kernel family."""
+    import ctypes
+    out = {}
+    for i in range(nat.lib().sqd_wino_num_cfgs()):
+        bn, wv = ctypes.c_int(), ctypes.c_int()
+        nat.check(nat.lib().sqd_wino_cfg_info(i, ctypes.byref(bn), ctypes.byref(wv)), 'sqd_wino_cfg_info')
+        out[i] = (bn.value, wv.value)
+    return out
+
+
+def choose_wino_cfg(C, N, npix):
+    """Winograd configuration for a 3x3 layer if the measured table (key ``W:C:N:npix``) says it beats the direct kernel,
+    else None (unmeasured shapes run the direct kernel)."""
+    if C % 8:
+        return None
+    hit = _tuning().get(f'W:{C}:{N}:{npix}')
+    if hit is None:
+        hit = _nearest_tuned(f'W:{C}:{N}:', npix) if any(k.startswith(f'W:{C}:{N}:') for k in _tuning()) else None
+    return hit if (hit is not None and hit >= 0) else None
+
+
+class WinoPlan:
+    """Transformed weights U = G g G^T ([C/8][16][Npad][8]) + bias of one 3x3 conv for ``conv_wino``."""
+    __slots__ = ('cfg_id', 'C', 'N', 'Npad', 'bn', 'w', 'bias')
+
+    def __init__(self, w_oihw, bias, cfg_id, dgrad=False):
+        No, Ci, kh, kw = w_oihw.shape
+        if (kh, kw) != (3, 3):
+            raise ValueError(f'Winograd plan needs a 3x3 weight, got {tuple(w_oihw.shape)}')
+        if not w_oihw.is_cuda or w_oihw.dtype != torch.float32:
+            raise ValueError('weights must be fp32 CUDA tensors')
+        N, C = (Ci, No) if dgrad else (No, Ci)
+        if C % 8 or N % 4:
+            raise ValueError('Winograd conv: C must be a multiple of 8 and N of 4')
+        bn = wino_cfgs()[cfg_id % 1000][0]
+        self.cfg_id, self.C, self.N, self.bn = cfg_id, C, N, bn
+        self.Npad = -(-N // bn) * bn
+        src = w_oihw.detach().contiguous()
+        self.w = torch.empty(C // 8, 16, self.Npad, 8, device=src.device, dtype=torch.float32)
+        nat.check(nat.lib().sqd_pack_wino_weight(nat.ptr(src), nat.ptr(self.w), No, Ci, self.Npad, int(dgrad),
+                                                 nat.stream_handle(src.device)), 'sqd_pack_wino_weight')
+        self.bias = None if (bias is None or dgrad) else bias.detach().contiguous()
+
+
+def conv_wino(x, x_coff, plan, y, y_coff, relu=False):
+    """y[..., y_coff:y_coff+N] = conv3x3(x[..., x_coff:x_coff+C]) (+bias) (ReLU), Winograd F(2x2,3x3) kernel."""
+    _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
+    B, H, W, xp = x.shape
+    if tuple(y.shape[:3]) != (B, H, W):
+        raise ValueError(f'conv_wino: x {tuple(x.shape)} and y {tuple(y.shape)} disagree on B,H,W')
+    yp = y.shape[3]
+    if x_coff < 0 or x_coff + plan.C > xp or y_coff < 0 or y_coff + plan.N > yp:
+        raise ValueError('conv_wino: channel window out of range')
+    if B * H * W * max(xp, yp) >= 2 ** 40:
+        raise ValueError('conv_wino: tensor too large')
+    br = None
+    if _timer is not None:
+        npix = B * H * W
+        bn, wv = wino_cfgs()[plan.cfg_id % 1000]
+        br = _Bracket(f'conv_wino<{bn // 16},{wv}>', f'9tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * 9,
+                      4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * 9))
+    rc = nat.lib().sqd_conv_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), B, H, W, plan.C, xp, x_coff,
+                                     plan.N, plan.Npad, yp, y_coff, int(relu), plan.cfg_id, nat.stream_handle(x.device))
+    nat.check(rc, 'sqd_conv_wino_fwd')
+    if br is not None:
+        br.done()
+    return y
+
+
 POOL_SQUEEZE_CFG = 28        # 1x1 tiling with KC = 32, 16-channel slices: its packed weights are [C/4][ceil16(N)][4]
 
 

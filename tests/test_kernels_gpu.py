@@ -199,3 +199,48 @@ def test_fused_pool_squeeze_vs_separate(C, N, H, W):
     ref = F.relu(F.conv2d(F.max_pool2d(x.cpu(), 3, 2, ceil_mode=True), w.cpu(), b.cpu()))
     assert (out[..., 4:4 + N].cpu() - _nhwc(ref)).abs().max().item() <= _tol(ref)
     assert not ops.pool_squeeze_ok(256, 192)
+
+
+@pytest.mark.parametrize("C,N,B,H,W", [
+    (16, 64, 2, 12, 20), (32, 128, 1, 9, 33), (48, 192, 1, 24, 78), (96, 384, 1, 5, 17), (768, 72, 1, 6, 18),
+    (16, 64, 1, 3, 3), (8, 16, 3, 4, 16), (64, 32, 7, 2, 2), (24, 20, 2, 7, 35),
+])
+def test_conv_winograd_all_cfgs(C, N, B, H, W):
+    """Winograd F(2x2,3x3) kernel == fp32 conv2d of the reference (within the same 1e-4 bound as the direct kernel),
+    every configuration, odd sizes (rows % 4, columns % 16, channel slices % 32 != 0), partial last super-group."""
+    ops = _ops()
+    x = _rand(B, C, H, W, seed=11)
+    w = _rand(N, C, 3, 3, seed=12, scale=(2.0 / (C * 9)) ** 0.5)
+    b = _rand(N, seed=13, scale=0.1)
+    ref = _nhwc(F.relu(F.conv2d(x, w, b, padding=1)))
+    xg = _nhwc(x).cuda()
+    for cid in ops.wino_cfgs():
+        plan = ops.WinoPlan(w.cuda(), b.cuda(), cid)
+        y = torch.full((B, H, W, N), float('nan'), device='cuda')
+        ops.conv_wino(xg, 0, plan, y, 0, relu=True)
+        err = (y.cpu() - ref).abs().max().item()
+        assert err <= _tol(ref), f'wino cfg {cid}: max err {err}'
+
+
+def test_conv_winograd_windows_no_relu_dgrad():
+    """Channel windows of wider buffers (bytes outside the window untouched), no bias / no ReLU, and the data-gradient
+    packing (== conv_transpose of the forward weight)."""
+    ops = _ops()
+    B, H, W, C, N = 2, 10, 19, 32, 64
+    xfull = _rand(B, 48, H, W, seed=14)
+    w = _rand(N, C, 3, 3, seed=15, scale=0.1)
+    ref = F.conv2d(xfull[:, 8:40], w, None, padding=1)
+    y0 = _rand(B, 96, H, W, seed=16)
+    exp = y0.clone(); exp[:, 16:80] = ref
+    for cid in ops.wino_cfgs():
+        y = _nhwc(y0).cuda()
+        ops.conv_wino(_nhwc(xfull).cuda(), 8, ops.WinoPlan(w.cuda(), None, cid), y, 16, relu=False)
+        got = y.cpu().permute(0, 3, 1, 2)
+        assert (got - exp).abs().max().item() <= _tol(exp), f'wino cfg {cid}'
+    dy = _rand(B, N, H, W, seed=17)
+    ref_dx = F.conv_transpose2d(dy, w, None, padding=1)
+    plan = ops.WinoPlan(w.cuda(), None, 0, dgrad=True)
+    assert (plan.C, plan.N) == (N, C)
+    dx = torch.full((B, H, W, C), float('nan'), device='cuda')
+    ops.conv_wino(_nhwc(dy).cuda(), 0, plan, dx, 0)
+    assert (dx.cpu() - _nhwc(ref_dx)).abs().max().item() <= _tol(ref_dx)
