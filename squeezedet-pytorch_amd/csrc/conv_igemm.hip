@@ -514,7 +514,9 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     const TilePos nxt = tile_pos(more ? tile + tstride : tile);
     pix_masks(nxt, okn);
     for (int cc = 0; cc < nchunks; ++cc) {
-      __syncthreads();                 // vmcnt(0): this stage's DMA has landed; all waves left the previous stage
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the stage's DMA has landed (explicit: the compiler
+                                                        // only tracks the issuing wave's own reads of DMA-written LDS)
+      __syncthreads();                 // ... and is published; all waves left the previous stage
       if (pending) { flush(ptp); pending = false; }
       const int last_i = 1 - (int)((unsigned)(cc + 1 - nchunks) >> 31);      // cc == nchunks - 1
       const bool last = last_i != 0;

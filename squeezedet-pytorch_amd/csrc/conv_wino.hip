@@ -48,7 +48,7 @@ __device__ __forceinline__ f32x4 wino_relu4(f32x4 v, float lo) {
 }
 
 template <int NT, int WV>
-__global__ __launch_bounds__(WV * 64, 1) void conv_wino_kernel(WinoArgs a) {
+__global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wino_kernel(WinoArgs a) {
   constexpr int NTHR = WV * 64;
   constexpr int BN = 16 * NT;
   constexpr int RP = 113;                     // slots per k-quad plane of the raw patch (108 used): 113*16 B = 16 mod 256, so the
@@ -63,7 +63,6 @@ __global__ __launch_bounds__(WV * 64, 1) void conv_wino_kernel(WinoArgs a) {
   float* const rawB = smem;                                 // [WV][256][4]
   float* const VB = rawB + WV * 256 * 4;                    // [WV][16][16][8]
   float* const UB = VB + WV * 2048;                         // [2][USLOTS][4]
-  float* const biasL = UB + 2 * USLOTS * 4;                 // [BN]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
@@ -151,7 +150,13 @@ __global__ __launch_bounds__(WV * 64, 1) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (tid < BN) biasL[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
+  // the slice's bias for this lane's 4 channels of every block (registers: with 4 waves the LDS is exactly two workgroups per CU)
+  f32x4 biasv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + 4 * g;
+    biasv[j] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const int ty = lr >> 3, tx = lr & 7;
   int o_off[4];
 #pragma unroll
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(WV * 64, 1) void conv_wino_kernel(WinoArgs a) {
       for (int px = 0; px < 4; ++px)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          f32x4 v = outv[px][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
+          f32x4 v = outv[px][j] + biasv[j];
           v = wino_relu4(v, relu_lo);
           *(f32x4*)(ybase + o_off[px] + j * 16) = v;
         }
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(WV * 64, 1) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (!valid || n0 + j * 16 + 4 * g >= a.N) continue;
-        f32x4 v = outv[px][j] + *(const f32x4*)(biasL + j * 16 + 4 * g);
+        f32x4 v = outv[px][j] + biasv[j];
         v = wino_relu4(v, relu_lo);
         *(f32x4*)(ybase + o_off[px] + j * 16) = v;
       }
@@ -216,7 +221,11 @@ __global__ __launch_bounds__(WV * 64, 1) void conv_wino_kernel(WinoArgs a) {
     const GPos nxt = group_pos(more ? tile + tstride : tile);
     pix_masks(nxt, okn);
     for (int cc = 0; cc < nchunks; ++cc) {
-      __syncthreads();                       // vmcnt(0): this stage's patch and U slice have landed; all waves left the previous U buffer
+      // this wave's share of the stage's DMA (patch + U slots) must have LANDED before the barrier publishes it to the other
+      // waves: the compiler only waits on vmcnt where the issuing wave itself reads DMA-written LDS, which says nothing
+      // about the slots other waves fetched
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                       // all waves left the previous U buffer
       if (pending) { flush(ptp); pending = false; }
       const int last_i = 1 - (int)((unsigned)(cc + 1 - nchunks) >> 31);
       const bool last = last_i != 0;
@@ -242,6 +251,11 @@ __global__ __launch_bounds__(WV * 64, 1) void conv_wino_kernel(WinoArgs a) {
           *(f32x4*)(vL + (i * 2 + 1) * 256) = (f32x4){v2.x, v2.y, v3.x, v3.y};
         }
       }
+      // The patch buffer is refilled (LDS-DMA, below) for the next chunk: its reads above must have returned, and neither
+      // the compiler nor the machine scheduler may move a DMA issue across this point (the DMA's LDS side is invisible to
+      // them).  The wait also publishes V to this wave's operand reads.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       const float* const uR = uR0 + ubuf * USLOTS * 4;
 
       // ---- 16 positions x 2 k-steps x NT MFMAs, software-pipelined over two operand sets (steps of 2 positions) ----
@@ -326,7 +340,7 @@ static int wino_num_cus() {
 template <int NT, int WV>
 static int launch_wino(WinoArgs a, hipStream_t stream) {
   constexpr int BN = 16 * NT, NTHR = WV * 64;
-  constexpr size_t lds = (size_t)(WV * 256 * 4 + WV * 2048 + 2 * 32 * BN * 4 + BN) * sizeof(float);
+  constexpr size_t lds = (size_t)(WV * 256 * 4 + WV * 2048 + 2 * 32 * BN * 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv_wino_kernel<NT, WV>;
   static int wgs_per_cu = 0;

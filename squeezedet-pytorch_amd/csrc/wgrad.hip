@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   int pb = blockIdx.x, buf = 0;
   if (pb < a.nblocks) dma_block(pb, 0);
   for (; pb < a.nblocks; pb += (int)gridDim.x) {
-    __syncthreads();                   // vmcnt(0) + barrier: this block's tiles landed, previous compute finished
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // explicit: every wave's share of the block's LDS-DMA has landed ...
+    __syncthreads();                   // ... before the barrier publishes it; previous compute finished
     const int nxt = pb + (int)gridDim.x;
     if (nxt < a.nblocks) dma_block(nxt, buf ^ 1);
     const float* dyT = dyB + buf * DSLOTS * 4;
@@ -692,7 +693,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_pooled_kernel(StemWgradArgs a)
       const int ntile = tile + (int)gridDim.x;
       const bool has_next = ntile < a.nblocks;
       const Tile nxt = tile_at(has_next ? ntile : tile);
-      __syncthreads();                       // previous tile's MFMAs left dyT / inB; this tile's patch has landed (vmcnt(0))
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch DMA has landed (explicit, see conv_igemm.hip)
+      __syncthreads();                       // previous tile's MFMAs left dyT / inB; the patch is published
       for (int idx = tid; idx < 128 * PN / 4; idx += 256) ((f32x4*)dyT)[idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
       __syncthreads();
 #pragma unroll
