@@ -86,7 +86,7 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                 ops.fire_expand(sq, 0, base.fused_expand_plan(i, fire, fcfg), out, 0)
             else:
                 ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, s, e1, npix)), out, 0, relu=True)
-                ops.conv(sq, 0, base.plan(f'{i}.expand3x3', fire.expand3x3, ops.choose_cfg(9, s, e3, npix)), out, e1, relu=True)
+                base.conv3x3(f'{i}.expand3x3', fire.expand3x3, sq, 0, out, e1, relu=True)
             if save:
                 saved[f'fire{i}'] = (a, sq, out)
             a = out
@@ -95,7 +95,7 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
     Bq, H, W, C = a.shape
     cd = base.convdet
     pred = torch.empty(Bq, H, W, cd.out_channels, device=a.device, dtype=torch.float32)
-    ops.conv(a, 0, base.plan('convdet', cd, ops.choose_cfg(9, C, cd.out_channels, Bq * H * W)), pred, 0, relu=False)
+    base.conv3x3('convdet', cd, a, 0, pred, 0, relu=False)
     if save:
         saved['convdet_in'] = a
         saved['drop_mask'] = drop_mask

@@ -90,6 +90,8 @@ class SqueezeDetBase(nn.Module):
         self.convdet = _ConvParams(convdet_in_channels(cfg.arch), cfg.anchors_per_grid * (cfg.num_classes + 5), 3, padding=1)
         self._plans = {}
         self._fused_plans = {}
+        self._wino_plans = {}
+        self.use_winograd = True                  # 3x3 forward convs: Winograd F(2x2,3x3) kernel where tuning.json says it is faster
         self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
         # inference forward: pool 2 / 3 folded into the following squeeze (ops.pool_squeeze).  Off by default: measured equal
         # to the two separate kernels (0.174 vs 0.18 ms) -- both are bound by the 9x L2 read amplification of the window gather
@@ -129,6 +131,31 @@ class SqueezeDetBase(nn.Module):
         p = ops.FusedExpandPlan(fire.expand1x1.weight, fire.expand1x1.bias, fire.expand3x3.weight, fire.expand3x3.bias, cfg_id)
         self._fused_plans[key] = (ver, p)
         return p
+
+    def wino_plan(self, name, mod, cfg_id, direction='fwd'):
+        """Transformed-weight cache of the Winograd 3x3 kernel (ops.WinoPlan), re-transformed in place when the parameter
+        changed."""
+        key = (name, cfg_id, direction)
+        ver = (mod.weight._version, mod.weight.data_ptr(), mod.bias._version, mod.bias.data_ptr())
+        hit = self._wino_plans.get(key)
+        if hit is not None:
+            if hit[0] != ver:
+                hit[1].repack(mod.weight, mod.bias, dgrad=(direction != 'fwd'))
+                self._wino_plans[key] = (ver, hit[1])
+            return hit[1]
+        p = ops.WinoPlan(mod.weight, mod.bias, cfg_id, dgrad=(direction != 'fwd'))
+        self._wino_plans[key] = (ver, p)
+        return p
+
+    def conv3x3(self, name, mod, x, x_coff, y, y_coff, relu):
+        """Forward 3x3 convolution of ``mod``: the Winograd kernel where the measured table prefers it, else the direct
+        implicit-GEMM kernel."""
+        Bq, H, W, _ = x.shape
+        C, N = mod.in_channels, mod.out_channels
+        wc = ops.choose_wino_cfg(C, N, Bq * H * W) if self.use_winograd else None
+        if wc is not None:
+            return ops.conv_wino(x, x_coff, self.wino_plan(name, mod, wc), y, y_coff, relu=relu)
+        return ops.conv(x, x_coff, self.plan(name, mod, ops.choose_cfg(9, C, N, Bq * H * W)), y, y_coff, relu=relu)
 
     def refresh_plans(self):
         """Re-pack every cached plan whose parameter changed since it was packed (after an optimizer step that

@@ -116,8 +116,15 @@ def _tuning():
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning.json')
         try:
             with open(path) as f:
-                _TUNING = {k: (int(v['cfg']) if not (k.startswith('F:') and v.get('separate_us', 0) and v['us'] >= v['separate_us']) else -1)
-                           for k, v in json.load(f).items()}
+                # F: (fused expand) and W: (Winograd) entries carry the time of the alternative they were measured against;
+                # -1 = the alternative was faster
+                def _pick(k, v):
+                    if k.startswith('F:') and v.get('separate_us', 0) and v['us'] >= v['separate_us']:
+                        return -1
+                    if k.startswith('W:') and v.get('direct_us', 0) and v['us'] >= v['direct_us']:
+                        return -1
+                    return int(v['cfg'])
+                _TUNING = {k: _pick(k, v) for k, v in json.load(f).items()}
         except (OSError, ValueError, KeyError):
             _TUNING = {}
     return _TUNING
@@ -388,6 +395,16 @@ class WinoPlan:
                                                  nat.stream_handle(src.device)), 'sqd_pack_wino_weight')
         self.bias = None if (bias is None or dgrad) else bias.detach().contiguous()
 
+    def repack(self, w_oihw, bias, dgrad=False):
+        """Re-transform into the same buffer after the parameter changed (pointer-stable: hipGraph replays stay valid)."""
+        src = w_oihw.detach()
+        if not src.is_contiguous():
+            raise ValueError('WinoPlan.repack: parameters must be contiguous')
+        nat.check(nat.lib().sqd_pack_wino_weight(nat.ptr(src), nat.ptr(self.w), src.shape[0], src.shape[1], self.Npad, int(dgrad),
+                                                 nat.stream_handle(src.device)), 'sqd_pack_wino_weight')
+        if self.bias is not None:
+            self.bias = bias.detach()
+
 
 def conv_wino(x, x_coff, plan, y, y_coff, relu=False):
     """y[..., y_coff:y_coff+N] = conv3x3(x[..., x_coff:x_coff+C]) (+bias) (ReLU), Winograd F(2x2,3x3) kernel."""
@@ -404,8 +421,10 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False):
     if _timer is not None:
         npix = B * H * W
         bn, wv = wino_cfgs()[plan.cfg_id % 1000]
-        br = _Bracket(f'conv_wino<{bn // 16},{wv}>', f'9tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * 9,
-                      4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * 9))
+        # flops = what the MFMA pipe executes (16 element-wise GEMMs per 2x2 tile = direct form / 2.25): the roofline
+        # fraction of this kernel is against that; bench.py also quotes the direct-form equivalent
+        br = _Bracket(f'conv_wino<{bn // 16},{wv}>', f'9tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * 4,
+                      4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * 16))
     rc = nat.lib().sqd_conv_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), B, H, W, plan.C, xp, x_coff,
                                      plan.N, plan.Npad, yp, y_coff, int(relu), plan.cfg_id, nat.stream_handle(x.device))
     nat.check(rc, 'sqd_conv_wino_fwd')

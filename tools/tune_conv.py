@@ -56,6 +56,23 @@ def time_cfg(taps, C, N, B, h, w, cid, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3      # us
 
 
+def time_wino(C, N, B, h, w, cid, reps=10):
+    wt = torch.randn(N, C, 3, 3, device='cuda') * 0.05
+    bias = torch.randn(N, device='cuda')
+    plan = ops.WinoPlan(wt, bias, cid)
+    x = torch.randn(B, h, w, C, device='cuda')
+    y = torch.empty(B, h, w, N, device='cuda')
+    for _ in range(2):
+        ops.conv_wino(x, 0, plan, y, 0, relu=True)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv_wino(x, 0, plan, y, 0, relu=True)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3      # us
+
+
 def fused_shapes(arch, B, H, W):
     """[(C, E, h, w)] of every Fire expand pair (inference forward, fused launch)."""
     out = set()
@@ -94,6 +111,7 @@ def main():
     ap.add_argument('--batch', type=int, default=20)
     ap.add_argument('--size', type=int, nargs=2, default=[384, 1248])
     ap.add_argument('--out', default=os.path.join(ROOT, 'squeezedet-pytorch_amd', 'tuning.json'))
+    ap.add_argument('--only', default='', help="'wino': keep the direct-kernel entries of the existing table, re-measure only the Winograd (W:) and fused-expand (F:) keys")
     args = ap.parse_args()
     B = args.batch
     table = {}
@@ -101,7 +119,7 @@ def main():
         table = json.load(open(args.out))
     tab = ops.cfg_table()
     print('configs:', {c: tab[c] + (ops.cfg_is_dma(c),) for c in tab})
-    for taps, C, N, h, w in shapes(args.arch, B, *args.size):
+    for taps, C, N, h, w in ([] if args.only == 'wino' else shapes(args.arch, B, *args.size)):
         res = []
         for cid, (t, kc, px, bn) in tab.items():
             if t != taps:
@@ -128,6 +146,30 @@ def main():
                       'all': {str(c): round(u, 1) for u, c in res}}
         print(f'{key:24s} best cfg {best:4d} {tab[best % 1000]}  {best_us:8.1f} us  {gf / (best_us * 1e-6) / 1e3:6.1f} TF/s   '
               + ' '.join(f'{c}:{u:.0f}' for u, c in res[:5]), flush=True)
+    # Winograd F(2x2,3x3) form of every 3x3 shape (key W:C:N:npix), compared with the best direct configuration above
+    for taps, C, N, h, w in shapes(args.arch, B, *args.size):
+        if taps != 9 or C % 8:
+            continue
+        res = []
+        for cid, (bn, wv) in ops.wino_cfgs().items():
+            if -(-N // bn) * bn > 2 * N and bn > 16:
+                continue
+            for cap in (0, 1):
+                try:
+                    res.append((time_wino(C, N, B, h, w, cid + 1000 * cap), cid + 1000 * cap))
+                except Exception as e:  # noqa: BLE001
+                    print('skip wino', (C, N, h, w), cid, e)
+        if not res:
+            continue
+        res.sort()
+        best_us, best = res[0]
+        npix = B * h * w
+        direct = table.get(f'9:{C}:{N}:{npix}', {}).get('us', 0)
+        gf = 2.0 * npix * N * C * 9 / 1e9
+        table[f'W:{C}:{N}:{npix}'] = {'cfg': best, 'us': round(best_us, 1), 'tflops_effective': round(gf / (best_us * 1e-6) / 1e3, 1),
+                                     'direct_us': direct, 'all': {str(c): round(u, 1) for u, c in res}}
+        print(f'W:{C}:{N}:{npix:<14d} best wino cfg {best:4d} {best_us:8.1f} us  {gf / (best_us * 1e-6) / 1e3:6.1f} eff TF/s  (direct {direct:.1f} us)  '
+              + ' '.join(f'{c}:{u:.0f}' for u, c in res[:6]), flush=True)
     # fused Fire expand (key F:C:E:npix): compared with the sum of the two separate launches of the same layer
     for C, E, h, w in fused_shapes(args.arch, B, *args.size):
         res = []
@@ -142,7 +184,9 @@ def main():
         res.sort()
         best_us, best = res[0]
         npix = B * h * w
-        sep = table.get(f'1:{C}:{E}:{npix}', {}).get('us', 0) + table.get(f'9:{C}:{E}:{npix}', {}).get('us', 0)
+        d3 = table.get(f'9:{C}:{E}:{npix}', {}).get('us', 0)
+        w3 = table.get(f'W:{C}:{E}:{npix}', {}).get('us', 0)
+        sep = table.get(f'1:{C}:{E}:{npix}', {}).get('us', 0) + (min(d3, w3) if (d3 and w3) else (d3 or w3))
         gf = 2.0 * npix * E * C * 10 / 1e9
         table[f'F:{C}:{E}:{npix}'] = {'cfg': best, 'us': round(best_us, 1), 'tflops': round(gf / (best_us * 1e-6) / 1e3, 1),
                                      'separate_us': round(sep, 1), 'all': {str(c): round(u, 1) for u, c in res}}
