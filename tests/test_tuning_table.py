@@ -22,6 +22,11 @@ def test_every_tuned_entry_names_a_compiled_configuration(table):
     assert len(tab) >= 70
     for key, v in table.items():
         cid = int(v["cfg"])
+        if key.startswith("W:"):                                                  # Winograd family: its own configuration list
+            _, C, N, npix = key.split(":")
+            assert cid % 1000 in ops.wino_cfgs() and cid // 1000 <= 8 and int(C) % 8 == 0, key
+            assert v["us"] > 0 and "direct_us" in v
+            continue
         assert 0 <= cid % 1000 < len(tab) and cid // 1000 <= 8, key
         taps = tab[cid % 1000][0]
         if key.startswith("F:"):
@@ -72,3 +77,18 @@ def test_choose_cfg_fallbacks():
     f = ops.choose_fused_cfg(64, 256, 20 * 24 * 78)
     assert f is not None and f % 1000 in ops.fused_expand_cfgs(256)
     assert ops.pool_squeeze_ok(128, 32) and ops.pool_squeeze_ok(256, 48) and not ops.pool_squeeze_ok(256, 192)
+
+
+def test_winograd_choice_follows_the_measured_comparison(table):
+    """W: entries win only where they were measured faster than the best direct configuration of the same shape."""
+    for key, v in table.items():
+        if not key.startswith("W:"):
+            continue
+        _, C, N, npix = key.split(":")
+        got = ops.choose_wino_cfg(int(C), int(N), int(npix))
+        if v["direct_us"] and v["us"] >= v["direct_us"]:
+            assert got is None, key
+        else:
+            assert got == int(v["cfg"]), key
+    assert ops.choose_wino_cfg(20, 64, 1000) is None                              # C % 8 != 0: direct kernel only
+    assert ops.choose_wino_cfg(24, 40, 1234) is None                              # never measured: direct kernel
