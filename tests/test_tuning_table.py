@@ -74,8 +74,16 @@ def test_choose_cfg_fallbacks():
     # fused expand: measured slower on this shape -> None (two separate launches); unknown half-width not a multiple of 16 -> None
     assert ops.choose_fused_cfg(96, 384, 20 * 24 * 78) is None
     assert ops.choose_fused_cfg(16, 24, 1000) is None
-    f = ops.choose_fused_cfg(64, 256, 20 * 24 * 78)
-    assert f is not None and f % 1000 in ops.fused_expand_cfgs(256)
+    # every measured F: entry: fused where it beat the two separate launches (expand1x1 + the faster of direct / Winograd 3x3)
+    with open(os.path.join(ROOT, "squeezedet-pytorch_amd", "tuning.json")) as fh:
+        for key, v in json.load(fh).items():
+            if key.startswith("F:"):
+                _, C, E, npix = key.split(":")
+                f = ops.choose_fused_cfg(int(C), int(E), int(npix))
+                if v["separate_us"] and v["us"] >= v["separate_us"]:
+                    assert f is None, key
+                else:
+                    assert f is not None and f % 1000 in ops.fused_expand_cfgs(int(E)), key
     assert ops.pool_squeeze_ok(128, 32) and ops.pool_squeeze_ok(256, 48) and not ops.pool_squeeze_ok(256, 192)
 
 
