@@ -136,12 +136,15 @@ int sqd_fire_expand_fwd(const float* x, const float* w_packed, const float* bias
 /* Winograd F(2x2,3x3) form of the 3x3 / pad 1 convolution (same layers as sqd_conv_fwd with a 3x3 configuration: Fire
  * expand3x3, src/model/squeezedet.py:14,20-22; ConvDet, :73-75,83): y[..., y_coff : y_coff+N] = (ReLU)(conv3x3(x[...,
  * x_coff : x_coff+C]) + bias), fp32, within fp32 rounding of the direct form.  u_packed = sqd_pack_wino_weight output
- * ([C/8][16][Npad][8], Npad = N rounded up to the configuration's slice width); C % 8 == 0.  cfg_id in
+ * (C/8 * 16 * Npad * 8 floats, Npad = N rounded up to the configuration's slice width); C % 8 == 0.  Epilogue options as
+ * in sqd_conv_fwd, for the data-gradient use: accumulate != 0 adds to y; ymul / ymask (NULL or NHWC tensors with the SAME
+ * pixel pitch and channel offset as y) multiply the result (dropout) / zero it where ymask <= 0 (ReLU backward).  cfg_id in
  * [0, sqd_wino_num_cfgs()) (+ 1000 * k = workgroups-per-CU cap); sqd_wino_cfg_info reports slice width and waves. */
 int sqd_wino_num_cfgs(void);
 int sqd_wino_cfg_info(int cfg_id, int* bn, int* waves);
-int sqd_conv_wino_fwd(const float* x, const float* u_packed, const float* bias, float* y, int B, int H, int W, int C,
-                      int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu, int cfg_id, void* stream);
+int sqd_conv_wino_fwd(const float* x, const float* u_packed, const float* bias, float* y, const float* ymask, const float* ymul,
+                      int B, int H, int W, int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
+                      int accumulate, int cfg_id, void* stream);
 /* Transformed weights U = G g G^T of an OIHW [No][Ci][3][3] parameter into the layout above; dgrad != 0 packs the
  * data-gradient orientation (in/out channels swapped, taps flipped). */
 int sqd_pack_wino_weight(const float* w_oihw, float* u_packed, int No, int Ci, int Npad, int dgrad, void* stream);

@@ -47,7 +47,7 @@ _SIGNATURES = {
     'sqd_kitti_ap': [c_i] + [c_p] * 12,
     'sqd_wino_num_cfgs': [],
     'sqd_wino_cfg_info': [c_i, c_p, c_p],
-    'sqd_conv_wino_fwd': [c_p] * 4 + [c_i] * 12 + [c_p],
+    'sqd_conv_wino_fwd': [c_p] * 6 + [c_i] * 13 + [c_p],
     'sqd_pack_wino_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_encode_gt_fwd': [c_p] * 8 + [c_i, c_i, c_i, c_i, c_p],
     'sqd_loss_fwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],

@@ -32,8 +32,7 @@ def run_backbone_backward(base, saved, dpred):
     assert layers[last][0] == 'fire'
     out_last = saved[f'fire{last}'][2]
     dA = torch.empty_like(out_last)
-    ops.conv(dpred, 0, base.plan('convdet', cd, ops.choose_cfg(9, ncd, cin_cd, npix), 'dgrad'), dA, 0,
-             ymul=saved['drop_mask'], ymask=out_last)
+    base.dgrad3x3('convdet', cd, dpred, 0, dA, ymul=saved['drop_mask'], ymask=out_last)
     for i in range(last, 1, -1):
         l = layers[i]
         if l[0] == 'pool':
@@ -54,8 +53,7 @@ def run_backbone_backward(base, saved, dpred):
         grads[pre + 'expand3x3.weight'], grads[pre + 'expand3x3.bias'] = ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9)
         dSq = torch.empty_like(sq)
         ops.conv(dA, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, e1, s, npix), 'dgrad'), dSq, 0)
-        ops.conv(dA, e1, base.plan(f'{i}.expand3x3', fire.expand3x3, ops.choose_cfg(9, e3, s, npix), 'dgrad'), dSq, 0,
-                 accumulate=True, ymask=sq)
+        base.dgrad3x3(f'{i}.expand3x3', fire.expand3x3, dA, e1, dSq, accumulate=True, ymask=sq)
         grads[pre + 'squeeze.weight'], grads[pre + 'squeeze.bias'] = ops.conv_wgrad(dSq, 0, s, x_in, 0, cin, 1)
         dIn = torch.empty_like(x_in)
         prev_is_fire = layers[i - 1][0] == 'fire'

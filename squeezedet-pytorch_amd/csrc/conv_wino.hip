@@ -31,7 +31,8 @@ struct WinoArgs {
   int B, H, W;
   int C, x_pitch, x_coff;
   int N, Npad, y_pitch, y_coff;
-  int relu;
+  int relu, accumulate;         // epilogue: y += result
+  const float* ymask; const float* ymul;   // epilogue (same pitch / channel offset as y): multiply by ymul (dropout), zero where ymask <= 0
   int gxn, gyn;                 // column / row groups per image
   int ngroups, ntiles;          // B*gyn*gxn groups; ntiles = super-groups of WV groups
   int nslices, gx;              // persistent grid: gx tile streams x nslices channel slices
@@ -187,8 +188,21 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
   bool pending = false;
   GPos ptp = cur;
 
+  const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
+  auto epi = [&](f32x4 v, int j, float* dst, const float* mul, const float* mask) {
+    v += biasv[j];
+    if (acc_i) v += *(const f32x4*)dst;
+    if (has_mul) v *= *(const f32x4*)mul;
+    if (has_mask) {
+      const f32x4 m = *(const f32x4*)mask;
+      v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    }
+    *(f32x4*)dst = wino_relu4(v, relu_lo);
+  };
   auto flush = [&](const GPos gp) {
     float* ybase = a.y + gp.p0 * a.y_pitch + a.y_coff + n0;
+    const float* mulbase = a.ymul + gp.p0 * a.y_pitch + a.y_coff + n0;     // dereferenced only when present
+    const float* maskbase = a.ymask + gp.p0 * a.y_pitch + a.y_coff + n0;
     const bool whole = gp.y0 + 4 <= a.H && gp.x0 + 16 <= a.W && n0 + BN <= a.N;
     if (!gp.valid) return;
     if (whole) {
@@ -196,9 +210,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       for (int px = 0; px < 4; ++px)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          f32x4 v = outv[px][j] + biasv[j];
-          v = wino_relu4(v, relu_lo);
-          *(f32x4*)(ybase + o_off[px] + j * 16) = v;
+          const int off = o_off[px] + j * 16;
+          epi(outv[px][j], j, ybase + off, mulbase + off, maskbase + off);
         }
       return;
     }
@@ -208,9 +221,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (!valid || n0 + j * 16 + 4 * g >= a.N) continue;
-        f32x4 v = outv[px][j] + biasv[j];
-        v = wino_relu4(v, relu_lo);
-        *(f32x4*)(ybase + o_off[px] + j * 16) = v;
+        const int off = o_off[px] + j * 16;
+        epi(outv[px][j], j, ybase + off, mulbase + off, maskbase + off);
       }
     }
   };
@@ -423,9 +435,9 @@ extern "C" int sqd_wino_cfg_info(int cfg_id, int* bn, int* waves) {
   return SQD_OK;
 }
 
-extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const float* bias, float* y, int B, int H, int W,
-                                 int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
-                                 int cfg_id, void* stream) {
+extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const float* bias, float* y, const float* ymask,
+                                 const float* ymul, int B, int H, int W, int C, int x_pitch, int x_coff, int N, int Npad,
+                                 int y_pitch, int y_coff, int relu, int accumulate, int cfg_id, void* stream) {
   SQD_CHECK_ARG(x && u_packed && y);
   SQD_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && N > 0);
   SQD_CHECK_ARG(C % 8 == 0 && N % 4 == 0 && Npad >= N);
@@ -438,6 +450,7 @@ extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const fl
   a.x = x; a.u = u_packed; a.bias = bias; a.y = y;
   a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff; a.relu = relu; a.wg_cap = cap;
+  a.accumulate = accumulate; a.ymask = ymask; a.ymul = ymul;
   hipStream_t s = (hipStream_t)stream;
   switch (cfg_id) {
     case 0: return launch_wino<2, 8>(a, s);

@@ -157,6 +157,18 @@ class SqueezeDetBase(nn.Module):
             return ops.conv_wino(x, x_coff, self.wino_plan(name, mod, wc), y, y_coff, relu=relu)
         return ops.conv(x, x_coff, self.plan(name, mod, ops.choose_cfg(9, C, N, Bq * H * W)), y, y_coff, relu=relu)
 
+    def dgrad3x3(self, name, mod, dy, dy_coff, dx, accumulate=False, ymask=None, ymul=None):
+        """dx (=|+=) data gradient of ``mod``'s 3x3 convolution (transposed, tap-flipped weights), ymul / ymask fused into the
+        epilogue; Winograd kernel where the measured table prefers it."""
+        Bq, H, W, _ = dy.shape
+        C, N = mod.out_channels, mod.in_channels                  # the dgrad convolves dY (out channels) into dX (in channels)
+        wc = ops.choose_wino_cfg(C, N, Bq * H * W) if self.use_winograd else None
+        same_geom = all(t is None or tuple(t.shape) == tuple(dx.shape) for t in (ymask, ymul))
+        if wc is not None and same_geom:
+            return ops.conv_wino(dy, dy_coff, self.wino_plan(name, mod, wc, 'dgrad'), dx, 0, accumulate=accumulate, ymask=ymask, ymul=ymul)
+        return ops.conv(dy, dy_coff, self.plan(name, mod, ops.choose_cfg(9, C, N, Bq * H * W), 'dgrad'), dx, 0,
+                        accumulate=accumulate, ymask=ymask, ymul=ymul)
+
     def refresh_plans(self):
         """Re-pack every cached plan whose parameter changed since it was packed (after an optimizer step that
         is all of them) with ONE batched kernel launch instead of one launch per plan."""

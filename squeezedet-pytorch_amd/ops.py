@@ -406,8 +406,9 @@ class WinoPlan:
             self.bias = bias.detach()
 
 
-def conv_wino(x, x_coff, plan, y, y_coff, relu=False):
-    """y[..., y_coff:y_coff+N] = conv3x3(x[..., x_coff:x_coff+C]) (+bias) (ReLU), Winograd F(2x2,3x3) kernel."""
+def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=None, ymul=None):
+    """y[..., y_coff:y_coff+N] (=|+=) conv3x3(x[..., x_coff:x_coff+C]) (+bias) (* ymul) (zero where ymask <= 0) (ReLU),
+    Winograd F(2x2,3x3) kernel.  ``ymask`` / ``ymul`` are read through y's own channel window (same shape as y)."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
     B, H, W, xp = x.shape
     if tuple(y.shape[:3]) != (B, H, W):
@@ -425,8 +426,14 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False):
         # fraction of this kernel is against that; bench.py also quotes the direct-form equivalent
         br = _Bracket(f'conv_wino<{bn // 16},{wv}>', f'9tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * 4,
                       4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * 16))
-    rc = nat.lib().sqd_conv_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), B, H, W, plan.C, xp, x_coff,
-                                     plan.N, plan.Npad, yp, y_coff, int(relu), plan.cfg_id, nat.stream_handle(x.device))
+    for t, nm in ((ymask, 'ymask'), (ymul, 'ymul')):
+        if t is not None:
+            _check_nhwc(t, nm)
+            if tuple(t.shape) != tuple(y.shape):
+                raise ValueError(f'conv_wino: {nm} must have the shape of y')
+    rc = nat.lib().sqd_conv_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(ymask), nat.ptr(ymul),
+                                     B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff, int(relu), int(accumulate),
+                                     plan.cfg_id, nat.stream_handle(x.device))
     nat.check(rc, 'sqd_conv_wino_fwd')
     if br is not None:
         br.done()

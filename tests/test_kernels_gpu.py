@@ -244,3 +244,24 @@ def test_conv_winograd_windows_no_relu_dgrad():
     dx = torch.full((B, H, W, C), float('nan'), device='cuda')
     ops.conv_wino(_nhwc(dy).cuda(), 0, plan, dx, 0)
     assert (dx.cpu() - _nhwc(ref_dx)).abs().max().item() <= _tol(ref_dx)
+
+
+def test_conv_winograd_dgrad_epilogue():
+    """The epilogue options the backward uses: accumulate into y, dropout scale (ymul) and ReLU-backward mask (ymask) read
+    through y's own channel window -- same semantics as sqd_conv_fwd."""
+    ops = _ops()
+    B, H, W, C, N = 2, 9, 21, 64, 32
+    dy = _rand(B, C, H, W, seed=21)
+    w = _rand(C, N, 3, 3, seed=22, scale=0.1)               # forward weight of a conv N -> C; its dgrad maps C -> N
+    ref = F.conv_transpose2d(dy, w, None, padding=1)
+    y0 = _rand(B, N, H, W, seed=23)
+    mul = _rand(B, N, H, W, seed=24).abs() + 0.5
+    mask = _rand(B, N, H, W, seed=25)
+    exp = (y0 + ref) * mul * (mask > 0)
+    for cid in ops.wino_cfgs():
+        plan = ops.WinoPlan(w.cuda(), None, cid, dgrad=True)
+        y = _nhwc(y0).cuda()
+        ops.conv_wino(_nhwc(dy).cuda(), 0, plan, y, 0, accumulate=True, ymul=_nhwc(mul).cuda(), ymask=_nhwc(mask).cuda())
+        assert (y.cpu() - _nhwc(exp)).abs().max().item() <= _tol(exp), f'wino cfg {cid}'
+    with pytest.raises(ValueError):
+        ops.conv_wino(_nhwc(dy).cuda(), 0, plan, y, 0, ymask=torch.zeros(B, H, W, N + 4, device='cuda'))
