@@ -39,7 +39,6 @@ struct WinoArgs {
   int wg_cap;
 };
 
-__device__ __attribute__((aligned(16))) float wino_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 typedef __attribute__((address_space(3))) void* lds_ptr_w_t;
 
 __device__ __forceinline__ f32x4 wino_relu4(f32x4 v, float lo) {
@@ -50,6 +49,7 @@ __device__ __forceinline__ f32x4 wino_relu4(f32x4 v, float lo) {
 
 template <int NT, int WV>
 __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wino_kernel(WinoArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)    // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
   constexpr int NTHR = WV * 64;
   constexpr int BN = 16 * NT;
   constexpr int RP = 113;                     // slots per k-quad plane of the raw patch (108 used): 113*16 B = 16 mod 256, so the
@@ -77,7 +77,13 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
   const int wv_s = __builtin_amdgcn_readfirstlane(wv);
 
   // ---- per-lane DMA slots ----
-  int r_off[RAW_IT], r_key[RAW_IT];
+  // Both DMA streams go through buffer resources: address = resource base + wave-uniform SGPR offset (group origin /
+  // K chunk) + per-lane 32-bit offset, so a stage's DMA issue costs no vector instruction at all, and a lane whose slot
+  // lies outside the image carries an offset beyond the resource's range -- the hardware range check then returns zeros
+  // (the zero padding of the convolution) without touching memory.  Only the per-lane offset is range-checked, the SGPR
+  // offset is not (MI355X_MICROARCH.md buffer addressing), so the range only has to exceed any in-patch offset.
+  constexpr unsigned OOB = 0x80000000u;
+  int r_offB[RAW_IT], r_key[RAW_IT];                        // byte offset inside the patch (padding slots: 0), row << 8 | col (-1 = padding)
 #pragma unroll
   for (int it = 0; it < RAW_IT; ++it) {
     const int slot = it * 64 + lane;
@@ -85,23 +91,23 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
     const bool real = kq < 2 && pix < 108;
     const int r = pix / 18, c = pix - r * 18;
     r_key[it] = real ? (r << 8 | c) : -1;
-    r_off[it] = real ? (r * a.W + c) * a.x_pitch + 4 * kq : 0;
+    r_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * kq) * 4 : 0;
   }
-  int u_off[U_IT];
+  int u_offB[U_IT];
 #pragma unroll
   for (int it = 0; it < U_IT; ++it) {
     const int slot = it * NTHR + tid;
     const int pp = slot / (4 * BN), rem = slot - pp * (4 * BN);     // position pair, 16-byte slot inside the slice's run
-    u_off[it] = (pp * a.Npad + n0) * 16 + rem * 4;
+    u_offB[it] = ((pp * a.Npad + n0) * 16 + rem * 4) * 4;
   }
-  const long long u_chunk = (long long)16 * a.Npad * 8;
+  const unsigned u_chunkB = 16u * a.Npad * 8u * 4u;
+  // patch resource: based one halo row + one halo column BEFORE the window's first element, so every group's SGPR offset
+  // (p0 * pitch * 4, host-checked < 4 GiB) is non-negative
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + a.x_coff - (long long)(a.W + 1) * a.x_pitch), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, 0x7ffffff0, 0x00020000);
 
-  struct GPos { int y0, x0, inner, valid; long long p0; const float* xorg; };
-  auto gp_sel = [](bool c, const GPos& u, const GPos& v) {
-    GPos r; r.y0 = c ? u.y0 : v.y0; r.x0 = c ? u.x0 : v.x0; r.inner = c ? u.inner : v.inner; r.valid = c ? u.valid : v.valid;
-    r.p0 = c ? u.p0 : v.p0; r.xorg = c ? u.xorg : v.xorg;
-    return r;
-  };
+  struct GPos { int y0, x0, inner, valid; long long p0; unsigned soff; };
   auto group_pos = [&](int t) {                              // this wave's group of super-group t (all wave-uniform)
     GPos gp;
     int q = t * WV + wv_s;
@@ -111,38 +117,34 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
     const int gyi = q % a.gyn; const int b = q / a.gyn;
     gp.y0 = gyi * 4; gp.x0 = gxi * 16;
     gp.p0 = ((long long)b * a.H + gp.y0) * a.W + gp.x0;
-    gp.xorg = a.x + (gp.p0 - a.W - 1) * a.x_pitch + a.x_coff;
+    gp.soff = (unsigned)(gp.p0 * a.x_pitch * 4);             // byte offset of the patch origin from the resource base
     gp.inner = (int)(((unsigned)(-gp.y0) & (unsigned)(gp.y0 + 4 - a.H) & (unsigned)(-gp.x0) & (unsigned)(gp.x0 + 16 - a.W)) >> 31);
     return gp;
   };
-  auto pix_masks = [&](const GPos gp, unsigned long long (&m)[RAW_IT]) {
+  // per-lane patch offsets of the group whose stages are being fetched: evaluated once per group (interior groups: the
+  // plain offsets), out-of-image slots -> OOB
+  int r_offG[RAW_IT];
+  auto group_offsets = [&](const GPos gp) {
     if (gp.inner) {
 #pragma unroll
-      for (int it = 0; it < RAW_IT; ++it) m[it] = ~0ull;
+      for (int it = 0; it < RAW_IT; ++it) r_offG[it] = r_offB[it];
       return;
     }
 #pragma unroll
     for (int it = 0; it < RAW_IT; ++it) {
       const int key = r_key[it];
       const bool ok = key >= 0 && (unsigned)(gp.y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(gp.x0 + (key & 255) - 1) < (unsigned)a.W;
-      m[it] = __builtin_amdgcn_ballot_w64(ok);
+      r_offG[it] = ok ? r_offB[it] : (int)OOB;
     }
   };
-  const unsigned long long zp = (unsigned long long)(const void*)wino_zero_page;
-  const unsigned zp_lo = (unsigned)zp, zp_hi = (unsigned)(zp >> 32);
   float* const rawW = rawB + wv_s * 256 * 4;                 // this wave's raw patch / V image
   float* const VW = VB + wv_s * 2048;
-  auto dma_raw_one = [&](int it, const GPos gp, unsigned long long okmask, int cc) {
-    const float* src = gp.xorg + cc * 8 + r_off[it];
-    const unsigned long long p = (unsigned long long)(const void*)src;
-    unsigned lo = (unsigned)p, hi = (unsigned)(p >> 32);
-    asm volatile("v_cndmask_b32 %0, %2, %0, %4\n\tv_cndmask_b32 %1, %3, %1, %4" : "+v"(lo), "+v"(hi) : "v"(zp_lo), "v"(zp_hi), "s"(okmask));
-    src = (const float*)(const void*)(((unsigned long long)hi << 32) | lo);
-    __builtin_amdgcn_global_load_lds(src, (lds_ptr_w_t)(rawW + it * 64 * 4), 16, 0, 0);
+  auto dma_raw_one = [&](int it, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_w_t)(rawW + it * 64 * 4), 16, r_offG[it], (int)soff, 0, 0);
   };
   auto dma_u_one = [&](int it, int cc, int buf) {
-    const float* src = a.u + cc * u_chunk + u_off[it];
-    __builtin_amdgcn_global_load_lds(src, (lds_ptr_w_t)(UB + (buf * USLOTS + it * NTHR + wv_s * 64) * 4), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ures, (lds_ptr_w_t)(UB + (buf * USLOTS + it * NTHR + wv_s * 64) * 4), 16, u_offB[it],
+                                             (int)(cc * u_chunkB), 0, 0);
   };
 
   f32x4 acc[16][NT], outv[4][NT];
@@ -176,12 +178,9 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
   const float* const uR0 = UB + g * 64 + lr * 4;
 
   GPos cur = group_pos(tile);
-  unsigned long long okc[RAW_IT], okn[RAW_IT];
+  group_offsets(cur);
 #pragma unroll
-  for (int it = 0; it < RAW_IT; ++it) { okc[it] = 0; okn[it] = 0; }
-  pix_masks(cur, okc);
-#pragma unroll
-  for (int it = 0; it < RAW_IT; ++it) dma_raw_one(it, cur, okc[it], 0);
+  for (int it = 0; it < RAW_IT; ++it) dma_raw_one(it, cur.soff);
 #pragma unroll
   for (int it = 0; it < U_IT; ++it) dma_u_one(it, 0, 0);
   int ubuf = 0;
@@ -231,7 +230,6 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
     const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);
     const bool more = more_i != 0;
     const GPos nxt = group_pos(more ? tile + tstride : tile);
-    pix_masks(nxt, okn);
     for (int cc = 0; cc < nchunks; ++cc) {
       // this wave's share of the stage's DMA (patch + U slots) must have LANDED before the barrier publishes it to the other
       // waves: the compiler only waits on vmcnt where the issuing wave itself reads DMA-written LDS, which says nothing
@@ -242,10 +240,10 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       const int last_i = 1 - (int)((unsigned)(cc + 1 - nchunks) >> 31);
       const bool last = last_i != 0;
       const int ncc = last ? 0 : cc + 1;
-      const GPos ntp = gp_sel(last, nxt, cur);
-      unsigned long long dm[RAW_IT];
-#pragma unroll
-      for (int it = 0; it < RAW_IT; ++it) dm[it] = last ? okn[it] : okc[it];
+      // the stage fetched during this chunk: the next K chunk of this group, or (last chunk) chunk 0 of the next group,
+      // whose per-lane offsets replace this group's now (its own last stage is already in LDS)
+      if (last) group_offsets(nxt);
+      const unsigned nsoff = (last ? nxt.soff : cur.soff) + (unsigned)ncc * 32u;
 
       // ---- input transform: V = B^T d B for (tile tt, channels 2cp, 2cp+1) ----
       {
@@ -290,7 +288,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 #pragma unroll
         for (int q = 0; q < NDMA; ++q) {
           if (q * NSTEP / NDMA != step) continue;
-          if (q < RAW_IT) dma_raw_one(q, ntp, dm[q < RAW_IT ? q : 0], ncc);
+          if (q < RAW_IT) dma_raw_one(q < RAW_IT ? q : 0, nsoff);
           else dma_u_one(q - RAW_IT, ncc, ubuf ^ 1);
         }
         if (step & 1) {
@@ -311,17 +309,25 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       if (last) {                            // inverse transform Y = A^T M A in registers; stored after the next barrier
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          f32x4 s[4][2];
+          // on register pairs (f32x2): adds AND subtracts then compile to one v_pk_add_f32 per pair (a 4-wide subtract
+          // would be four scalar v_sub_f32)
+          auto inv = [&](auto half, auto put) {             // half(v): the register pair to work on; put(px, y): store it
+            f32x2 s[4][2];
 #pragma unroll
-          for (int xi = 0; xi < 4; ++xi) {
-            s[xi][0] = acc[xi * 4 + 0][j] + acc[xi * 4 + 1][j] + acc[xi * 4 + 2][j];
-            s[xi][1] = acc[xi * 4 + 1][j] - acc[xi * 4 + 2][j] - acc[xi * 4 + 3][j];
-          }
+            for (int xi = 0; xi < 4; ++xi) {
+              const f32x2 m0 = half(acc[xi * 4 + 0][j]), m1 = half(acc[xi * 4 + 1][j]);
+              const f32x2 m2 = half(acc[xi * 4 + 2][j]), m3 = half(acc[xi * 4 + 3][j]);
+              s[xi][0] = m0 + m1 + m2;
+              s[xi][1] = m1 - (m2 + m3);
+            }
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            outv[0 * 2 + b][j] = s[0][b] + s[1][b] + s[2][b];
-            outv[1 * 2 + b][j] = s[1][b] - s[2][b] - s[3][b];
-          }
+            for (int b = 0; b < 2; ++b) {
+              put(0 * 2 + b, s[0][b] + s[1][b] + s[2][b]);
+              put(1 * 2 + b, s[1][b] - (s[2][b] + s[3][b]));
+            }
+          };
+          inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { outv[px][j].lo = y; });
+          inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { outv[px][j].hi = y; });
 #pragma unroll
           for (int p = 0; p < 16; ++p) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -332,11 +338,10 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
     if (!more) break;
     tile += tstride;
     cur = nxt;
-#pragma unroll
-    for (int it = 0; it < RAW_IT; ++it) okc[it] = okn[it];
   }
   if (pending) flush(ptp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 static int wino_num_cus() {
@@ -443,7 +448,9 @@ extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const fl
   SQD_CHECK_ARG(C % 8 == 0 && N % 4 == 0 && Npad >= N);
   SQD_CHECK_ARG(x_pitch % 4 == 0 && x_coff % 4 == 0 && y_pitch % 4 == 0 && y_coff % 4 == 0);
   SQD_CHECK_ARG(x_coff >= 0 && x_coff + C <= x_pitch && y_coff >= 0 && y_coff + N <= y_pitch);
-  SQD_CHECK_ARG((long long)W * 6 * (x_pitch > y_pitch ? x_pitch : y_pitch) < (1ll << 31));    // 32-bit lane offsets inside a group
+  SQD_CHECK_ARG((long long)W * 6 * (x_pitch > y_pitch ? x_pitch : y_pitch) * 4 < (1ll << 30));   // per-lane byte offsets inside a group
+  SQD_CHECK_ARG((long long)B * H * W * x_pitch * 4 < (1ll << 32) - (1ll << 30));                   // 32-bit SGPR byte offset of a group origin
+  SQD_CHECK_ARG((long long)(C >> 3) * 16 * Npad * 8 * 4 < (1ll << 32));
   const int cap = cfg_id / 1000; cfg_id %= 1000;
   SQD_CHECK_ARG(cfg_id >= 0 && cfg_id < kNumWinoCfgs);
   WinoArgs a{};
