@@ -259,9 +259,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 // vmcnt(0) retires the DMA, the barrier publishes it and frees the other buffer).  The DMA writes
 // 64 consecutive 16-byte slots per wave instruction (wave-uniform base + lane*16), which is exactly the
 // k-quad-major image when the slot index space is [plane][padded row]; out-of-image halo pixels and
-// padded rows read from a zero page so the image needs no conditional writes.
+// padded rows are zero-filled by the buffer range check (below) so the image needs no conditional writes.
 // ---------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) float sqd_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -282,6 +281,7 @@ __device__ __forceinline__ f32x4 sqd_relu4(f32x4 v, float lo) {      // lo (wave
 // squeeze tile, and the 1x1 outputs' stores drain under the 3x3's matrix work.
 template <int TAPS, int KC, int MT, int NT, int WM, int MINW, bool FUSE, bool WSTAT>
 __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)    // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
   // WSTAT: the whole K fits one chunk (C <= KC), the weight slice is loaded once and stays in LDS (launch-time property
   // made a template flag so that the tap loop below contains no branch at all)
   static_assert(!FUSE || (TAPS == 9 && (NT % 2) == 0), "fused expand: 3x3 tiles with an even number of channel groups");
@@ -317,12 +317,15 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 
   const int wm_s = __builtin_amdgcn_readfirstlane(wm);  // wave index as a scalar: the LDS-DMA destinations stay in SGPRs
 
-  // Tile-independent part of every lane's DMA slots.  a_off is the lane's 32-bit element offset from the tile's
-  // origin pointer (3x3: halo pixel (y0-1, x0-1); 1x1: first pixel), so an interior tile issues its DMA with no
-  // per-lane address arithmetic at all: uniform 64-bit base + a_off.  Only edge tiles / a partial last K chunk
-  // look at (a_v, a_r, a_c) to redirect out-of-range slots to the zero page.  Padding slots (never read by the
-  // MFMA loop) carry offset 0 and fetch the origin pixel.
-  int a_off[A_IT], a_key[A_IT];                         // a_key = plane << 16 | tile row << 8 | tile col (1x1: flat pixel), -1 = padding
+  // Both DMA streams go through buffer resources: address = resource base + wave-uniform SGPR byte offset (tile origin
+  // + K chunk) + per-lane 32-bit byte offset, so issuing a stage's DMA costs NO vector instruction (every VALU
+  // instruction stalls the fp32 MFMA stream of its SIMD, DESIGN.md cost model).  A lane whose slot does not exist (halo
+  // outside the image, pixels past the end, channels past C in a partial last chunk) carries an offset beyond the
+  // resource's range: the hardware range check -- which looks at the per-lane offset only, not at the SGPR offset --
+  // then returns zeros without touching memory: the zero padding.  a_offB is the lane's byte offset from the tile's
+  // origin (3x3: halo pixel (y0-1, x0-1); 1x1: first pixel); padding slots (never read by the MFMA loop) carry 0.
+  constexpr unsigned OOB = 0x80000000u;
+  int a_offB[A_IT], a_key[A_IT];                        // a_key = plane << 16 | tile row << 8 | tile col (1x1: flat pixel), -1 = padding
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int slot = it * NTHR + tid;
@@ -330,25 +333,25 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     const bool real = v < KV && pix < NPIX;
     const int r = (TAPS == 9) ? pix / 18 : 0, c = (TAPS == 9) ? pix - r * 18 : pix;
     a_key[it] = real ? (v << 16 | ((TAPS == 9) ? (r << 8 | c) : c)) : -1;
-    a_off[it] = real ? (r * a.W + c) * a.x_pitch + 4 * v : 0;
+    a_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * v) * 4 : 0;
   }
-  int w_off[W_IT];                                      // float offset inside one chunk's packed weights (padding slots: 0)
+  int w_offB[W_IT];                                     // byte offset inside one chunk's packed weights (padding slots: 0)
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) {
     const int slot = it * NTHR + tid;
     const int v = slot / WROWS, tn = slot - v * WROWS;
     const int tap = tn / BN, n = tn - tap * BN;
-    w_off[it] = (v < KV) ? ((v * TAPS + tap) * a.Npad + n0 + n) * 4 : 0;
+    w_offB[it] = (v < KV) ? ((v * TAPS + tap) * a.Npad + n0 + n) * 16 : 0;
   }
-  const long long w_chunk = (long long)KV * TAPS * a.Npad * 4;
+  const unsigned w_chunkB = (unsigned)(KV * TAPS * 16) * (unsigned)a.Npad;
+  // activation resource: for 3x3 based one halo row + one halo column BEFORE the window's first element, so that every
+  // tile's SGPR offset (p0 * pitch * 4; the host checks it stays below 3 GiB) is non-negative
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + a.x_coff - ((TAPS == 9) ? (long long)(a.W + 1) * a.x_pitch : 0ll)), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
 
   // All fields are wave-uniform (SGPRs).  p0 = flat index of the tile's first output pixel.
-  struct TilePos { int y0, x0, inner; long long p0; const float* xorg; };
-  auto tp_sel = [](bool c, const TilePos& u, const TilePos& v) {      // field-wise: keeps everything in SGPRs
-    TilePos r; r.y0 = c ? u.y0 : v.y0; r.x0 = c ? u.x0 : v.x0; r.inner = c ? u.inner : v.inner;
-    r.p0 = c ? u.p0 : v.p0; r.xorg = c ? u.xorg : v.xorg;
-    return r;
-  };
+  struct TilePos { int y0, x0, inner; long long p0; unsigned soff; };     // soff: byte offset of the tile origin from the resource base
   auto tile_pos = [&](int t) {
     TilePos tp;
     if (TAPS == 9) {
@@ -356,25 +359,26 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
       const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
       tp.y0 = ty * TH; tp.x0 = tx * 16;
       tp.p0 = ((long long)b * a.H + tp.y0) * a.W + tp.x0;
-      tp.xorg = a.x + (tp.p0 - a.W - 1) * a.x_pitch + a.x_coff;          // dereferenced only where the pixel exists
+      tp.soff = (unsigned)(tp.p0 * a.x_pitch * 4);
       // sign-bit arithmetic keeps the flag a plain SGPR integer (y0 >= 1, y0 + TH + 1 <= H, x0 >= 1, x0 + 17 <= W)
       tp.inner = (int)(((unsigned)(-tp.y0) & (unsigned)(tp.y0 + TH - a.H) & (unsigned)(-tp.x0) & (unsigned)(tp.x0 + 16 - a.W)) >> 31);
     } else {
       tp.y0 = 0; tp.x0 = 0;
       tp.p0 = (long long)t * (TH * 16);
-      tp.xorg = a.x + tp.p0 * a.x_pitch + a.x_coff;
+      tp.soff = (unsigned)(tp.p0 * a.x_pitch * 4);
       tp.inner = (int)((unsigned long long)(tp.p0 + TH * 16 - a.total_px - 1) >> 63);      // p0 + TH*16 <= total_px
     }
     return tp;
   };
-  // Border tiles: which of this lane's slots point at existing pixels depends on the tile only, not on the K chunk, so it
-  // is evaluated ONCE per tile into wave-wide lane masks (SGPR pairs) and every chunk's DMA just selects between the
-  // source and the zero page with them (2 VALU per DMA instead of ~10; ConvDet walks 48 chunks per tile).
+  // Per-lane offsets of the stage being fetched, evaluated once per (tile, mask situation) -- not per stage: interior
+  // tiles take the plain offsets; border tiles and the partial last K chunk send non-existent slots out of range.
   const int has_partial = (a.C % KC) != 0;
-  auto pix_masks = [&](const TilePos tp, unsigned long long (&m)[A_IT]) {
-    if (tp.inner) {                                                       // uniform: every real slot exists (padding slots fetch the origin)
+  int a_offT[A_IT];
+  auto stage_offsets = [&](const TilePos tp, int cc) {
+    const bool part = has_partial && (cc + 1) * KC > a.C;
+    if (tp.inner && !part) {                                              // uniform
 #pragma unroll
-      for (int it = 0; it < A_IT; ++it) m[it] = ~0ull;
+      for (int it = 0; it < A_IT; ++it) a_offT[it] = a_offB[it];
       return;
     }
 #pragma unroll
@@ -383,34 +387,18 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
       bool ok = key >= 0;
       if (TAPS == 9) ok = ok && (unsigned)(tp.y0 + ((key >> 8) & 255) - 1) < (unsigned)a.H && (unsigned)(tp.x0 + (key & 255) - 1) < (unsigned)a.W;
       else ok = ok && tp.p0 + (key & 0xffff) < a.total_px;
-      m[it] = __builtin_amdgcn_ballot_w64(ok);
+      if (part) ok = ok && cc * KC + 4 * (key >> 16) < a.C;
+      a_offT[it] = ok ? a_offB[it] : (int)OOB;
     }
   };
-  const unsigned long long zp = (unsigned long long)(const void*)sqd_zero_page;
-  const unsigned zp_lo = (unsigned)zp, zp_hi = (unsigned)(zp >> 32);
-  // Straight-line DMA issue (no branch: the tap loop must stay ONE basic block so the compiler can hoist the next
-  // tap's LDS reads above this tap's MFMAs): source = uniform base + lane offset, replaced by the zero page where the
-  // stage's lane mask says the slot does not exist (2 v_cndmask with an SGPR-pair mask).
-  auto dma_act_one = [&](int it, const TilePos tp, unsigned long long okmask, int cc, int buf) {
-    const float* src = tp.xorg + cc * KC + a_off[it];
-    const unsigned long long p = (unsigned long long)(const void*)src;
-    unsigned lo = (unsigned)p, hi = (unsigned)(p >> 32);
-    asm volatile("v_cndmask_b32 %0, %2, %0, %4\n\tv_cndmask_b32 %1, %3, %1, %4" : "+v"(lo), "+v"(hi) : "v"(zp_lo), "v"(zp_hi), "s"(okmask));
-    src = (const float*)(const void*)(((unsigned long long)hi << 32) | lo);
-    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(actB + (buf * ASLOTS + it * NTHR + wm_s * 64) * 4), 16, 0, 0);
-  };
-  // lane masks of one stage's activation slots: the tile's pixel masks, minus channels beyond C in a partial last chunk
-  auto stage_masks = [&](const unsigned long long (&pm)[A_IT], int cc, unsigned long long (&m)[A_IT]) {
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) m[it] = pm[it];
-    if (has_partial && (cc + 1) * KC > a.C) {                             // uniform, outside the tap loop
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it) m[it] &= __builtin_amdgcn_ballot_w64(a_key[it] >= 0 && cc * KC + 4 * (a_key[it] >> 16) < a.C);
-    }
+  // Straight-line DMA issue (the tap loop must stay ONE basic block so the compiler can hoist the next tap's LDS reads
+  // above this tap's MFMAs)
+  auto dma_act_one = [&](int it, unsigned soff, int buf) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_t)(actB + (buf * ASLOTS + it * NTHR + wm_s * 64) * 4), 16, a_offT[it], (int)soff, 0, 0);
   };
   auto dma_w_one = [&](int it, int cc, int buf) {
-    const float* src = a.w + cc * w_chunk + w_off[it];
-    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(wB + (buf * WSLOTS + it * NTHR + wm_s * 64) * 4), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_ptr_t)(wB + (buf * WSLOTS + it * NTHR + wm_s * 64) * 4), 16, w_offB[it],
+                                             (int)((unsigned)cc * w_chunkB), 0, 0);
   };
 
   f32x4 acc[MT][NT], outv[MT][NT];
@@ -435,15 +423,10 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   const float relu_lo = a.relu ? 0.f : -__builtin_inff();             // branch-free ReLU switch (one v_max per element)
 
   TilePos cur = tile_pos(tile);
-  unsigned long long okc[A_IT], okn[A_IT];                                // slot validity masks of the current / next tile
-#pragma unroll
-  for (int it = 0; it < A_IT; ++it) { okc[it] = 0; okn[it] = 0; }
-  pix_masks(cur, okc);
-  unsigned long long dm[A_IT];                                            // masks of the stage being fetched
-  stage_masks(okc, 0, dm);
+  stage_offsets(cur, 0);
   // prologue: stage 0 into buffer 0
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) dma_act_one(it, cur, dm[it], 0, 0);
+  for (int it = 0; it < A_IT; ++it) dma_act_one(it, cur.soff, 0);
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) dma_w_one(it, 0, 0);
   int sbuf = 0, wbuf = 0;              // buffers holding the stage about to be computed
@@ -512,7 +495,6 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);     // tile + tstride < ntiles
     const bool more = more_i != 0;
     const TilePos nxt = tile_pos(more ? tile + tstride : tile);
-    pix_masks(nxt, okn);
     for (int cc = 0; cc < nchunks; ++cc) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the stage's DMA has landed (explicit: the compiler
                                                         // only tracks the issuing wave's own reads of DMA-written LDS)
@@ -522,12 +504,13 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
       const bool last = last_i != 0;
       const int ncc = last ? 0 : cc + 1;
       // plain SALU integers (sign-bit arithmetic): as i1 values the compiler round-trips them through VGPRs
-      const int has_next = (last_i ^ 1) | more_i;
-      const TilePos ntp = tp_sel(last, nxt, cur);
       // The next stage's DMA is issued unconditionally: after the very last stage it re-fetches this workgroup's last tile
-      // into the idle buffer (never read; retired by the vmcnt(0) before the kernel ends) -- cheaper than a branch per tap
-      if (last) stage_masks(okn, ncc, dm); else stage_masks(okc, ncc, dm);
-      (void)has_next;
+      // into the idle buffer (never read; retired by the vmcnt(0) before the kernel ends) -- cheaper than a branch per tap.
+      // Its per-lane offsets change only at a tile switch and in front of a partial last chunk (uniform branches, outside
+      // the tap loop).
+      if (last) stage_offsets(nxt, 0);
+      else if (has_partial && ncc == nchunks - 1) stage_offsets(cur, ncc);
+      const unsigned nsoff = (last ? nxt.soff : cur.soff) + (unsigned)(ncc * KC * 4);
       // per-lane LDS bases of this stage (one VALU add each per stage); every read below is base + immediate
       const float* actL = actB + sbuf * ASLOTS * 4 + (g * NPIXP + ((TAPS == 9) ? wm * MT * 18 : wm * MT * 16) + lr) * 4;
       const float* wL = wB + wbuf * WSLOTS * 4 + (g * WROWS + lr) * 4;
@@ -568,7 +551,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < A_IT + W_IT; ++q) {
           if (q * STEPS / (A_IT + W_IT) != step) continue;
-          if (q < A_IT) dma_act_one(q, ntp, dm[q < A_IT ? q : 0], ncc, sbuf ^ 1);
+          if (q < A_IT) dma_act_one(q < A_IT ? q : 0, nsoff, sbuf ^ 1);
           else if (!WSTAT) dma_w_one(q - A_IT, ncc, wbuf ^ 1);
         }
         // The next step's reads go out in the MIDDLE of this step's MFMAs: when the next step starts (and the compiler's
@@ -602,11 +585,10 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     if (!more) break;
     tile += tstride;
     cur = nxt;
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) okc[it] = okn[it];
   }
   if (pending) flush(ptp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may still be in flight when the LDS is released
+#endif
 }
 
 static int sqd_num_cus() {
@@ -671,6 +653,8 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   constexpr size_t lds_max = (size_t)(2 * ASLOTS + 2 * WSLOTS) * 16 + BN * sizeof(float);
   static_assert(lds_max <= 160 * 1024, "LDS budget");
   if (a.xmask) return SQD_ERR_UNSUPPORTED;               // input-side mask needs register staging (v3 path)
+  // 32-bit SGPR byte offset of a tile origin / per-lane byte offsets inside a tile (buffer-resource addressing)
+  if (a.total_px * a.x_pitch * 4 >= (3ll << 30) || (long long)a.W * (TH + 2) * a.x_pitch * 4 >= (1ll << 30)) return SQD_ERR_UNSUPPORTED;
   const int stationary = (a.C <= KC) ? 1 : 0;            // one K chunk: a single weight buffer suffices
   const size_t lds = (size_t)(2 * ASLOTS + (stationary ? 1 : 2) * WSLOTS) * 16 + BN * sizeof(float);
   // waves per SIMD the register allocator must leave room for: workgroups per CU (by LDS) x waves per SIMD of one
