@@ -1,5 +1,5 @@
 """Randomised parity sweep of sqd_conv_fwd / sqd_fire_expand_fwd / sqd_conv_wgrad against torch (CPU fp32):
-every compiled tile configuration x random shapes (tiny maps, widths off the 16-pixel grid, partial K chunks,
+every compiled tile configuration (and the Winograd family on the 3x3 cases) x random shapes (tiny maps, widths off the 16-pixel grid, partial K chunks,
 channel windows inside wider buffers), with the epilogue options the backward uses.  usage: fuzz_conv.py [seconds]"""
 import sys, time
 sys.path.insert(0, '.')
@@ -60,6 +60,34 @@ while time.time() - t0 < budget:
         if not (e2 <= tol and torch.equal(yf[..., :4], keep[..., :4]) and torch.equal(yf[..., 4 + 2 * N:], keep[..., 4 + 2 * N:])):
             print('FUSED MISMATCH', dict(cid=cid, B=B, H=H, W=W, C=C, E=N, err=e2, tol=tol)); sys.exit(1)
         n_ok += 1
+    # Winograd form of the same 3x3 layer (C % 8 == 0), same windows; the epilogue options need y's own geometry
+    if taps == 9 and C % 8 == 0:
+        wc = int(rs.choice(list(ops.wino_cfgs()))) + 1000 * int(rs.choice([0, 0, 1]))
+        wmode = int(rs.randint(0, 4)); wrelu = bool(rs.randint(0, 2))
+        yw = y0.clone().cuda(); wkw = {}; wref = nhwc(ref)
+        if wmode in (1, 3):
+            wkw['accumulate'] = True; wref = wref + y0[..., yo:yo + N]
+        if wmode in (2, 3):
+            mm = torch.rand(B, H, W, yp) + 0.5; mk = torch.randn(B, H, W, yp)
+            wkw['ymul'] = mm.cuda(); wkw['ymask'] = mk.cuda()
+            wref = torch.where(mk[..., yo:yo + N] > 0, wref * mm[..., yo:yo + N], torch.zeros(()))
+        if wrelu: wref = torch.relu(wref)
+        ops.conv_wino(xb.cuda(), xo, ops.WinoPlan(w.cuda(), b.cuda(), wc), yw, yo, relu=wrelu, **wkw)
+        outw = yw.cpu()
+        e5 = (outw[..., yo:yo + N] - wref).abs().max().item()
+        tolw = 2e-5 * max(1.0, wref.abs().max().item()) + 1e-5
+        if not (e5 <= tolw and torch.equal(outw[..., :yo], y0[..., :yo]) and torch.equal(outw[..., yo + N:], y0[..., yo + N:])):
+            print('WINOGRAD MISMATCH', dict(wc=wc, B=B, H=H, W=W, C=C, N=N, xp=xp, xo=xo, yp=yp, yo=yo, mode=wmode, relu=wrelu, err=e5, tol=tolw)); sys.exit(1)
+        worst = max(worst, e5 / tolw); n_ok += 1
+        if N % 8 == 0 and rs.rand() < 0.5:             # data-gradient packing: dX = conv_transpose(dY, w)
+            dyw = torch.randn(B, N, H, W)
+            refdx = nhwc(F.conv_transpose2d(dyw, w, None, padding=1))
+            dxw = torch.full((B, H, W, C), float('nan')).cuda()
+            ops.conv_wino(nhwc(dyw).cuda(), 0, ops.WinoPlan(w.cuda(), None, wc, dgrad=True), dxw, 0)
+            e6 = (dxw.cpu() - refdx).abs().max().item()
+            if not e6 <= 2e-5 * max(1.0, refdx.abs().max().item()) + 1e-5:
+                print('WINOGRAD DGRAD MISMATCH', dict(wc=wc, B=B, H=H, W=W, C=C, N=N, err=e6)); sys.exit(1)
+            n_ok += 1
     # weight gradient of the same layer
     if rs.rand() < 0.3:
         dy = torch.randn(B, N, H, W)
