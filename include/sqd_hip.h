@@ -58,6 +58,13 @@ int sqd_pack_conv_weights_batched(const void* descs_dev, int n, int blocks_per_d
 int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
                    int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int taps, int S,
                    void* stream);
+/* dw == NULL in sqd_conv_wgrad: write the S partial slabs only; the caller then reduces many layers with ONE launch:
+ * descs_dev = device array of n records of 9 int64 {slab offset, dw offset, db offset (floats from slab_base / grad_base;
+ * db offset < 0: no bias gradient), S, slab stride (= N*taps*C + N), N, C, taps, first workgroup of the record}
+ * (a record takes ceil((N*taps*C + N) / 32) workgroups; total_blocks = their sum).  Results are bitwise those of the
+ * per-layer reduction. */
+int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base, void* stream);
+
 
 /* Stem weight + bias gradient (the image needs no data gradient).  slab: S*(N*3*k*k + N) floats. */
 int sqd_stem_wgrad(const float* dy_nhwc, const float* img_nchw, float* slab, float* dw_oihw, float* db,
@@ -148,6 +155,9 @@ int sqd_conv_wino_fwd(const float* x, const float* u_packed, const float* bias, 
 /* Transformed weights U = G g G^T of an OIHW [No][Ci][3][3] parameter into the layout above; dgrad != 0 packs the
  * data-gradient orientation (in/out channels swapped, taps flipped). */
 int sqd_pack_wino_weight(const float* w_oihw, float* u_packed, int No, int Ci, int Npad, int dgrad, void* stream);
+/* The same for many plans in ONE launch (after an optimizer step).  descs_dev: device array of n records of 7 int64
+ * {w_oihw ptr, u_packed ptr, No, Ci, Npad, dgrad, C/8 * Npad * 8}; blocks_per_desc workgroups walk each record. */
+int sqd_pack_wino_weights_batched(const void* descs_dev, int n, int blocks_per_desc, void* stream);
 
 /* Fused MaxPool2d(3, 2, ceil_mode) + Fire squeeze 1x1 + ReLU, inference forward (src/model/squeezedet.py:39,42 followed
  * by :12,18): y[..., y_coff : y_coff+N] = ReLU(conv1x1(pool(x[..., x_coff : x_coff+C])) + bias); the pooled tensor is never

@@ -31,6 +31,7 @@ _SIGNATURES = {
     'sqd_pack_conv_weight': [c_p, c_p] + [c_i] * 6 + [c_p],
     'sqd_pack_conv_weights_batched': [c_p, c_i, c_i, c_p],
     'sqd_conv_wgrad': [c_p] * 5 + [c_i] * 11 + [c_p],
+    'sqd_wgrad_reduce_batched': [c_p, c_i, c_i, c_p, c_p, c_p],
     'sqd_stem_wgrad': [c_p] * 5 + [c_i] * 6 + [c_p],
     'sqd_stem_wgrad_pooled': [c_p] * 7 + [c_i] * 6 + [c_p],
     'sqd_stem_conv_relu_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -49,6 +50,7 @@ _SIGNATURES = {
     'sqd_wino_cfg_info': [c_i, c_p, c_p],
     'sqd_conv_wino_fwd': [c_p] * 6 + [c_i] * 13 + [c_p],
     'sqd_pack_wino_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    'sqd_pack_wino_weights_batched': [c_p, c_i, c_i, c_p],
     'sqd_encode_gt_fwd': [c_p] * 8 + [c_i, c_i, c_i, c_i, c_p],
     'sqd_loss_fwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],
     'sqd_loss_bwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],

@@ -105,9 +105,10 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
 def _make_drop_mask(base, like_nhwc_shape, device):
     if base._forced_drop_mask is not None:
         return base._forced_drop_mask.to(device).permute(0, 2, 3, 1).contiguous()
-    p = base.dropout_prob
-    keep = torch.rand(like_nhwc_shape, device=device) >= p
-    return keep.to(torch.float32) / (1.0 - p)
+    # nn.Dropout semantics (Bernoulli keep mask scaled by 1/(1-p)) drawn directly in NHWC: one fused torch RNG kernel
+    # on a tensor of ones yields the scaled mask itself (elementwise plumbing; the stream differs from the reference's
+    # CPU generator either way -- tests inject the mask)
+    return torch.nn.functional.dropout(torch.ones(like_nhwc_shape, device=device), base.dropout_prob, training=True)
 
 
 def _feature_shape(base, image):

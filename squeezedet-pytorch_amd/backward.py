@@ -16,18 +16,50 @@ from .autograd import run_backbone_forward
 from .synthetic import layer_table
 
 
+def _wgrad_layout(base, saved, B, H, W):
+    """Flat gradient layout (named_parameters order: every gradient is a view of ONE buffer) and the batched-reduction
+    entries of all Fire / ConvDet weight gradients for the shapes of this step."""
+    slots, off = {}, 0
+    for n, p in base.named_parameters():
+        slots[n] = (off, tuple(p.shape)); off += p.numel()
+    layers = layer_table(base.arch)
+    entries = []
+
+    def add(pre, N, C, taps, shp):
+        entries.append((pre, N, C, taps, shp[0], shp[1], shp[2], slots[pre + '.weight'][0], slots[pre + '.bias'][0]))
+    add('convdet', base.convdet.out_channels, base.convdet.in_channels, 9, (B, H, W))
+    for i in range(len(layers) - 1, 1, -1):
+        if layers[i][0] != 'fire':
+            continue
+        _, cin, s, e1, e3 = layers[i]
+        shp = saved[f'fire{i}'][2].shape
+        add(f'features.{i}.expand1x1', e1, s, 1, shp)
+        add(f'features.{i}.expand3x3', e3, s, 9, shp)
+        add(f'features.{i}.squeeze', s, cin, 1, shp)
+    return entries, slots, off
+
+
 def run_backbone_backward(base, saved, dpred):
-    """dpred: NHWC [B,H,W,anchors_per_grid*(C+5)].  Returns {param_name (relative to base): grad}."""
+    """dpred: NHWC [B,H,W,anchors_per_grid*(C+5)].  Returns {param_name (relative to base): grad}; every gradient is a
+    view of one flat fp32 buffer in ``named_parameters`` order (``base.last_grad_flat``)."""
     layers = layer_table(base.arch)
     feats = base.features
-    grads = {}
     dpred = dpred.contiguous()
     B, H, W, ncd = dpred.shape
     cd = base.convdet
     a_in = saved['convdet_in']
     cin_cd = a_in.shape[3]
-    npix = B * H * W
-    grads['convdet.weight'], grads['convdet.bias'] = ops.conv_wgrad(dpred, 0, ncd, a_in, 0, cin_cd, 9)
+    shape_key = (B, H, W) + tuple(tuple(saved[f'fire{i}'][2].shape) for i in range(len(layers)) if layers[i][0] == 'fire')
+    wb, slots, total = base.wgrad_batch(lambda: _wgrad_layout(base, saved, B, H, W), shape_key)
+    grad_flat = torch.empty(total, device=dpred.device, dtype=torch.float32)
+
+    def gview(name):
+        off, shape = slots[name]
+        n = 1
+        for d in shape:
+            n *= d
+        return grad_flat[off:off + n].view(shape)
+    ops.conv_wgrad(dpred, 0, ncd, a_in, 0, cin_cd, 9, slab=wb.slab('convdet'))
     last = len(layers) - 1
     assert layers[last][0] == 'fire'
     out_last = saved[f'fire{last}'][2]
@@ -49,26 +81,27 @@ def run_backbone_backward(base, saved, dpred):
         Bq, Hq, Wq, _ = out.shape
         npix = Bq * Hq * Wq
         pre = f'features.{i}.'
-        grads[pre + 'expand1x1.weight'], grads[pre + 'expand1x1.bias'] = ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1)
-        grads[pre + 'expand3x3.weight'], grads[pre + 'expand3x3.bias'] = ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9)
+        ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
+        ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
         dSq = torch.empty_like(sq)
         ops.conv(dA, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, e1, s, npix), 'dgrad'), dSq, 0)
         base.dgrad3x3(f'{i}.expand3x3', fire.expand3x3, dA, e1, dSq, accumulate=True, ymask=sq)
-        grads[pre + 'squeeze.weight'], grads[pre + 'squeeze.bias'] = ops.conv_wgrad(dSq, 0, s, x_in, 0, cin, 1)
+        ops.conv_wgrad(dSq, 0, s, x_in, 0, cin, 1, slab=wb.slab(pre + 'squeeze'))
         dIn = torch.empty_like(x_in)
         prev_is_fire = layers[i - 1][0] == 'fire'
         ops.conv(dSq, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, s, cin, npix), 'dgrad'), dIn, 0,
                  ymask=x_in if prev_is_fire else None)
         dA = dIn
     stem = feats[0]
+    stem_out = (gview('features.0.weight'), gview('features.0.bias'))
     if 'stem_pool' in saved:
         am, pooled = saved['stem_pool']
-        grads['features.0.weight'], grads['features.0.bias'] = ops.stem_wgrad_pooled(dA, pooled, am, saved['image'].contiguous(),
-                                                                                      stem.out_channels, stem.kernel_size[0])
+        ops.stem_wgrad_pooled(dA, pooled, am, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
     else:
-        grads['features.0.weight'], grads['features.0.bias'] = ops.stem_wgrad(dA, saved['image'].contiguous(), stem.out_channels,
-                                                                               stem.kernel_size[0])
-    return grads
+        ops.stem_wgrad(dA, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
+    wb.reduce(grad_flat)                                   # all 31 Fire / ConvDet slab reductions: one launch
+    base.last_grad_flat = grad_flat
+    return {n: gview(n) for n in slots}
 
 
 class BackboneFn(torch.autograd.Function):

@@ -384,11 +384,9 @@ static int launch_wino(WinoArgs a, hipStream_t stream) {
 }
 
 // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: one thread per (chunk, n, channel) writes its 16 positions
-__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int No, int Ci, int Npad, int dgrad) {
-  const int N = dgrad ? Ci : No, C = dgrad ? No : Ci;
-  const long long total = (long long)(C >> 3) * Npad * 8;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int No, int Ci, int Npad, int dgrad,
+                                              long long idx) {
+  const int N = dgrad ? Ci : No;
   const int c8 = (int)(idx & 7);
   const int n = (int)((idx >> 3) % Npad);
   const int chunk = (int)((idx >> 3) / Npad);
@@ -415,6 +413,30 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     const long long pps = (long long)Npad * 16;                  // floats per position pair
     dst[0] = o0; dst[2] = o1; dst[pps] = o2; dst[pps + 2] = o3;
   }
+}
+
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int No, int Ci, int Npad, int dgrad) {
+  const int C = dgrad ? No : Ci;
+  const long long total = (long long)(C >> 3) * Npad * 8;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) wino_pack_one(w, u, No, Ci, Npad, dgrad, idx);
+}
+
+// Batched re-transform after an optimizer step: one launch for every Winograd plan.  descs: device array of n records
+// of 7 int64 {w ptr, out ptr, No, Ci, Npad, dgrad, total threads = C/8 * Npad * 8}.
+struct WinoPackDesc { const float* w; float* out; long long No, Ci, Npad, dgrad, total; };
+
+__global__ __launch_bounds__(256) void pack_wino_batched_kernel(const WinoPackDesc* __restrict__ descs) {
+  const WinoPackDesc d = descs[blockIdx.y];
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < d.total; idx += (long long)gridDim.x * blockDim.x)
+    wino_pack_one(d.w, d.out, (int)d.No, (int)d.Ci, (int)d.Npad, (int)d.dgrad, idx);
+}
+
+extern "C" int sqd_pack_wino_weights_batched(const void* descs_dev, int n, int blocks_per_desc, void* stream) {
+  SQD_CHECK_ARG(descs_dev && n > 0 && n <= 65535 && blocks_per_desc > 0 && blocks_per_desc <= 4096);
+  hipLaunchKernelGGL(pack_wino_batched_kernel, dim3((unsigned)blocks_per_desc, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     (const WinoPackDesc*)descs_dev);
+  return sqd_launch_status();
 }
 
 extern "C" int sqd_pack_wino_weight(const float* w_oihw, float* u_packed, int No, int Ci, int Npad, int dgrad, void* stream) {

@@ -346,7 +346,7 @@ static int launch_wgrad(WgradArgs a, int S, hipStream_t stream) {
 extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
                               int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int taps, int S,
                               void* stream) {
-  SQD_CHECK_ARG(dy && x && slab && dw && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535);
+  SQD_CHECK_ARG(dy && x && slab && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535);
   SQD_CHECK_ARG((N & 3) == 0 && (C & 3) == 0 && (dy_pitch & 3) == 0 && (dy_coff & 3) == 0 && (x_pitch & 3) == 0 && (x_coff & 3) == 0);
   SQD_CHECK_ARG(dy_coff + N <= dy_pitch && x_coff + C <= x_pitch);
   SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0);
@@ -378,9 +378,57 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
 #undef SQD_WG_CASE
   }
   if (rc != SQD_OK) return rc;
+  if (!dw) return sqd_launch_status();       // partial slabs only: the caller reduces many layers at once (sqd_wgrad_reduce_batched)
   const long long outs = a.slab_stride;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs + WGR_OUT - 1) / WGR_OUT)), dim3(WGR_OUT * WGR_PARTS), 0, s, slab, dw, db, S,
                      a.slab_stride, N, C, taps);
+  return sqd_launch_status();
+}
+
+// The slab reduction of MANY layers in one launch (a training step has 32 of them, 8 us each when launched one by one).
+// descs: device array of n records of 9 int64 {slab offset, dw offset, db offset (floats; db < 0: none), S, slab stride,
+// N, C, TAPS, first workgroup}; slabs live in one workspace (slab_base), gradients in one flat buffer (grad_base), so the
+// table is the same every step.  Same arithmetic and order as wgrad_reduce_kernel (bitwise identical results).
+struct WgrDesc { long long slab_off, dw_off, db_off, S, slab_stride, N, C, TAPS, block_begin; };
+
+__global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_batched_kernel(const WgrDesc* __restrict__ descs, int n,
+                                                                                   const float* __restrict__ slab_base,
+                                                                                   float* __restrict__ grad_base) {
+  __shared__ float red[WGR_PARTS][WGR_OUT];
+  int row = 0;
+  while (row + 1 < n && descs[row + 1].block_begin <= (long long)blockIdx.x) ++row;      // uniform (scalar loads)
+  const WgrDesc d = descs[row];
+  const float* slab = slab_base + d.slab_off;
+  const int S = (int)d.S, C = (int)d.C, TAPS = (int)d.TAPS;
+  const long long nw = d.N * d.TAPS * d.C;
+  const int o = threadIdx.x & (WGR_OUT - 1), part = threadIdx.x / WGR_OUT;
+  const long long idx = ((long long)blockIdx.x - d.block_begin) * WGR_OUT + o;
+  const bool live = idx < nw + d.N;
+  float s = 0.f;
+  if (live) {
+#pragma unroll 8
+    for (int k = part; k < S; k += WGR_PARTS) s += slab[(long long)k * d.slab_stride + idx];
+  }
+  red[part][o] = s;
+  __syncthreads();
+  if (part != 0 || !live) return;
+  float t = red[0][o];
+#pragma unroll
+  for (int p = 1; p < WGR_PARTS; ++p) t += red[p][o];
+  if (idx < nw) {
+    const int c = (int)(idx % C); const long long q = idx / C;
+    const int tap = (int)(q % TAPS); const int nn = (int)(q / TAPS);
+    grad_base[d.dw_off + ((long long)nn * C + c) * TAPS + tap] = t;
+  } else if (d.db_off >= 0) {
+    grad_base[d.db_off + (idx - nw)] = t;
+  }
+}
+
+extern "C" int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base,
+                                        void* stream) {
+  SQD_CHECK_ARG(descs_dev && n > 0 && n <= 4096 && total_blocks > 0 && slab_base && grad_base);
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(WGR_OUT * WGR_PARTS), 0, (hipStream_t)stream,
+                     (const WgrDesc*)descs_dev, n, slab_base, grad_base);
   return sqd_launch_status();
 }
 

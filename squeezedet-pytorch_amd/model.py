@@ -91,6 +91,8 @@ class SqueezeDetBase(nn.Module):
         self._plans = {}
         self._fused_plans = {}
         self._wino_plans = {}
+        self._wgrad_batches = {}
+        self.last_grad_flat = None                # flat gradient buffer of the latest backward (every .grad is a view of it)
         self.use_winograd = True                  # 3x3 forward convs: Winograd F(2x2,3x3) kernel where tuning.json says it is faster
         self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
         # inference forward: pool 2 / 3 folded into the following squeeze (ops.pool_squeeze).  Off by default: measured equal
@@ -181,6 +183,7 @@ class SqueezeDetBase(nn.Module):
             now = (mod.weight._version, mod.weight.data_ptr(), mod.bias._version, mod.bias.data_ptr())
             if now != ver:
                 stale.append((plan, mod.weight)); dg.append(direction != 'fwd'); keys.append((key, now, mod))
+        self._refresh_wino_plans()
         if not stale:
             return
         if self._pack_table_keepalive is not None and len(self._pack_table_keepalive) > 8:
@@ -191,6 +194,35 @@ class SqueezeDetBase(nn.Module):
             if plan.bias is not None:
                 plan.bias = mod.bias.detach()
             self._plans[key] = (now, plan)
+
+    def _refresh_wino_plans(self):
+        """The same for the Winograd plans: every transformed-weight copy whose parameter changed, one launch."""
+        stale, dg, keys = [], [], []
+        for key, (ver, plan) in self._wino_plans.items():
+            name, _cfg, direction = key
+            mod = self.convdet if name == 'convdet' else getattr(self.features[int(name.split('.')[0])], name.split('.')[1])
+            now = (mod.weight._version, mod.weight.data_ptr(), mod.bias._version, mod.bias.data_ptr())
+            if now != ver:
+                stale.append((plan, mod.weight)); dg.append(direction != 'fwd'); keys.append((key, now, mod))
+        if not stale:
+            return
+        table = ops.repack_wino_batched(stale, dg)
+        self._pack_table_keepalive = (self._pack_table_keepalive or [])[-6:] + [table]
+        for (key, now, mod), (plan, _w) in zip(keys, stale):
+            if plan.bias is not None:
+                plan.bias = mod.bias.detach()
+            self._wino_plans[key] = (now, plan)
+
+    def wgrad_batch(self, entries_fn, key):
+        """Cached ops.WgradBatch for one set of layer shapes (``entries_fn()`` builds the entry list on a miss)."""
+        hit = self._wgrad_batches.get(key)
+        if hit is None:
+            if len(self._wgrad_batches) > 4:
+                self._wgrad_batches.clear()
+            entries, slots, total = entries_fn()
+            hit = (ops.WgradBatch(entries, self.convdet.weight.device), slots, total)
+            self._wgrad_batches[key] = hit
+        return hit
 
     def forward(self, x):
         from .autograd import backbone_apply

@@ -406,6 +406,27 @@ class WinoPlan:
             self.bias = bias.detach()
 
 
+def repack_wino_batched(plans_and_weights, is_dgrad):
+    """Re-transform many WinoPlans with ONE kernel launch (pointer-stable).  plans_and_weights: [(WinoPlan, weight)]."""
+    if not plans_and_weights:
+        return None
+    rows = []
+    for (plan, w), dg in zip(plans_and_weights, is_dgrad):
+        if not w.is_contiguous():
+            raise ValueError('repack_wino_batched: parameters must be contiguous')
+        rows.append([w.data_ptr(), plan.w.data_ptr(), w.shape[0], w.shape[1], plan.Npad, int(dg), (plan.C // 8) * plan.Npad * 8])
+    dev = plans_and_weights[0][1].device
+    key = ('wino', str(dev), tuple(tuple(r) for r in rows))
+    table = _PACK_TABLES.get(key)
+    if table is None:
+        if len(_PACK_TABLES) > 16:
+            _PACK_TABLES.clear()
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _PACK_TABLES[key] = table
+    nat.check(nat.lib().sqd_pack_wino_weights_batched(nat.ptr(table), len(rows), 16, nat.stream_handle(dev)), 'sqd_pack_wino_weights_batched')
+    return table
+
+
 def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=None, ymul=None):
     """y[..., y_coff:y_coff+N] (=|+=) conv3x3(x[..., x_coff:x_coff+C]) (+bias) (* ymul) (zero where ymask <= 0) (ReLU),
     Winograd F(2x2,3x3) kernel.  ``ymask`` / ``ymul`` are read through y's own channel window (same shape as y)."""
@@ -672,17 +693,8 @@ _TARGET_WGS = 1536          # workgroups a 3x3 weight-gradient launch aims for (
 _TARGET_WGS_1X1 = 1024      # 1x1: fewer, longer pixel streams (less slab traffic per MFMA)
 
 
-def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps):
-    """(dW OIHW [N,C,k,k], db [N]) from dy[..., dy_coff:dy_coff+N] (already ReLU-masked) and
-    x[..., x_coff:x_coff+C]."""
-    _check_nhwc(dy, 'dy'); _check_nhwc(x, 'x')
-    B, H, W, dyp = dy.shape
-    if tuple(x.shape[:3]) != (B, H, W):
-        raise ValueError('wgrad: dy and x disagree on B,H,W')
-    xp = x.shape[3]
-    if dy_coff + N > dyp or x_coff + C > xp or N % 4 or C % 4 or taps not in (1, 9):
-        raise ValueError('wgrad: channel window out of range')
-    k = 3 if taps == 9 else 1
+def wgrad_split(N, C, taps, B, H, W):
+    """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab."""
     tn = 4 if N >= 64 else -(-N // 16)
     if taps == 9:
         if 64 < N <= 80:
@@ -699,10 +711,31 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps):
         nblocks = -(-(B * H * W) // 128)
     groups = -(-N // (tn * 16)) * -(-C // (tc * 16))
     S = max(1, min(nblocks, (_TARGET_WGS if taps == 9 else _TARGET_WGS_1X1) // groups, 256))
-    stride = N * taps * C + N
-    slab = torch.empty(S * stride, device=dy.device, dtype=torch.float32)
-    dw = torch.empty(N, C, k, k, device=dy.device, dtype=torch.float32)
-    db = torch.empty(N, device=dy.device, dtype=torch.float32)
+    return S, N * taps * C + N
+
+
+def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None):
+    """(dW OIHW [N,C,k,k], db [N]) from dy[..., dy_coff:dy_coff+N] (already ReLU-masked) and
+    x[..., x_coff:x_coff+C].  With ``slab`` (a workspace view of S * stride floats, see ``WgradBatch``) only the partial
+    slabs are written and None is returned: the caller reduces all layers with one launch."""
+    _check_nhwc(dy, 'dy'); _check_nhwc(x, 'x')
+    B, H, W, dyp = dy.shape
+    if tuple(x.shape[:3]) != (B, H, W):
+        raise ValueError('wgrad: dy and x disagree on B,H,W')
+    xp = x.shape[3]
+    if dy_coff + N > dyp or x_coff + C > xp or N % 4 or C % 4 or taps not in (1, 9):
+        raise ValueError('wgrad: channel window out of range')
+    k = 3 if taps == 9 else 1
+    S, stride = wgrad_split(N, C, taps, B, H, W)
+    deferred = slab is not None
+    if deferred:
+        if slab.numel() != S * stride or not slab.is_contiguous() or slab.dtype != torch.float32:
+            raise ValueError('wgrad: slab workspace does not match this layer')
+        dw = db = None
+    else:
+        slab = torch.empty(S * stride, device=dy.device, dtype=torch.float32)
+        dw = torch.empty(N, C, k, k, device=dy.device, dtype=torch.float32)
+        db = torch.empty(N, device=dy.device, dtype=torch.float32)
     br = _Bracket(f'conv_wgrad<{taps}>', f'wgrad {taps}tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * taps,
                   4.0 * (B * H * W * (C + N) + 2 * S * stride)) if _timer is not None else None
     rc = nat.lib().sqd_conv_wgrad(nat.ptr(dy), nat.ptr(x), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, dyp, dy_coff,
@@ -710,10 +743,48 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps):
     nat.check(rc, 'sqd_conv_wgrad')
     if br is not None:
         br.done()
-    return dw, db
+    return None if deferred else (dw, db)
 
 
-def stem_wgrad(dy, image, N, ksize):
+class WgradBatch:
+    """Workspace + descriptor table for reducing the partial slabs of many conv weight gradients with ONE launch into a
+    flat gradient buffer.  ``entries``: [(key, N, C, taps, B, H, W, dw_offset, db_offset)] (offsets in floats into the flat
+    buffer).  Slab workspace and table are allocated once and reused every step (pointer-stable)."""
+
+    def __init__(self, entries, device):
+        rows, self.slabs, off, blk = [], {}, 0, 0
+        for key, N, C, taps, B, H, W, dw_off, db_off in entries:
+            S, stride = wgrad_split(N, C, taps, B, H, W)
+            rows.append([off, dw_off, db_off, S, stride, N, C, taps, blk])
+            self.slabs[key] = (off, S * stride)
+            off += S * stride
+            blk += -(-stride // 32)
+        self.total_blocks = blk
+        self.workspace = torch.empty(off, device=device, dtype=torch.float32)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.nrows = len(rows)
+        self.bytes = 4.0 * off
+
+    def slab(self, key):
+        off, n = self.slabs[key]
+        return self.workspace[off:off + n]
+
+    def reduce(self, grad_flat):
+        br = _Bracket('wgrad_reduce_batched', f'{self.nrows} layers', 0.0, self.bytes) if _timer is not None else None
+        rc = nat.lib().sqd_wgrad_reduce_batched(nat.ptr(self.table), self.nrows, self.total_blocks, nat.ptr(self.workspace),
+                                                nat.ptr(grad_flat), nat.stream_handle(grad_flat.device))
+        nat.check(rc, 'sqd_wgrad_reduce_batched')
+        if br is not None:
+            br.done()
+
+
+def _check_stem_out(dw, db, N, ksize):
+    if tuple(dw.shape) != (N, 3, ksize, ksize) or tuple(db.shape) != (N,) or not dw.is_contiguous() or not db.is_contiguous() \
+            or dw.dtype != torch.float32 or db.dtype != torch.float32:
+        raise ValueError('stem wgrad: out=(dw, db) must be contiguous fp32 [N,3,k,k] / [N]')
+
+
+def stem_wgrad(dy, image, N, ksize, out=None):
     """(dW [N,3,k,k], db [N]) of the stem from dy NHWC [B,Ho,Wo,N] (ReLU-masked) and the NCHW image."""
     _check_nhwc(dy, 'dy')
     B, Ho, Wo, n = dy.shape
@@ -726,8 +797,9 @@ def stem_wgrad(dy, image, N, ksize):
     S = max(1, min(nblocks, 1024))
     K = 3 * ksize * ksize
     slab = torch.empty(S * (N * K + N), device=dy.device, dtype=torch.float32)
-    dw = torch.empty(N, 3, ksize, ksize, device=dy.device, dtype=torch.float32)
-    db = torch.empty(N, device=dy.device, dtype=torch.float32)
+    dw, db = out if out is not None else (torch.empty(N, 3, ksize, ksize, device=dy.device, dtype=torch.float32),
+                                          torch.empty(N, device=dy.device, dtype=torch.float32))
+    _check_stem_out(dw, db, N, ksize)
     br = _Bracket(f'stem_wgrad<{ksize}>', f'stem wgrad {H}x{W}', 2.0 * B * Ho * Wo * N * K,
                   4.0 * (B * Ho * Wo * N + B * 3 * H * W)) if _timer is not None else None
     rc = nat.lib().sqd_stem_wgrad(nat.ptr(dy), nat.ptr(image), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, ksize, S,
@@ -738,7 +810,7 @@ def stem_wgrad(dy, image, N, ksize):
     return dw, db
 
 
-def stem_wgrad_pooled(dpool, pooled, argmax, image, N, ksize):
+def stem_wgrad_pooled(dpool, pooled, argmax, image, N, ksize, out=None):
     """Stem (dW, db) when the forward ran fused (stem_pool with argmax): ReLU + max-pool backward folded in."""
     _check_nhwc(dpool, 'dpool'); _check_nhwc(pooled, 'pooled')
     B, Hp, Wp, n = dpool.shape
@@ -755,8 +827,9 @@ def stem_wgrad_pooled(dpool, pooled, argmax, image, N, ksize):
     S = max(1, min(nblocks, 1024))
     K = 3 * ksize * ksize
     slab = torch.empty(S * (N * K + N), device=dpool.device, dtype=torch.float32)
-    dw = torch.empty(N, 3, ksize, ksize, device=dpool.device, dtype=torch.float32)
-    db = torch.empty(N, device=dpool.device, dtype=torch.float32)
+    dw, db = out if out is not None else (torch.empty(N, 3, ksize, ksize, device=dpool.device, dtype=torch.float32),
+                                          torch.empty(N, device=dpool.device, dtype=torch.float32))
+    _check_stem_out(dw, db, N, ksize)
     br = _Bracket(f'stem_wgrad_pooled<{ksize}>', f'stem wgrad (pooled) {H}x{W}', 2.0 * B * Ho * Wo * N * K,
                   4.0 * (B * Hp * Wp * N * 2.25 + B * 3 * H * W)) if _timer is not None else None
     rc = nat.lib().sqd_stem_wgrad_pooled(nat.ptr(dpool), nat.ptr(pooled), nat.ptr(argmax), nat.ptr(image), nat.ptr(slab), nat.ptr(dw),

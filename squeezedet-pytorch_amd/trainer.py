@@ -58,6 +58,24 @@ def allreduce_gradients(params, world=None, group=None):
         return None
     if world is None:
         world = dist.get_world_size(group) if dist is not None else 1
+    # The HIP backward already emits every gradient as a view of one flat buffer (named_parameters order): all-reduce
+    # that buffer in place -- no gather copy, no scatter back.
+    g0 = params[0].grad
+    off, contiguous_views = 0, g0.is_contiguous()
+    for p in params:
+        g = p.grad
+        if not (contiguous_views and g.is_contiguous() and g.dtype == g0.dtype and g.device == g0.device
+                and g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr()
+                and g.storage_offset() == g0.storage_offset() + off):
+            contiguous_views = False
+            break
+        off += g.numel()
+    if contiguous_views:
+        flat = g0.as_strided((off,), (1,), g0.storage_offset()) if off != g0.numel() else g0.reshape(-1)
+        if dist is not None and world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.mul_(1.0 / world)
+        return flat
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     if dist is not None and world > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

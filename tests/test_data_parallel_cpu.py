@@ -69,3 +69,22 @@ def test_shard_sizes():
     assert shard_sizes(160, 8) == [20] * 8
     assert shard_sizes(20, 1) == [20]
     assert shard_sizes(22, 4) == [6, 6, 5, 5] and sum(shard_sizes(23, 8)) == 23
+
+
+def test_allreduce_flat_view_fast_path():
+    """Gradients that already are consecutive views of one flat buffer (what the HIP backward emits) are all-reduced in
+    place: the returned bucket aliases them, values unchanged at world size 1."""
+    import torch
+    from squeezedet_pytorch_amd.trainer import allreduce_gradients
+    ps = [torch.nn.Parameter(torch.zeros(3, 2)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2, 1, 1))]
+    flat = torch.arange(6 + 5 + 4, dtype=torch.float32)
+    off = 0
+    for p in ps:
+        p.grad = flat[off:off + p.numel()].view_as(p); off += p.numel()
+    out = allreduce_gradients(ps, world=1)
+    assert out.data_ptr() == flat.data_ptr() and out.numel() == flat.numel()
+    assert torch.equal(out, torch.arange(15, dtype=torch.float32))
+    # not consecutive -> gather / scatter path, same values
+    ps[1].grad = torch.full((5,), 7.0)
+    out2 = allreduce_gradients(ps, world=1)
+    assert out2.data_ptr() != flat.data_ptr() and torch.equal(out2[6:11], torch.full((5,), 7.0))
