@@ -21,6 +21,8 @@ def short_name(k):
     if m:
         base = "fire_expand" if m.group(6) == "true" else "conv_dma"
         return f"{base}<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>"
+    m = re.match(r"conv_wino_kernel<(\d+), (\d+)>", short)
+    if m: return f"conv_wino<{m.group(1)},{m.group(2)}>"
     m = re.match(r"(stem_pool|stem_conv|stem_wgrad)_kernel<(\d+),", short)
     if m: return f"{m.group(1)}<{m.group(2)}>"
     return {"maxpool_fwd_kernel": "maxpool_fwd", "maxpool_bwd_kernel": "maxpool_bwd", "detect_kernel": "detect"}.get(short, short)
