@@ -228,6 +228,33 @@ def main():
                        'tflops': round(v['flops'] / (v['ms'] / 1e3) / 1e12, 2) if v['ms'] > 0 else 0,
                        'gbs': round(v['bytes'] / (v['ms'] / 1e3) / 1e9, 1) if v['ms'] > 0 else 0}
                    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
+        # the two layer families BASELINE.json's north_star asks for: HBM rate of the memory-bound 1x1 squeeze layers,
+        # matrix-core rate of the 3x3 expand / ConvDet layers (forward launches of this step; per-shape medians)
+        import re as _re
+        fam = {'squeeze_1x1': [0.0, 0.0, 0.0, 0, 0.0], 'expand3x3_convdet': [0.0, 0.0, 0.0, 0, 0.0]}       # ms, direct flops, bytes, launches, executed flops
+        for kname, v in summ.items():
+            for tag, t in v['tags'].items():
+                m = _re.match(r'(\d+)tap C(\d+) N(\d+) ', tag)
+                if not m or len(t) < 4:
+                    continue
+                taps, Cc, Nn = int(m.group(1)), int(m.group(2)), int(m.group(3))
+                key = 'squeeze_1x1' if (taps == 1 and Nn < Cc) else ('expand3x3_convdet' if taps == 9 else None)
+                if key is None:
+                    continue
+                direct = t[2] * (2.25 if kname.startswith('conv_wino') else 1.0)                  # direct-form flops of the layer
+                f = fam[key]; f[0] += t[1]; f[1] += direct; f[2] += t[3]; f[3] += int(round(t[0])); f[4] += t[2]
+        layer_families = {
+            'squeeze_1x1': {'launches_per_step': fam['squeeze_1x1'][3], 'ms_per_step': round(fam['squeeze_1x1'][0], 4),
+                            'achieved_gbs': round(fam['squeeze_1x1'][2] / max(fam['squeeze_1x1'][0], 1e-9) / 1e6, 1),
+                            'frac_of_hbm_peak': round(fam['squeeze_1x1'][2] / max(fam['squeeze_1x1'][0], 1e-9) / 1e6 / PEAK_HBM_GBS, 4),
+                            'note': 'algorithmic bytes (input + output windows + weights) / HIP-event time; includes the squeeze data gradients in training mode'},
+            'expand3x3_convdet': {'launches_per_step': fam['expand3x3_convdet'][3], 'ms_per_step': round(fam['expand3x3_convdet'][0], 4),
+                                  'executed_tflops': round(fam['expand3x3_convdet'][4] / max(fam['expand3x3_convdet'][0], 1e-9) / 1e9, 2),
+                                  'frac_of_fp32_mfma_peak': round(fam['expand3x3_convdet'][4] / max(fam['expand3x3_convdet'][0], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                  'direct_form_tflops': round(fam['expand3x3_convdet'][1] / max(fam['expand3x3_convdet'][0], 1e-9) / 1e9, 2),
+                                  'frac_of_fp32_mfma_peak_direct_form': round(fam['expand3x3_convdet'][1] / max(fam['expand3x3_convdet'][0], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                  'note': 'executed = multiply-adds the matrix cores perform (Winograd launches: direct form / 2.25); direct_form = the 3x3 convolution flops'},
+        }
         cpu = None
         if not args.no_cpu_baseline and args.mode == 'infer' and world == 1:      # rank 0 at N = 1 only (bounded sample)
             cpu = cpu_baseline(cfg, sd, B)
@@ -240,6 +267,7 @@ def main():
                        'input': '3x384x1248 fp32 NCHW, HBM resident', 'weights': 'synthetic Kaiming-scale, seed 1234',
                        'parallelism': f'replicas x{world}' if args.mode == 'infer' else f'dp{world}'},
             'roofline': roof, 'cpu_baseline': cpu, 'whole_network': whole, 'timed_with': 'hipGraph replay' if graph is not None else 'eager launches',
+            'layer_families': layer_families,
             'kernels_event_profile': kernels,
         }
         print(json.dumps(line))

@@ -25,6 +25,9 @@
 // Packed weights: U[C/8][8 position pairs][Npad/16][4 channel pairs][16 n][position parity][2 channels] -- the LDS image
 // of a slice is a set of contiguous runs (sqd_pack_wino_weight; host: ops.WinoPlan).
 #include "sqd_common.h"
+#ifndef SQD_WINO_DMA_EARLY
+#define SQD_WINO_DMA_EARLY 0      /* 1: issue the whole next stage at the first MFMA step -- measured 5-8 % slower than spreading it */
+#endif
 
 struct WinoArgs {
   const float* x; const float* u; const float* bias; float* y;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       for (int step = 0; step < NSTEP; ++step) {
 #pragma unroll
         for (int q = 0; q < NDMA; ++q) {
-          if (q * NSTEP / NDMA != step) continue;
+          if (((SQD_WINO_DMA_EARLY) ? 0 : q * NSTEP / NDMA) != step) continue;
           if (q < RAW_IT) dma_raw_one(q < RAW_IT ? q : 0, nsoff);
           else dma_u_one(q - RAW_IT, ncc, ubuf ^ 1);
         }

@@ -44,7 +44,7 @@ class KernelTimer:
             d = out.setdefault(name, dict(launches=0.0, ms=0.0, flops=0.0, bytes=0.0, tags={}))
             d['launches'] += per_step; d['ms'] += med * per_step
             d['flops'] += g['flops'] * per_step; d['bytes'] += g['bytes'] * per_step
-            d['tags'][tag] = [per_step, med * per_step]
+            d['tags'][tag] = [per_step, med * per_step, g['flops'] * per_step, g['bytes'] * per_step]
         return out
 
 
