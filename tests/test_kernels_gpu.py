@@ -265,3 +265,43 @@ def test_conv_winograd_dgrad_epilogue():
         assert (y.cpu() - _nhwc(exp)).abs().max().item() <= _tol(exp), f'wino cfg {cid}'
     with pytest.raises(ValueError):
         ops.conv_wino(_nhwc(dy).cuda(), 0, plan, y, 0, ymask=torch.zeros(B, H, W, N + 4, device='cuda'))
+
+
+def test_wgrad_batched_reduce_is_bitwise_the_per_layer_reduce():
+    """ops.WgradBatch (partial slabs of several layers + ONE reduction into a flat buffer) == per-layer conv_wgrad,
+    bit for bit, for 1x1 and 3x3 layers of different sizes."""
+    ops = _ops()
+    B, H, W = 2, 9, 21
+    layers = [('a', 32, 16, 9), ('b', 16, 64, 1), ('c', 72, 24, 9), ('d', 48, 48, 1)]       # (key, N, C, taps)
+    off, entries, slots = 0, [], {}
+    for key, N, C, taps in layers:
+        slots[key] = (off, off + N * C * taps)
+        entries.append((key, N, C, taps, B, H, W, off, off + N * C * taps))
+        off += N * C * taps + N
+    wb = ops.WgradBatch(entries, torch.device('cuda'))
+    flat = torch.full((off,), float('nan'), device='cuda')
+    want = {}
+    for i, (key, N, C, taps) in enumerate(layers):
+        dy = _rand(B, H, W, N + 8, seed=40 + i).cuda(); x = _rand(B, H, W, C + 4, seed=50 + i).cuda()
+        want[key] = ops.conv_wgrad(dy, 4, N, x, 4, C, taps)
+        assert ops.conv_wgrad(dy, 4, N, x, 4, C, taps, slab=wb.slab(key)) is None
+    wb.reduce(flat)
+    for key, N, C, taps in layers:
+        wo, bo = slots[key]
+        k = 3 if taps == 9 else 1
+        assert torch.equal(flat[wo:bo].view(N, C, k, k), want[key][0]), key
+        assert torch.equal(flat[bo:bo + N], want[key][1]), key
+    with pytest.raises(ValueError):
+        ops.conv_wgrad(dy, 4, N, x, 4, C, taps, slab=wb.slab('a'))                          # slab of another layer
+
+
+def test_winograd_batched_repack_matches_single_pack():
+    ops = _ops()
+    ws = [_rand(64, 16, 3, 3, seed=60).cuda(), _rand(72, 24, 3, 3, seed=61).cuda()]
+    plans = [ops.WinoPlan(ws[0], None, 0), ops.WinoPlan(ws[1], None, 2, dgrad=True)]
+    ref = [p.w.clone() for p in plans]
+    for p in plans:
+        p.w.fill_(float('nan'))
+    ops.repack_wino_batched(list(zip(plans, ws)), [False, True])
+    for p, r in zip(plans, ref):
+        assert torch.equal(p.w, r)
