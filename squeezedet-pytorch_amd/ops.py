@@ -714,7 +714,10 @@ def wgrad_split(N, C, taps, B, H, W):
     return S, N * taps * C + N
 
 
-def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None):
+WINO_WGRAD = True          # 3x3 weight gradients: Winograd kernel where it applies (N % 64 == 0)
+
+
+def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
     """(dW OIHW [N,C,k,k], db [N]) from dy[..., dy_coff:dy_coff+N] (already ReLU-masked) and
     x[..., x_coff:x_coff+C].  With ``slab`` (a workspace view of S * stride floats, see ``WgradBatch``) only the partial
     slabs are written and None is returned: the caller reduces all layers with one launch."""
@@ -736,11 +739,20 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None):
         slab = torch.empty(S * stride, device=dy.device, dtype=torch.float32)
         dw = torch.empty(N, C, k, k, device=dy.device, dtype=torch.float32)
         db = torch.empty(N, device=dy.device, dtype=torch.float32)
-    br = _Bracket(f'conv_wgrad<{taps}>', f'wgrad {taps}tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * taps,
-                  4.0 * (B * H * W * (C + N) + 2 * S * stride)) if _timer is not None else None
-    rc = nat.lib().sqd_conv_wgrad(nat.ptr(dy), nat.ptr(x), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, dyp, dy_coff,
-                                  C, xp, x_coff, taps, S, nat.stream_handle(dy.device))
-    nat.check(rc, 'sqd_conv_wgrad')
+    use_wino = (WINO_WGRAD if wino is None else wino) and taps == 9 and N % 64 == 0 and S <= B * -(-H // 4) * -(-W // 16)
+    if use_wino:
+        # executed multiply-adds = direct form / 2.25 (16 position GEMMs per 2x2 tile)
+        br = _Bracket('conv_wgrad_wino', f'wgrad 9tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * 4,
+                      4.0 * (B * H * W * (C + N) + 2 * S * stride)) if _timer is not None else None
+        rc = nat.lib().sqd_conv_wgrad_wino(nat.ptr(dy), nat.ptr(x), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, dyp, dy_coff,
+                                           C, xp, x_coff, S, nat.stream_handle(dy.device))
+        nat.check(rc, 'sqd_conv_wgrad_wino')
+    else:
+        br = _Bracket(f'conv_wgrad<{taps}>', f'wgrad {taps}tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * taps,
+                      4.0 * (B * H * W * (C + N) + 2 * S * stride)) if _timer is not None else None
+        rc = nat.lib().sqd_conv_wgrad(nat.ptr(dy), nat.ptr(x), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, dyp, dy_coff,
+                                      C, xp, x_coff, taps, S, nat.stream_handle(dy.device))
+        nat.check(rc, 'sqd_conv_wgrad')
     if br is not None:
         br.done()
     return None if deferred else (dw, db)

@@ -305,3 +305,26 @@ def test_winograd_batched_repack_matches_single_pack():
     ops.repack_wino_batched(list(zip(plans, ws)), [False, True])
     for p, r in zip(plans, ref):
         assert torch.equal(p.w, r)
+
+
+@pytest.mark.parametrize("C,N,B,H,W", [
+    (16, 64, 2, 12, 20), (32, 128, 1, 9, 33), (48, 192, 1, 24, 78), (96, 64, 1, 5, 17), (64, 256, 2, 8, 16), (24, 64, 3, 3, 3),
+])
+def test_conv_wgrad_winograd(C, N, B, H, W):
+    """Winograd weight gradient == autograd of fp32 conv2d (same bound as the direct kernel), channel windows, odd sizes,
+    partial last input-channel block; and agrees with the direct kernel."""
+    ops = _ops()
+    x = _rand(B, C, H, W, seed=71).requires_grad_(False)
+    dy = _rand(B, N, H, W, seed=72)
+    w = torch.zeros(N, C, 3, 3, requires_grad=True); b = torch.zeros(N, requires_grad=True)
+    F.conv2d(x, w, b, padding=1).backward(dy)
+    dyb = _rand(B, H, W, N + 8, seed=73); dyb[..., 4:4 + N] = _nhwc(dy)
+    xb = _rand(B, H, W, C + 4, seed=74); xb[..., 4:4 + C] = _nhwc(x)
+    dw, db = ops.conv_wgrad(dyb.cuda(), 4, N, xb.cuda(), 4, C, 9, wino=True)
+    dw0, db0 = ops.conv_wgrad(dyb.cuda(), 4, N, xb.cuda(), 4, C, 9, wino=False)
+    sc = max(1.0, w.grad.abs().max().item())
+    assert (dw.cpu() - w.grad).abs().max().item() <= 1e-4 * sc
+    assert (db.cpu() - b.grad).abs().max().item() <= 1e-4 * max(1.0, b.grad.abs().max().item())
+    assert (dw - dw0).abs().max().item() <= 1e-4 * sc and (db - db0).abs().max().item() <= 1e-4 * sc
+    dw2, db2 = ops.conv_wgrad(dyb.cuda(), 4, N, xb.cuda(), 4, C, 9, wino=True)        # fixed-order sums: bitwise reproducible
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
