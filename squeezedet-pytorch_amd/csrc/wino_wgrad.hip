@@ -1,0 +1,273 @@
+// Winograd F(2x2,3x3) weight gradient (see the block comment below); split-K slabs and their reduction are shared with
+// the direct kernels of wgrad.hip.  Built without the SI load/store optimiser (Makefile): it would pair the transform's
+// ds_read_b32 by address adjacency, not by the (tile row 0, tile row 1) register pairs the packed arithmetic works on.
+#include "sqd_common.h"
+
+extern "C" int sqd_wgrad_reduce_launch(const float* slab, float* dw, float* db, int S, long long slab_stride, int N, int C, int taps,
+                                       void* stream);
+
+// ---------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) weight gradient of a 3x3 / pad 1 convolution.
+//   dW = sum over 2x2 output tiles of  G^T [ (A dY A^T) .* (B^T d B) ] G
+// i.e. per transform position (xi, nu) a GEMM dU[n][c] = sum_tiles dM[tile][n] * V[tile][c] with the TILE axis as K --
+// 2.25x fewer multiply-adds than the direct form (conv_wgrad_kernel above).  Same split-K slab scheme and slab layout,
+// so the (batched) slab reduction is shared.
+// A workgroup (4 waves) owns TN*16 output channels x TC*16 input channels and every S-th 4x16-pixel group (16 tiles);
+// wave xi owns the four positions (xi, 0..3).  Per group the dY tile (64 px) and the X patch (6x18 px) arrive by LDS-DMA
+// (buffer resources, zero fill by the range check) in a double buffer; both operands are transformed IN REGISTERS straight
+// into the MFMA layout: lane (lr, g) holds channel lr of a 16-channel block for the 2x2 tile quad g, so its four tiles
+// are the four k-steps of one v_mfma_f32_16x16x4_f32 operand.  Row transforms are wave-uniform two-term combinations
+// (coefficients 0 / +-1: exact), column transforms are fixed; everything is written on register pairs so that it
+// compiles to packed fp32 instructions.  After the last group dg = G^T dU G: the nu sum inside the wave, the xi sum
+// across the waves through LDS in a fixed order (bitwise reproducible); the bias gradient is the tile sum, which IS
+// position (1,1) of A dY A^T, accumulated by wave 1 against a constant 1 operand.
+// ---------------------------------------------------------------------------------------------
+struct WwArgs {
+  const float* dy; const float* x; float* slab;
+  int B, H, W;
+  int N, dy_pitch, dy_coff;
+  int C, x_pitch, x_coff;
+  int gxn, gyn, ngroups;
+  int S, ncg;
+  long long slab_stride;
+};
+typedef __attribute__((address_space(3))) void* lds_ptr_ww_t;
+
+template <int TN, int TC>
+__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CHD = TN * 16, CHX = TC * 16;
+  constexpr int DQ = TN * 4, XQ = TC * 4;                  // 16-byte slots per pixel
+  constexpr int DSLOTS = 64 * DQ, D_IT = DSLOTS / 256;
+  constexpr int XREAL = 108 * XQ, X_IT = (XREAL + 255) / 256, XSLOTS = X_IT * 256;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const dyB = smem;                                  // [2][DSLOTS][4]: dY tile, pixel-major [64 px][CHD]
+  float* const xB = smem + 2 * DSLOTS * 4;                  // [2][XSLOTS][4]: X patch [108 px][CHX]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int xi = __builtin_amdgcn_readfirstlane(wv);
+  const int s = (int)blockIdx.x % a.S, bg = (int)blockIdx.x / a.S;
+  const int ng = bg / a.ncg, cg = bg - ng * a.ncg;
+  const int n0 = ng * CHD, c0 = cg * CHX;
+
+  int d_offB[D_IT], d_key[D_IT];
+#pragma unroll
+  for (int it = 0; it < D_IT; ++it) {
+    const int slot = it * 256 + tid;
+    const int px = slot / DQ, chq = slot - px * DQ;
+    const int row = px >> 4, col = px & 15;
+    d_key[it] = row << 8 | col;
+    d_offB[it] = ((row * a.W + col) * a.dy_pitch + 4 * chq) * 4;
+  }
+  int x_offB[X_IT], x_key[X_IT];
+#pragma unroll
+  for (int it = 0; it < X_IT; ++it) {
+    const int slot = it * 256 + tid;
+    const int px = slot / XQ, chq = slot - px * XQ;
+    const bool real = px < 108 && c0 + 4 * chq < a.C;       // channels past C (partial last block) stay zero
+    const int r = px / 18, c = px - r * 18;
+    x_key[it] = real ? (r << 8 | c) : -1;
+    x_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * chq) * 4 : 0;
+  }
+  const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + a.dy_coff + n0), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + a.x_coff + c0 - (long long)(a.W + 1) * a.x_pitch), 0, 0x7ffffff0, 0x00020000);
+  const int wv_s = xi;
+
+  auto issue = [&](int q, int buf) {                         // DMA of group q into buffer buf (all wave-uniform but the offsets)
+    const int gxi = q % a.gxn; int t = q / a.gxn;
+    const int gyi = t % a.gyn; const int b = t / a.gyn;
+    const int y0 = gyi * 4, x0 = gxi * 16;
+    const long long p0 = ((long long)b * a.H + y0) * a.W + x0;
+    const unsigned soffD = (unsigned)(p0 * a.dy_pitch * 4), soffX = (unsigned)(p0 * a.x_pitch * 4);
+#pragma unroll
+    for (int it = 0; it < D_IT; ++it) {
+      const int key = d_key[it];
+      const bool ok = y0 + (key >> 8) < a.H && x0 + (key & 255) < a.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dres, (lds_ptr_ww_t)(dyB + (buf * DSLOTS + it * 256 + wv_s * 64) * 4), 16,
+                                               ok ? d_offB[it] : (int)OOB, (int)soffD, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int key = x_key[it];
+      const bool ok = key >= 0 && (unsigned)(y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(x0 + (key & 255) - 1) < (unsigned)a.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_ww_t)(xB + (buf * XSLOTS + it * 256 + wv_s * 64) * 4), 16,
+                                               ok ? x_offB[it] : (int)OOB, (int)soffX, 0, 0);
+    }
+  };
+
+  // Wave-uniform row transforms, each ONE packed fma per register pair (every VALU instruction stalls the MFMA stream):
+  //   V row xi of B^T d B   = sgx * (d[i1] + sx * d[i2]):  xi0: d0 - d2, xi1: d1 + d2, xi2: -(d1 - d2), xi3: d1 - d3
+  //   dM row xi of A dY A^T = sgd * (y[r0] + sd * y[1]):   xi0: y0 (sd = 0), xi1: y0 + y1, xi2: y0 - y1, xi3: -(y1 + 0 * y1)
+  // The overall signs sgx * sgd multiply the whole dU row: applied once, in the epilogue.  Column nu = 3 of dM is -r1:
+  // that sign moves into V's column 3 (t3 - t1 instead of t1 - t3).
+  const int i1 = (xi == 0) ? 0 : 1, i2 = (xi == 3) ? 3 : 2;
+  const float sx = (xi == 1) ? 1.f : -1.f;
+  const float sd = (xi == 0 || xi == 3) ? 0.f : ((xi == 1) ? 1.f : -1.f);
+  const int r0 = (xi == 3) ? 1 : 0;                           // xi = 3: "y0" is read from row 1 as well (r = y1 + 0 * y1)
+  const float row_sign = ((xi == 2) ? -1.f : 1.f) * ((xi == 3) ? -1.f : 1.f);
+  const f32x2 sx2 = {sx, sx}, sd2 = {sd, sd};
+  // lane bases (floats): dY element (px, ch) at px*CHD + ch, X element at px*CHX + ch; the quad's 4 pixel columns 4g..
+  const int dL0 = (r0 * 16 + 4 * g) * CHD + lr, dL1 = (1 * 16 + 4 * g) * CHD + lr;
+  const int xL1 = (i1 * 18 + 4 * g) * CHX + lr, xL2 = (i2 * 18 + 4 * g) * CHX + lr;
+
+  f32x4 acc[4][TN][TC], accb[TN];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j) acc[nu][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TN; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int buf = 0;
+  issue(s, 0);
+  for (int q = s; q < a.ngroups; q += a.S) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the group's DMA has landed ...
+    __syncthreads();                                         // ... and is published; the other buffer is free again
+    if (q + a.S < a.ngroups) issue(q + a.S, buf ^ 1);
+    const float* const dP0 = dyB + buf * DSLOTS * 4 + dL0;
+    const float* const dP1 = dyB + buf * DSLOTS * 4 + dL1;
+    const float* const xP1 = xB + buf * XSLOTS * 4 + xL1;
+    const float* const xP2 = xB + buf * XSLOTS * 4 + xL2;
+
+    // ---- V = B^T d B, row xi, for every input-channel block: bfr[cb][nu] = 4 tiles (k-steps) of channel lr ----
+    // tile member t = 2*txl + ty (tile column 2g+txl, tile row ty): the (ty=0, ty=1) pair sits in adjacent registers
+    f32x4 bfr[TC][4];
+#pragma unroll
+    for (int cbk = 0; cbk < TC; ++cbk) {
+      f32x2 tt[6];                                           // row-transformed patch columns 0..5 of the quad, pair over ty
+#pragma unroll
+      for (int jj = 0; jj < 6; ++jj) {
+        const f32x2 d1 = {xP1[(0 * 18 + jj) * CHX + cbk * 16], xP1[(2 * 18 + jj) * CHX + cbk * 16]};
+        const f32x2 d2 = {xP2[(0 * 18 + jj) * CHX + cbk * 16], xP2[(2 * 18 + jj) * CHX + cbk * 16]};
+        tt[jj] = __builtin_elementwise_fma(sx2, d2, d1);
+      }
+#pragma unroll
+      for (int txl = 0; txl < 2; ++txl) {
+        const int j0 = 2 * txl;
+        const f32x2 v0 = tt[j0] - tt[j0 + 2], v1 = tt[j0 + 1] + tt[j0 + 2], v2 = tt[j0 + 2] - tt[j0 + 1], v3 = tt[j0 + 3] - tt[j0 + 1];   // (sign of dM column 3)
+        if (txl == 0) { bfr[cbk][0].lo = v0; bfr[cbk][1].lo = v1; bfr[cbk][2].lo = v2; bfr[cbk][3].lo = v3; }
+        else          { bfr[cbk][0].hi = v0; bfr[cbk][1].hi = v1; bfr[cbk][2].hi = v2; bfr[cbk][3].hi = v3; }
+      }
+    }
+    // ---- per output-channel block: dM = A dY A^T, row xi, then the MFMAs over (nu, cb, k-step) ----
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      f32x4 afr[4];
+#pragma unroll
+      for (int txl = 0; txl < 2; ++txl) {
+        f32x2 rp[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x2 y0 = {dP0[(2 * txl + j) * CHD + nb * 16], dP0[(2 * 16 + 2 * txl + j) * CHD + nb * 16]};
+          const f32x2 y1 = {dP1[(2 * txl + j) * CHD + nb * 16], dP1[(2 * 16 + 2 * txl + j) * CHD + nb * 16]};
+          rp[j] = __builtin_elementwise_fma(sd2, y1, y0);
+        }
+        const f32x2 m0 = rp[0], m1 = rp[0] + rp[1], m2 = rp[0] - rp[1], m3 = rp[1];
+        if (txl == 0) { afr[0].lo = m0; afr[1].lo = m1; afr[2].lo = m2; afr[3].lo = m3; }
+        else          { afr[0].hi = m0; afr[1].hi = m1; afr[2].hi = m2; afr[3].hi = m3; }
+      }
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int cbk = 0; cbk < TC; ++cbk)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[nu][nb][cbk] = mfma16(afr[nu][t], bfr[cbk][nu][t], acc[nu][nb][cbk]);
+      if (xi == 1) {                                         // bias gradient: position (1,1) of A dY A^T is the tile sum
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accb[nb] = mfma16(afr[1][t], 1.0f, accb[nb]);
+      }
+    }
+    buf ^= 1;
+  }
+
+  // ---- dg = G^T dU G: nu sum in registers, xi sum across the waves through LDS (fixed order) ----
+  float* const sl = a.slab + (long long)s * a.slab_stride;
+  f32x4* const wL = (f32x4*)smem;                            // [4 waves][3][TC][64 lanes] (+ bias row)
+  f32x4* const bL = wL + 4 * 3 * TC * 64;                    // [64 lanes]
+  const long long nw = (long long)a.N * 9 * a.C;
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    __syncthreads();
+#pragma unroll
+    for (int cbk = 0; cbk < TC; ++cbk) {
+      const f32x4 u0 = row_sign * acc[0][nb][cbk], u1 = row_sign * acc[1][nb][cbk], u2 = row_sign * acc[2][nb][cbk], u3 = row_sign * acc[3][nb][cbk];
+      const f32x4 h = 0.5f * (u1 + u2);
+      wL[((xi * 3 + 0) * TC + cbk) * 64 + lane] = u0 + h;
+      wL[((xi * 3 + 1) * TC + cbk) * 64 + lane] = 0.5f * (u1 - u2);
+      wL[((xi * 3 + 2) * TC + cbk) * 64 + lane] = h + u3;
+    }
+    if (xi == 1) bL[lane] = accb[nb];
+    __syncthreads();
+    if (xi < 3) {                                            // wave r = xi finishes kernel row r
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int cbk = 0; cbk < TC; ++cbk) {
+          const f32x4 w0 = wL[((0 * 3 + s3) * TC + cbk) * 64 + lane], w1 = wL[((1 * 3 + s3) * TC + cbk) * 64 + lane];
+          const f32x4 w2 = wL[((2 * 3 + s3) * TC + cbk) * 64 + lane], w3 = wL[((3 * 3 + s3) * TC + cbk) * 64 + lane];
+          f32x4 v;
+          if (xi == 0) v = w0 + 0.5f * (w1 + w2);
+          else if (xi == 1) v = 0.5f * (w1 - w2);
+          else v = 0.5f * (w1 + w2) + w3;
+          const int c = c0 + cbk * 16 + lr;
+          if (c < a.C) {
+            const int tap = xi * 3 + s3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sl[((long long)(n0 + nb * 16 + 4 * g + i) * 9 + tap) * a.C + c] = v[i];
+          }
+        }
+    } else if (cg == 0 && lr == 0) {                         // wave 3: bias gradient (every column of the 1-operand product is the sum)
+      const f32x4 v = bL[lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sl[nw + n0 + nb * 16 + 4 * g + i] = v[i];
+    }
+  }
+#endif
+}
+
+template <int TN, int TC>
+static int launch_wino_wgrad(WwArgs a, hipStream_t stream) {
+  constexpr int DSLOTS = 64 * TN * 4, XSLOTS = (108 * TC * 4 + 255) / 256 * 256;
+  constexpr size_t lds = (size_t)2 * (DSLOTS + XSLOTS) * 16;
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  static_assert((size_t)(4 * 3 * TC + 1) * 64 * 16 <= lds, "epilogue exchange fits the staging buffers");
+  auto kern = wino_wgrad_kernel<TN, TC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SQD_ERR_LAUNCH;
+    attr_done = true;
+  }
+  a.ncg = sqd_cdiv(a.C, TC * 16);
+  const int groups = (a.N / (TN * 16)) * a.ncg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * a.S)), dim3(256), lds, stream, a);
+  return sqd_launch_status();
+}
+
+// Winograd form of sqd_conv_wgrad for 3x3 layers (same arguments, slab layout and dw == NULL convention); supported:
+// N % 64 == 0, C % 4 == 0, S <= number of 4x16-pixel groups.  Returns SQD_ERR_UNSUPPORTED otherwise.
+extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
+                                   int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, void* stream) {
+  SQD_CHECK_ARG(dy && x && slab && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535);
+  SQD_CHECK_ARG((N & 3) == 0 && (C & 3) == 0 && (dy_pitch & 3) == 0 && (dy_coff & 3) == 0 && (x_pitch & 3) == 0 && (x_coff & 3) == 0);
+  SQD_CHECK_ARG(dy_coff + N <= dy_pitch && x_coff + C <= x_pitch);
+  SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0);
+  WwArgs a;
+  a.dy = dy; a.x = x; a.slab = slab; a.B = B; a.H = H; a.W = W;
+  a.N = N; a.dy_pitch = dy_pitch; a.dy_coff = dy_coff; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.gxn = sqd_cdiv(W, 16); a.gyn = sqd_cdiv(H, 4); a.ngroups = B * a.gxn * a.gyn;
+  a.S = S; a.slab_stride = (long long)N * 9 * C + N;
+  if (N % 64 || S > a.ngroups) return SQD_ERR_UNSUPPORTED;
+  const long long px = (long long)B * H * W;
+  if (px * dy_pitch * 4 >= (3ll << 30) || px * x_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;   // 32-bit SGPR byte offsets
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = (C <= 16) ? launch_wino_wgrad<4, 1>(a, s) : launch_wino_wgrad<4, 2>(a, s);
+  if (rc != SQD_OK || !dw) return rc;
+  return sqd_wgrad_reduce_launch(slab, dw, db, S, a.slab_stride, N, C, 9, stream);
+}
+
