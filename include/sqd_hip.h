@@ -60,7 +60,7 @@ int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, floa
                    void* stream);
 /* Winograd F(2x2,3x3) form of sqd_conv_wgrad for the 3x3 layers (Fire expand3x3, src/model/squeezedet.py:14; autograd of
  * nn.Conv2d as triggered by loss.backward(), src/engine/trainer.py:47): same arguments (taps is 9), slab layout and
- * dw == NULL convention; executes 2.25x fewer multiply-adds.  Supported: N % 64 == 0 and S <= B * ceil(H/4) * ceil(W/16);
+ * dw == NULL convention; executes 2.25x fewer multiply-adds.  Supported: (N % 64 == 0 or N <= 80) and S <= B * ceil(H/4) * ceil(W/16);
  * SQD_ERR_UNSUPPORTED otherwise (use sqd_conv_wgrad). */
 int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
                         int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, void* stream);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
     const int slot = it * 256 + tid;
     const int px = slot / DQ, chq = slot - px * DQ;
     const int row = px >> 4, col = px & 15;
-    d_key[it] = row << 8 | col;
+    d_key[it] = (n0 + 4 * chq < a.N) ? (row << 8 | col) : -1;        // channels past N (partial last block) stay zero
     d_offB[it] = ((row * a.W + col) * a.dy_pitch + 4 * chq) * 4;
   }
   int x_offB[X_IT], x_key[X_IT];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 #pragma unroll
     for (int it = 0; it < D_IT; ++it) {
       const int key = d_key[it];
-      const bool ok = y0 + (key >> 8) < a.H && x0 + (key & 255) < a.W;
+      const bool ok = key >= 0 && y0 + (key >> 8) < a.H && x0 + (key & 255) < a.W;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(dres, (lds_ptr_ww_t)(dyB + (buf * DSLOTS + it * 256 + wv_s * 64) * 4), 16,
                                                ok ? d_offB[it] : (int)OOB, (int)soffD, 0, 0);
     }
@@ -214,14 +214,14 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
           if (xi == 0) v = w0 + 0.5f * (w1 + w2);
           else if (xi == 1) v = 0.5f * (w1 - w2);
           else v = 0.5f * (w1 + w2) + w3;
-          const int c = c0 + cbk * 16 + lr;
-          if (c < a.C) {
+          const int c = c0 + cbk * 16 + lr, n = n0 + nb * 16 + 4 * g;
+          if (c < a.C && n < a.N) {                           // (N, C multiples of 4: a quad of channels is in or out as a whole)
             const int tap = xi * 3 + s3;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sl[((long long)(n0 + nb * 16 + 4 * g + i) * 9 + tap) * a.C + c] = v[i];
+            for (int i = 0; i < 4; ++i) sl[((long long)(n + i) * 9 + tap) * a.C + c] = v[i];
           }
         }
-    } else if (cg == 0 && lr == 0) {                         // wave 3: bias gradient (every column of the 1-operand product is the sum)
+    } else if (cg == 0 && lr == 0 && n0 + nb * 16 + 4 * g < a.N) {   // wave 3: bias gradient (every column of the 1-operand product is the sum)
       const f32x4 v = bL[lane];
 #pragma unroll
       for (int i = 0; i < 4; ++i) sl[nw + n0 + nb * 16 + 4 * g + i] = v[i];
@@ -244,13 +244,13 @@ static int launch_wino_wgrad(WwArgs a, hipStream_t stream) {
     attr_done = true;
   }
   a.ncg = sqd_cdiv(a.C, TC * 16);
-  const int groups = (a.N / (TN * 16)) * a.ncg;
+  const int groups = sqd_cdiv(a.N, TN * 16) * a.ncg;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * a.S)), dim3(256), lds, stream, a);
   return sqd_launch_status();
 }
 
 // Winograd form of sqd_conv_wgrad for 3x3 layers (same arguments, slab layout and dw == NULL convention); supported:
-// N % 64 == 0, C % 4 == 0, S <= number of 4x16-pixel groups.  Returns SQD_ERR_UNSUPPORTED otherwise.
+// N % 64 == 0 or N <= 80, C % 4 == 0, S <= number of 4x16-pixel groups.  Returns SQD_ERR_UNSUPPORTED otherwise.
 extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
                                    int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, void* stream) {
   SQD_CHECK_ARG(dy && x && slab && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535);
@@ -262,11 +262,12 @@ extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab,
   a.N = N; a.dy_pitch = dy_pitch; a.dy_coff = dy_coff; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.gxn = sqd_cdiv(W, 16); a.gyn = sqd_cdiv(H, 4); a.ngroups = B * a.gxn * a.gyn;
   a.S = S; a.slab_stride = (long long)N * 9 * C + N;
-  if (N % 64 || S > a.ngroups) return SQD_ERR_UNSUPPORTED;
+  if ((N % 64 && N > 80) || S > a.ngroups) return SQD_ERR_UNSUPPORTED;
   const long long px = (long long)B * H * W;
   if (px * dy_pitch * 4 >= (3ll << 30) || px * x_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;   // 32-bit SGPR byte offsets
   hipStream_t s = (hipStream_t)stream;
-  const int rc = (C <= 16) ? launch_wino_wgrad<4, 1>(a, s) : launch_wino_wgrad<4, 2>(a, s);
+  // N <= 80 (ConvDet: 72): one 5-block output-channel group; else 64-channel groups
+  const int rc = (N % 64) ? launch_wino_wgrad<5, 1>(a, s) : ((C <= 16) ? launch_wino_wgrad<4, 1>(a, s) : launch_wino_wgrad<4, 2>(a, s));
   if (rc != SQD_OK || !dw) return rc;
   return sqd_wgrad_reduce_launch(slab, dw, db, S, a.slab_stride, N, C, 9, stream);
 }

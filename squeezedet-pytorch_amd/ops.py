@@ -693,8 +693,23 @@ _TARGET_WGS = 1536          # workgroups a 3x3 weight-gradient launch aims for (
 _TARGET_WGS_1X1 = 1024      # 1x1: fewer, longer pixel streams (less slab traffic per MFMA)
 
 
-def wgrad_split(N, C, taps, B, H, W):
+WINO_WGRAD = True          # 3x3 weight gradients: Winograd kernel where it applies (N % 64 == 0)
+_TARGET_WGS_WINO = 512      # Winograd wgrad: one resident round (two 4-wave workgroups per CU), every workgroup the same work
+
+
+def wgrad_uses_wino(N, C, taps, B, H, W, wino=None):
+    """Whether conv_wgrad runs the Winograd F(2x2,3x3) kernel for this layer (3x3, N % 64 == 0; ``wino`` overrides the
+    module default WINO_WGRAD)."""
+    return bool(WINO_WGRAD if wino is None else wino) and taps == 9 and (N % 64 == 0 or N <= 80) and N % 4 == 0 and C % 4 == 0
+
+
+def wgrad_split(N, C, taps, B, H, W, wino=None):
     """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab."""
+    if wgrad_uses_wino(N, C, taps, B, H, W, wino):
+        ngroups = B * -(-H // 4) * -(-W // 16)                    # 4x16-pixel groups = the K axis of the 16 position GEMMs
+        # (out-channel, in-channel) blocks of dU per workgroup: 64 x 16|32, or all of N <= 80 x 16 (ConvDet)
+        blocks = -(-C // 16) if N % 64 else (N // 64) * -(-C // (16 if C <= 16 else 32))
+        return max(1, min(ngroups, _TARGET_WGS_WINO // blocks if blocks <= _TARGET_WGS_WINO else 1)), N * taps * C + N
     tn = 4 if N >= 64 else -(-N // 16)
     if taps == 9:
         if 64 < N <= 80:
@@ -714,9 +729,6 @@ def wgrad_split(N, C, taps, B, H, W):
     return S, N * taps * C + N
 
 
-WINO_WGRAD = True          # 3x3 weight gradients: Winograd kernel where it applies (N % 64 == 0)
-
-
 def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
     """(dW OIHW [N,C,k,k], db [N]) from dy[..., dy_coff:dy_coff+N] (already ReLU-masked) and
     x[..., x_coff:x_coff+C].  With ``slab`` (a workspace view of S * stride floats, see ``WgradBatch``) only the partial
@@ -729,7 +741,8 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
     if dy_coff + N > dyp or x_coff + C > xp or N % 4 or C % 4 or taps not in (1, 9):
         raise ValueError('wgrad: channel window out of range')
     k = 3 if taps == 9 else 1
-    S, stride = wgrad_split(N, C, taps, B, H, W)
+    use_wino = wgrad_uses_wino(N, C, taps, B, H, W, wino)
+    S, stride = wgrad_split(N, C, taps, B, H, W, wino)
     deferred = slab is not None
     if deferred:
         if slab.numel() != S * stride or not slab.is_contiguous() or slab.dtype != torch.float32:
@@ -739,7 +752,6 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
         slab = torch.empty(S * stride, device=dy.device, dtype=torch.float32)
         dw = torch.empty(N, C, k, k, device=dy.device, dtype=torch.float32)
         db = torch.empty(N, device=dy.device, dtype=torch.float32)
-    use_wino = (WINO_WGRAD if wino is None else wino) and taps == 9 and N % 64 == 0 and S <= B * -(-H // 4) * -(-W // 16)
     if use_wino:
         # executed multiply-adds = direct form / 2.25 (16 position GEMMs per 2x2 tile)
         br = _Bracket('conv_wgrad_wino', f'wgrad 9tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * 4,

@@ -309,6 +309,7 @@ def test_winograd_batched_repack_matches_single_pack():
 
 @pytest.mark.parametrize("C,N,B,H,W", [
     (16, 64, 2, 12, 20), (32, 128, 1, 9, 33), (48, 192, 1, 24, 78), (96, 64, 1, 5, 17), (64, 256, 2, 8, 16), (24, 64, 3, 3, 3),
+    (768, 72, 1, 6, 18), (40, 72, 2, 7, 19), (16, 48, 1, 4, 16),
 ])
 def test_conv_wgrad_winograd(C, N, B, H, W):
     """Winograd weight gradient == autograd of fp32 conv2d (same bound as the direct kernel), channel windows, odd sizes,
