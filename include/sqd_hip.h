@@ -61,14 +61,15 @@ int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, floa
 /* Winograd F(2x2,3x3) form of sqd_conv_wgrad for the 3x3 layers (Fire expand3x3, src/model/squeezedet.py:14; autograd of
  * nn.Conv2d as triggered by loss.backward(), src/engine/trainer.py:47): same arguments (taps is 9), slab layout and
  * dw == NULL convention; executes 2.25x fewer multiply-adds.  Supported: (N % 64 == 0 or N <= 80) and S <= B * ceil(H/4) * ceil(W/16);
- * SQD_ERR_UNSUPPORTED otherwise (use sqd_conv_wgrad). */
+ * SQD_ERR_UNSUPPORTED otherwise (use sqd_conv_wgrad).  tc = input-channel blocks of 16 per workgroup (1 or 2; N % 64 != 0
+ * always runs 1). */
 int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
-                        int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, void* stream);
+                        int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, int tc, void* stream);
 
 /* dw == NULL in sqd_conv_wgrad: write the S partial slabs only; the caller then reduces many layers with ONE launch:
  * descs_dev = device array of n records of 9 int64 {slab offset, dw offset, db offset (floats from slab_base / grad_base;
  * db offset < 0: no bias gradient), S, slab stride (= N*taps*C + N), N, C, taps, first workgroup of the record}
- * (a record takes ceil((N*taps*C + N) / 32) workgroups; total_blocks = their sum).  Results are bitwise those of the
+ * (a record takes ceil((N*taps*C + N) / 64) workgroups; total_blocks = their sum).  Results are bitwise those of the
  * per-layer reduction. */
 int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base, void* stream);
 

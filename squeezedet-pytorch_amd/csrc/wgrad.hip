@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // dw (OIHW: [N][C][TAPS]) and db ([N]) = fixed-order sum of S slabs.  A block reduces 32 consecutive
 // outputs; its 8 thread groups each sum the slabs k = g, g+8, ... in ascending order, then the 8 partials
 // are combined in a fixed order through LDS -- parallel over slabs yet bitwise reproducible.
-#define WGR_OUT 32
-#define WGR_PARTS 8
+#define WGR_OUT 64          /* outputs per workgroup: 256 contiguous bytes of every slab row */
+#define WGR_PARTS 4        /* slab partitions summed in parallel, combined in a fixed order */
 __global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                            float* __restrict__ db, int S, long long slab_stride,
                                                                            int N, int C, int TAPS) {

@@ -252,8 +252,8 @@ static int launch_wino_wgrad(WwArgs a, hipStream_t stream) {
 // Winograd form of sqd_conv_wgrad for 3x3 layers (same arguments, slab layout and dw == NULL convention); supported:
 // N % 64 == 0 or N <= 80, C % 4 == 0, S <= number of 4x16-pixel groups.  Returns SQD_ERR_UNSUPPORTED otherwise.
 extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
-                                   int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, void* stream) {
-  SQD_CHECK_ARG(dy && x && slab && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535);
+                                   int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, int tc, void* stream) {
+  SQD_CHECK_ARG(dy && x && slab && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535 && (tc == 1 || tc == 2));
   SQD_CHECK_ARG((N & 3) == 0 && (C & 3) == 0 && (dy_pitch & 3) == 0 && (dy_coff & 3) == 0 && (x_pitch & 3) == 0 && (x_coff & 3) == 0);
   SQD_CHECK_ARG(dy_coff + N <= dy_pitch && x_coff + C <= x_pitch);
   SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0);
@@ -267,7 +267,7 @@ extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab,
   if (px * dy_pitch * 4 >= (3ll << 30) || px * x_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;   // 32-bit SGPR byte offsets
   hipStream_t s = (hipStream_t)stream;
   // N <= 80 (ConvDet: 72): one 5-block output-channel group; else 64-channel groups
-  const int rc = (N % 64) ? launch_wino_wgrad<5, 1>(a, s) : ((C <= 16) ? launch_wino_wgrad<4, 1>(a, s) : launch_wino_wgrad<4, 2>(a, s));
+  const int rc = (N % 64) ? launch_wino_wgrad<5, 1>(a, s) : ((tc <= 1 || C <= 16) ? launch_wino_wgrad<4, 1>(a, s) : launch_wino_wgrad<4, 2>(a, s));
   if (rc != SQD_OK || !dw) return rc;
   return sqd_wgrad_reduce_launch(slab, dw, db, S, a.slab_stride, N, C, 9, stream);
 }

@@ -703,12 +703,18 @@ def wgrad_uses_wino(N, C, taps, B, H, W, wino=None):
     return bool(WINO_WGRAD if wino is None else wino) and taps == 9 and (N % 64 == 0 or N <= 80) and N % 4 == 0 and C % 4 == 0
 
 
+def _wino_wgrad_tc(N, C):
+    """Input-channel blocks of 16 per workgroup of the Winograd wgrad kernel: 2 (32 channels) unless that would leave the
+    last block half empty (C = 16, 48, ...: measured 50 vs 62 us on C48 -> N192) or the 5-block ConvDet variant runs."""
+    return 1 if (N % 64 or C % 32 == 16 or C < 32) else 2
+
+
 def wgrad_split(N, C, taps, B, H, W, wino=None):
     """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab."""
     if wgrad_uses_wino(N, C, taps, B, H, W, wino):
         ngroups = B * -(-H // 4) * -(-W // 16)                    # 4x16-pixel groups = the K axis of the 16 position GEMMs
         # (out-channel, in-channel) blocks of dU per workgroup: 64 x 16|32, or all of N <= 80 x 16 (ConvDet)
-        blocks = -(-C // 16) if N % 64 else (N // 64) * -(-C // (16 if C <= 16 else 32))
+        blocks = -(-C // 16) if N % 64 else (N // 64) * -(-C // (16 * _wino_wgrad_tc(N, C)))
         return max(1, min(ngroups, _TARGET_WGS_WINO // blocks if blocks <= _TARGET_WGS_WINO else 1)), N * taps * C + N
     tn = 4 if N >= 64 else -(-N // 16)
     if taps == 9:
@@ -757,7 +763,7 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
         br = _Bracket('conv_wgrad_wino', f'wgrad 9tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * 4,
                       4.0 * (B * H * W * (C + N) + 2 * S * stride)) if _timer is not None else None
         rc = nat.lib().sqd_conv_wgrad_wino(nat.ptr(dy), nat.ptr(x), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, dyp, dy_coff,
-                                           C, xp, x_coff, S, nat.stream_handle(dy.device))
+                                           C, xp, x_coff, S, _wino_wgrad_tc(N, C), nat.stream_handle(dy.device))
         nat.check(rc, 'sqd_conv_wgrad_wino')
     else:
         br = _Bracket(f'conv_wgrad<{taps}>', f'wgrad {taps}tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * taps,
@@ -768,6 +774,9 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
     if br is not None:
         br.done()
     return None if deferred else (dw, db)
+
+
+_WGR_OUT = 64               # outputs per workgroup of the slab-reduction kernels (csrc/wgrad.hip WGR_OUT)
 
 
 class WgradBatch:
@@ -782,7 +791,7 @@ class WgradBatch:
             rows.append([off, dw_off, db_off, S, stride, N, C, taps, blk])
             self.slabs[key] = (off, S * stride)
             off += S * stride
-            blk += -(-stride // 32)
+            blk += -(-stride // _WGR_OUT)
         self.total_blocks = blk
         self.workspace = torch.empty(off, device=device, dtype=torch.float32)
         self.table = torch.tensor(rows, dtype=torch.int64).to(device)
