@@ -25,6 +25,7 @@
 // Packed weights: U[C/8][8 position pairs][Npad/16][4 channel pairs][16 n][position parity][2 channels] -- the LDS image
 // of a slice is a set of contiguous runs (sqd_pack_wino_weight; host: ops.WinoPlan).
 #include "sqd_common.h"
+#include <type_traits>
 #ifndef SQD_WINO_DMA_EARLY
 #define SQD_WINO_DMA_EARLY 0      /* 1: issue the whole next stage at the first MFMA step -- measured 5-8 % slower than spreading it */
 #endif
@@ -192,8 +193,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 
   const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
   auto epi = [&](f32x4 v, int j, float* dst, const float* mul, const float* mask) {
-    v += biasv[j];
-    if (acc_i) v += *(const f32x4*)dst;
+    if (acc_i) v += *(const f32x4*)dst;                       // (the bias is already inside: accumulator (1,1) started from it)
     if (has_mul) v *= *(const f32x4*)mul;
     if (has_mask) {
       const f32x4 m = *(const f32x4*)mask;
@@ -277,12 +277,20 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 #pragma unroll
         for (int j = 0; j < NT; ++j) afr[j] = *(const f32x4*)(uR + (step * NT + j) * 256);
       };
+      // FIRST (chunk 0 of a tile): the first MFMA of every accumulator takes C = 0 instead of the accumulator -- no zeroing
+      // pass after the previous tile -- and position (1,1) starts from the bias: m11 enters all four outputs of the inverse
+      // transform with weight +1, so the bias add of the epilogue comes for free.
+      auto mfma_phase = [&](auto first_c) {
+      constexpr bool FIRST = decltype(first_c)::value;
       auto mfma_pos = [&](int step, const f32x4& bfr, const f32x4 (&afr)[NT], int h) {
         const int p = 2 * step + h;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[p][j] = mfma16(afr[j][2 * h + t], bfr[2 * h + t], acc[p][j]);
+          for (int j = 0; j < NT; ++j) {
+            const f32x4 c0v = (FIRST && t == 0) ? ((p == 5) ? biasv[j] : (f32x4){0.f, 0.f, 0.f, 0.f}) : acc[p][j];
+            acc[p][j] = mfma16(afr[j][2 * h + t], bfr[2 * h + t], c0v);
+          }
       };
       f32x4 bf0, af0[NT], bf1, af1[NT];
       load_ops(0, bf0, af0);
@@ -308,6 +316,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
           mfma_pos(step, bf0, af0, 1);
         }
       }
+      };
+      if (cc == 0) mfma_phase(std::true_type{}); else mfma_phase(std::false_type{});
 
       if (last) {                            // inverse transform Y = A^T M A in registers; stored after the next barrier
 #pragma unroll
@@ -331,8 +341,6 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
           };
           inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { outv[px][j].lo = y; });
           inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { outv[px][j].hi = y; });
-#pragma unroll
-          for (int p = 0; p < 16; ++p) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         pending = true; ptp = cur;
       }
