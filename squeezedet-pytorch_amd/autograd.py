@@ -48,6 +48,7 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
             saved['stem_out'] = a
     if save:
         saved['image'] = image
+    drop_applied = False
     unpooled = None                            # inference: a pool whose output only feeds the next squeeze is folded into it
     for i in range(first, len(layers)):
         l = layers[i]
@@ -79,19 +80,26 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
             else:
                 ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
             out = torch.empty(Bq, H, W, e1 + e3, device=a.device, dtype=torch.float32)
-            fcfg = ops.choose_fused_cfg(s, e1, npix) if (not save and base.fuse_expand and e1 == e3) else None
+            fcfg = ops.choose_fused_cfg(s, e1, npix) if (not save and base.fuse_expand and e1 == e3 and
+                                                         not (drop_mask is not None and i == len(layers) - 1)) else None
             if fcfg is not None:
                 # inference: both expands in one launch (they read the same squeeze tile; the 1x1 rides along as extra
                 # channel groups that only run the centre tap)
                 ops.fire_expand(sq, 0, base.fused_expand_plan(i, fire, fcfg), out, 0)
             else:
-                ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, s, e1, npix)), out, 0, relu=True)
-                base.conv3x3(f'{i}.expand3x3', fire.expand3x3, sq, 0, out, e1, relu=True)
+                # dropout in front of ConvDet (reference: squeezedet.py:81-82): relu(x) * m == relu(x * m) for the non-negative
+                # scaled keep mask, so it is the `ymul` epilogue of the last Fire's two expand kernels -- no extra pass
+                ym = drop_mask if (drop_mask is not None and i == len(layers) - 1) else None
+                ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, s, e1, npix)), out, 0, relu=True,
+                         ymul=ym, ymul_coff=0)
+                base.conv3x3(f'{i}.expand3x3', fire.expand3x3, sq, 0, out, e1, relu=True, ymul=ym)
+                if ym is not None:
+                    drop_applied = True
             if save:
                 saved[f'fire{i}'] = (a, sq, out)
             a = out
-    if drop_mask is not None:
-        a = a * drop_mask                      # elementwise plumbing; mask is NHWC, pre-scaled by 1/(1-p)
+    if drop_mask is not None and not drop_applied:
+        a = a * drop_mask                      # (layer tables that do not end in a Fire: elementwise fallback)
     Bq, H, W, C = a.shape
     cd = base.convdet
     pred = torch.empty(Bq, H, W, cd.out_channels, device=a.device, dtype=torch.float32)
@@ -108,7 +116,13 @@ def _make_drop_mask(base, like_nhwc_shape, device):
     # nn.Dropout semantics (Bernoulli keep mask scaled by 1/(1-p)) drawn directly in NHWC: one fused torch RNG kernel
     # on a tensor of ones yields the scaled mask itself (elementwise plumbing; the stream differs from the reference's
     # CPU generator either way -- tests inject the mask)
-    return torch.nn.functional.dropout(torch.ones(like_nhwc_shape, device=device), base.dropout_prob, training=True)
+    key = (tuple(like_nhwc_shape), str(device))
+    ones = base._ones_cache.get(key)
+    if ones is None:
+        base._ones_cache.clear()
+        ones = torch.ones(like_nhwc_shape, device=device)
+        base._ones_cache[key] = ones
+    return torch.nn.functional.dropout(ones, base.dropout_prob, training=True)
 
 
 def _feature_shape(base, image):

@@ -92,6 +92,7 @@ class SqueezeDetBase(nn.Module):
         self._fused_plans = {}
         self._wino_plans = {}
         self._wgrad_batches = {}
+        self._ones_cache = {}
         self.last_grad_flat = None                # flat gradient buffer of the latest backward (every .grad is a view of it)
         self.use_winograd = True                  # 3x3 forward convs: Winograd F(2x2,3x3) kernel where tuning.json says it is faster
         self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
@@ -149,15 +150,16 @@ class SqueezeDetBase(nn.Module):
         self._wino_plans[key] = (ver, p)
         return p
 
-    def conv3x3(self, name, mod, x, x_coff, y, y_coff, relu):
+    def conv3x3(self, name, mod, x, x_coff, y, y_coff, relu, ymul=None):
         """Forward 3x3 convolution of ``mod``: the Winograd kernel where the measured table prefers it, else the direct
         implicit-GEMM kernel."""
         Bq, H, W, _ = x.shape
         C, N = mod.in_channels, mod.out_channels
         wc = ops.choose_wino_cfg(C, N, Bq * H * W) if self.use_winograd else None
-        if wc is not None:
-            return ops.conv_wino(x, x_coff, self.wino_plan(name, mod, wc), y, y_coff, relu=relu)
-        return ops.conv(x, x_coff, self.plan(name, mod, ops.choose_cfg(9, C, N, Bq * H * W)), y, y_coff, relu=relu)
+        if wc is not None and (ymul is None or tuple(ymul.shape) == tuple(y.shape)):
+            return ops.conv_wino(x, x_coff, self.wino_plan(name, mod, wc), y, y_coff, relu=relu, ymul=ymul)
+        return ops.conv(x, x_coff, self.plan(name, mod, ops.choose_cfg(9, C, N, Bq * H * W)), y, y_coff, relu=relu,
+                        ymul=ymul, ymul_coff=y_coff)
 
     def dgrad3x3(self, name, mod, dy, dy_coff, dx, accumulate=False, ymask=None, ymul=None):
         """dx (=|+=) data gradient of ``mod``'s 3x3 convolution (transposed, tap-flipped weights), ymul / ymask fused into the
