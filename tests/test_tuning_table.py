@@ -100,3 +100,32 @@ def test_winograd_choice_follows_the_measured_comparison(table):
             assert got == int(v["cfg"]), key
     assert ops.choose_wino_cfg(20, 64, 1000) is None                              # C % 8 != 0: direct kernel only
     assert ops.choose_wino_cfg(24, 40, 1234) is None                              # never measured: direct kernel
+
+
+def test_wgrad_split_plans_one_resident_round_for_winograd_layers():
+    """Host logic of the weight-gradient split (no GPU): every 3x3 layer of both architectures takes the Winograd kernel,
+    its S x channel-block grid is one resident round (<= 512 workgroups), S never exceeds the number of 4x16-pixel groups,
+    and the slab stride matches the C-ABI contract (N*taps*C + N)."""
+    for arch, B in (("squeezedet", 20), ("squeezedetplus", 16), ("squeezedet", 1)):
+        layers = layer_table(arch)
+        h, w = ops.stem_out_size(384, 1248, layers[0][3])
+        shapes = []
+        for l in layers[2:]:
+            if l[0] == "pool":
+                h, w = ops.pool_out_size(h, w)
+                continue
+            _, cin, s, e1, e3 = l
+            shapes += [(e3, s, 9, h, w), (e1, s, 1, h, w), (s, cin, 1, h, w)]
+        shapes.append((72, layers[-1][3] + layers[-1][4], 9, h, w))                    # ConvDet
+        for N, C, taps, hh, ww in shapes:
+            S, stride = ops.wgrad_split(N, C, taps, B, hh, ww)
+            assert stride == N * taps * C + N and S >= 1
+            ngroups = B * -(-hh // 4) * -(-ww // 16)
+            if taps == 9:
+                assert ops.wgrad_uses_wino(N, C, taps, B, hh, ww), (arch, N, C)
+                tc = ops._wino_wgrad_tc(N, C)
+                blocks = -(-C // 16) if N % 64 else (N // 64) * -(-C // (16 * tc))
+                assert S <= ngroups and S * blocks <= 512, (arch, N, C, S, blocks)
+                assert ops.wgrad_split(N, C, taps, B, hh, ww, wino=False)[1] == stride  # same slab layout either way
+            else:
+                assert not ops.wgrad_uses_wino(N, C, taps, B, hh, ww)
