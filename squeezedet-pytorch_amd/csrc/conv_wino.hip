@@ -13,14 +13,16 @@
 // workgroup is WV waves working on WV consecutive groups of the flattened (image, row-group, column-group) list --
 // they need not be adjacent, so the only padding is the 16-column / 4-row granularity (78 -> 80 columns) -- and shares
 // the transformed weights U of the slice through LDS.  Per K chunk of 8 channels:
-//   * the wave's 6x18-pixel input patch arrives by LDS-DMA into a wave-private raw buffer (zero page outside the image),
-//   * every lane transforms one (tile, channel pair): 16 ds_read_b64, 32 packed adds, 16 ds_write_b64 into the
-//     wave-private V[pos][tile][8] image,
-//   * 16 positions x 2 k-steps x NT MFMAs read V and U (both as conflict-free contiguous ds_read_b64),
+//   * the wave's 6x18-pixel input patch arrives by buffer-resource LDS-DMA into a wave-private raw buffer (slots outside
+//     the image are zero-filled by the hardware range check),
+//   * every lane transforms one (tile, channel pair): 16 ds_read_b64, 32 packed adds, 8 ds_write_b128 into the
+//     wave-private V image [8 position pairs][4 channel pairs][16 tiles][parity][2 channels],
+//   * 16 positions x 2 k-steps x NT MFMAs read V and U, one conflict-free ds_read_b128 per position pair and operand,
 //   * the next chunk's patch and U slice are fetched by LDS-DMA during the MFMA phase (U double-buffered; the patch
 //     buffer is wave-private and dead once the wave has transformed it, so it needs no second copy).
-// Workgroups are persistent (strided super-group list); the inverse transform runs in registers after the last chunk
-// and the stores drain behind the next stage's barrier.
+// Workgroups are persistent (strided super-group list); a tile's first chunk starts its accumulators from 0 / the bias
+// (position (1,1) enters all four outputs with weight +1), the inverse transform runs on register pairs after the last
+// chunk and the stores drain behind the next stage's barrier.  4-wave workgroups use exactly 80 KB of LDS: two per CU.
 //
 // Packed weights: U[C/8][8 position pairs][Npad/16][4 channel pairs][16 n][position parity][2 channels] -- the LDS image
 // of a slice is a set of contiguous runs (sqd_pack_wino_weight; host: ops.WinoPlan).
