@@ -71,6 +71,12 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
     x_key[it] = real ? (r << 8 | c) : -1;
     x_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * chq) * 4 : 0;
   }
+  // interior fast path: X offsets with the tile-independent invalid slots (patch padding, channels past C) already out of
+  // range; it applies when the dY channel block is full as well
+  int x_offI[X_IT];
+#pragma unroll
+  for (int it = 0; it < X_IT; ++it) x_offI[it] = x_key[it] >= 0 ? x_offB[it] : (int)OOB;
+  const bool full_blocks = n0 + CHD <= a.N;
   const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + a.dy_coff + n0), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.x + a.x_coff + c0 - (long long)(a.W + 1) * a.x_pitch), 0, 0x7ffffff0, 0x00020000);
@@ -82,6 +88,20 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
     const int y0 = gyi * 4, x0 = gxi * 16;
     const long long p0 = ((long long)b * a.H + y0) * a.W + x0;
     const unsigned soffD = (unsigned)(p0 * a.dy_pitch * 4), soffX = (unsigned)(p0 * a.x_pitch * 4);
+    // interior groups (the whole 6x18 patch inside the image) and full channel blocks: the precomputed offsets as they
+    // are -- no per-lane validity arithmetic (uniform branch)
+    const bool inner = y0 >= 1 && y0 + 5 <= a.H && x0 >= 1 && x0 + 17 <= a.W && full_blocks;
+    if (inner) {
+#pragma unroll
+      for (int it = 0; it < D_IT; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dres, (lds_ptr_ww_t)(dyB + (buf * DSLOTS + it * 256 + wv_s * 64) * 4), 16,
+                                                 d_offB[it], (int)soffD, 0, 0);
+#pragma unroll
+      for (int it = 0; it < X_IT; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_ww_t)(xB + (buf * XSLOTS + it * 256 + wv_s * 64) * 4), 16,
+                                                 x_offI[it], (int)soffX, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < D_IT; ++it) {
       const int key = d_key[it];
