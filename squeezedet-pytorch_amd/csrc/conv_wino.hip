@@ -153,7 +153,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
                                              (int)(cc * u_chunkB), 0, 0);
   };
 
-  f32x4 acc[16][NT], outv[4][NT];
+  f32x4 acc[16][NT];
 #pragma unroll
   for (int p = 0; p < 16; ++p)
 #pragma unroll
@@ -175,13 +175,15 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
   // transform unit of this lane: tile tt, channel pair cp of the chunk
   // (lanes 0-31 = tile row 0, lanes 32-63 = tile row 1; within a half: 8 tiles x (k-quad, channel half) -- the 32 lanes of
   // a ds_read_b64 half then cover 32 distinct 8-byte units of one 256-byte bank row: conflict-free)
-  const int tt = ((lane >> 5) << 3) | (lane & 7), cp = (lane >> 3) & 3;
+  // = the lane's role as MFMA B operand (column = tile lr, k = channel pair g): the transformed values V[pos][tile][2 ch]
+  // are consumed by the lane that computed them and never leave its registers (the patch reads are 2-way bank
+  // conflicted in this order: 16 ds_read_b64 per chunk, cheap next to a V round trip through LDS)
+  const int tt = lr, cp = g;
   const float* const rawL = rawW + (((cp >> 1) * RP + (2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 4 + 2 * (cp & 1));
-  // V image: [8 position pairs][4 channel pairs][16 tiles][pos parity][2 channels] -- one ds_read_b128 per lane and
-  // position pair in the k-quad-major (conflict-free) order of the direct kernel; U has the same order per 16 channels
-  float* const vL = VW + cp * 64 + tt * 4;
-  const float* const vR = VW + g * 64 + lr * 4;
+  // U image per 16 channels: [8 position pairs][4 channel pairs][16 n][pos parity][2 channels] (k-quad-major: conflict-free)
   const float* const uR0 = UB + g * 64 + lr * 4;
+  // the former V image now parks a finished tile's outputs until the next barrier: [4 px][NT][64 lanes] f32x4
+  f32x4* const parkW = (f32x4*)VW + lane;
 
   GPos cur = group_pos(tile);
   group_offsets(cur);
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int off = o_off[px] + j * 16;
-          epi(outv[px][j], j, ybase + off, mulbase + off, maskbase + off);
+          epi(parkW[(px * NT + j) * 64], j, ybase + off, mulbase + off, maskbase + off);
         }
       return;
     }
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       for (int j = 0; j < NT; ++j) {
         if (!valid || n0 + j * 16 + 4 * g >= a.N) continue;
         const int off = o_off[px] + j * 16;
-        epi(outv[px][j], j, ybase + off, mulbase + off, maskbase + off);
+        epi(parkW[(px * NT + j) * 64], j, ybase + off, mulbase + off, maskbase + off);
       }
     }
   };
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       const unsigned nsoff = (last ? nxt.soff : cur.soff) + (unsigned)ncc * 32u;
 
       // ---- input transform: V = B^T d B for (tile tt, channels 2cp, 2cp+1) ----
+      f32x2 vv[16];                          // V[pos] for (tile lr, channels 2g, 2g+1): this lane's B operands of the chunk
       {
         f32x2 t[4][4];
 #pragma unroll
@@ -261,21 +264,19 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const f32x2 v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
-          *(f32x4*)(vL + (i * 2 + 0) * 256) = (f32x4){v0.x, v0.y, v1.x, v1.y};
-          *(f32x4*)(vL + (i * 2 + 1) * 256) = (f32x4){v2.x, v2.y, v3.x, v3.y};
+          vv[i * 4 + 0] = t[i][0] - t[i][2]; vv[i * 4 + 1] = t[i][1] + t[i][2];
+          vv[i * 4 + 2] = t[i][2] - t[i][1]; vv[i * 4 + 3] = t[i][1] - t[i][3];
         }
       }
       // The patch buffer is refilled (LDS-DMA, below) for the next chunk: its reads above must have returned, and neither
       // the compiler nor the machine scheduler may move a DMA issue across this point (the DMA's LDS side is invisible to
-      // them).  The wait also publishes V to this wave's operand reads.
+      // them).
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       const float* const uR = uR0 + ubuf * USLOTS * 4;
 
       // ---- 16 positions x 2 k-steps x NT MFMAs, software-pipelined over two operand sets (steps of 2 positions) ----
-      auto load_ops = [&](int step, f32x4& bfr, f32x4 (&afr)[NT]) {           // step = position pair
-        bfr = *(const f32x4*)(vR + step * 256);
+      auto load_ops = [&](int step, f32x4 (&afr)[NT]) {                       // step = position pair
 #pragma unroll
         for (int j = 0; j < NT; ++j) afr[j] = *(const f32x4*)(uR + (step * NT + j) * 256);
       };
@@ -284,18 +285,18 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       // transform with weight +1, so the bias add of the epilogue comes for free.
       auto mfma_phase = [&](auto first_c) {
       constexpr bool FIRST = decltype(first_c)::value;
-      auto mfma_pos = [&](int step, const f32x4& bfr, const f32x4 (&afr)[NT], int h) {
+      auto mfma_pos = [&](int step, const f32x4 (&afr)[NT], int h) {
         const int p = 2 * step + h;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const f32x4 c0v = (FIRST && t == 0) ? ((p == 5) ? biasv[j] : (f32x4){0.f, 0.f, 0.f, 0.f}) : acc[p][j];
-            acc[p][j] = mfma16(afr[j][2 * h + t], bfr[2 * h + t], c0v);
+            acc[p][j] = mfma16(afr[j][2 * h + t], vv[p][t], c0v);
           }
       };
-      f32x4 bf0, af0[NT], bf1, af1[NT];
-      load_ops(0, bf0, af0);
+      f32x4 af0[NT], af1[NT];
+      load_ops(0, af0);
 #pragma unroll
       for (int step = 0; step < NSTEP; ++step) {
 #pragma unroll
@@ -305,17 +306,17 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
           else dma_u_one(q - RAW_IT, ncc, ubuf ^ 1);
         }
         if (step & 1) {
-          mfma_pos(step, bf1, af1, 0);
+          mfma_pos(step, af1, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (step + 1 < NSTEP) load_ops(step + 1, bf0, af0);
+          if (step + 1 < NSTEP) load_ops(step + 1, af0);
           __builtin_amdgcn_sched_barrier(0);
-          mfma_pos(step, bf1, af1, 1);
+          mfma_pos(step, af1, 1);
         } else {
-          mfma_pos(step, bf0, af0, 0);
+          mfma_pos(step, af0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (step + 1 < NSTEP) load_ops(step + 1, bf1, af1);
+          if (step + 1 < NSTEP) load_ops(step + 1, af1);
           __builtin_amdgcn_sched_barrier(0);
-          mfma_pos(step, bf0, af0, 1);
+          mfma_pos(step, af0, 1);
         }
       }
       };
@@ -341,8 +342,11 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
               put(1 * 2 + b, s[1][b] - (s[2][b] + s[3][b]));
             }
           };
-          inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { outv[px][j].lo = y; });
-          inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { outv[px][j].hi = y; });
+          f32x4 ov[4];
+          inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
+          inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
+#pragma unroll
+          for (int px = 0; px < 4; ++px) parkW[(px * NT + j) * 64] = ov[px];     // lane-contiguous 16-byte slots: conflict-free
         }
         pending = true; ptp = cur;
       }
