@@ -241,3 +241,41 @@ def test_eval_flow_images_to_ap(tmp_path):
     aps = R.evaluate(str(tmp_path / 'results'), str(lab), str(tmp_path / 'set.txt'))
     assert set(aps) == {f'{c}_{d}' for c in R.KITTI_CLASS_NAMES for d in ('easy', 'moderate', 'hard')} | {'mAP'}
     assert all(0.0 <= v <= 1.0 for v in aps.values()) and aps['mAP'] > 0.0
+
+
+@pytest.fixture
+def force_winograd(monkeypatch):
+    """Route EVERY 3x3 convolution (forward, data gradient, weight gradient where it applies) through the Winograd kernels,
+    whatever the measured table would choose for the test's small shapes."""
+    from squeezedet_pytorch_amd import ops
+    used = {'n': 0}
+
+    def always(C, N, npix):
+        if C % 8:
+            return None
+        used['n'] += 1
+        return 2                                              # <2,4>: the configuration the headline workload runs
+    monkeypatch.setattr(ops, 'choose_wino_cfg', always)
+    monkeypatch.setattr(ops, 'WINO_WGRAD', True)
+    return used
+
+
+def test_golden_forward_through_winograd_kernels(golden_dir, force_winograd):
+    """The reference-generated goldens (small backbone + KITTI-size rows) with all 3x3 layers forced onto the Winograd
+    kernel: same 1e-4 bound as the direct path."""
+    g = np.load(os.path.join(golden_dir, "backbone_small.npz"))
+    cfg, m, sd = _model('squeezedet', (64, 96))
+    m.base.fuse_expand = False                               # (the fused expand launch would take the 3x3 away from Winograd)
+    x = synthetic.make_images(2, (64, 96), seed=3)
+    with torch.no_grad():
+        pred = m.base(x.cuda())
+    np.testing.assert_allclose(pred.cpu().numpy(), g["squeezedet_pred"], atol=TOL, rtol=0)
+    gk = np.load(os.path.join(golden_dir, "kitti_full.npz"))
+    cfg, m, sd = _model('squeezedet', (384, 1248))
+    m.base.fuse_expand = False
+    x1 = synthetic.make_images(1, (384, 1248), seed=0)
+    with torch.no_grad():
+        pred1 = m.base(x1.cuda())
+    np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(pred1[0].cpu().numpy()[gk["top_idx"]], gk["pred_top"], atol=TOL, rtol=0)
+    assert force_winograd['n'] >= 22                         # 10 expand3x3 + ConvDet, both models

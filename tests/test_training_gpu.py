@@ -282,3 +282,21 @@ def test_trainer_epochs_dense_and_sparse_annotations():
         params, mom, _, _, loss_vec, _ = oracle.train_step_reference(params, mom, x, gt, cfg.anchors, size, arch='squeezedet')
         losses.append(float(loss_vec.mean()))
     assert abs(logs['dense'][0]['loss'] - np.mean(losses)) <= 2e-3 * abs(np.mean(losses))
+
+
+def test_train_step_vs_golden_through_winograd_kernels(golden_dir, monkeypatch):
+    """The reference's own training step (golden) with every 3x3 forward, data gradient and weight gradient forced onto the
+    Winograd kernels: same tolerances as the default path."""
+    from squeezedet_pytorch_amd import ops
+    monkeypatch.setattr(ops, 'choose_wino_cfg', lambda C, N, npix: (2 if C % 8 == 0 else None))
+    monkeypatch.setattr(ops, 'WINO_WGRAD', True)
+    test_train_step_vs_golden(golden_dir)
+    calls = {'wino': 0}
+    real = ops.conv_wino
+
+    def counting(*a, **k):
+        calls['wino'] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(ops, 'conv_wino', counting)
+    test_train_step_vs_golden(golden_dir)
+    assert calls['wino'] >= 21                               # 11 forward + >= 10 data gradients went through conv_wino
