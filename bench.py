@@ -1,42 +1,35 @@
 #!/usr/bin/env python
-"""Benchmark of the SqueezeDet hot path on MI355X (contract: see the task brief / DESIGN.md).
+"""Benchmark of the SqueezeDet hot path on MI355X (contract: see the task brief / DESIGN.md section 5).
 
-A *step* is one pass of the inference hot path over one batch of 20 synthetic 1248x384 images that
-are already resident in HBM: stem -> pools -> 10 Fire modules -> ConvDet (HIP kernels) -> fused
-decode / top-64 / class-wise NMS / threshold kernel.  ``value`` = images/sec over all ranks.
+A *step* is one pass of the hot path over one batch of 20 synthetic 1248x384 images that are already resident in HBM.
+  inference step: stem -> pools -> 10 Fire modules -> ConvDet (HIP kernels) -> fused decode / top-64 / class-wise NMS
+  training step : forward + multi-task loss + backward + (RCCL gradient all-reduce) + clip_grad_norm_(5) + SGD
+``value`` = inference images/sec over all ranks (BASELINE.json's target is stated on inference); the default run also
+times the training step and reports it in the same JSON line under ``"train"`` (the metric is "infer+train").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode both|infer|train] [--no-cpu-baseline]
 
-For N > 1 launch with ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``:
-one process per GPU, batches sharded by rank, no data-path collective for inference (replicas), an
-RCCL gradient all-reduce per step for training.  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU over RCCL.  Either the launcher starts the ranks (``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or -- WORLD_SIZE unset --
+this script starts N fresh rank processes itself BEFORE anything touches the GPU and relays rank 0's line.  Batches
+are sharded by rank; inference has no data-path collective (replicas), training all-reduces the gradient buckets.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (spec)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FWD_GFLOP_PER_IMAGE = {'squeezedet': 10.566, 'squeezedetplus': 83.386}   # SURVEY.md 8d / BASELINE.md 3 (2*MAC, convs only)
-
-
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/traffic.json, written by
-    scratch/traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for gfx950), or None."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            t = json.load(f)
-        return int(t[kernel]['hbm_bytes_per_launch'])
-    except (OSError, KeyError, ValueError):
-        return None
 
 
 def parse():
@@ -45,23 +38,67 @@ def parse():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=0, help='images per GPU per step (default 20; 16 for squeezedetplus)')
-    ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
+    ap.add_argument('--mode', default='both', choices=['both', 'infer', 'train'],
+                    help='both (default): value = inference, training reported under "train"; infer / train: that step only')
     ap.add_argument('--arch', default='squeezedet')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle leg (baseline timing + parity check)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
+    ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even at N=1 (exercises the RCCL path on one GPU)')
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, batch, seconds_budget=25.0):
-    """The oracle (CPU restatement of the reference, kind='port') timed on the host cores on a
-    bounded sample of the same workload: whole inference path for `batch` images."""
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves (fresh processes; this parent never touches the GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    import torch                                     # import only: device_count() does not initialise the GPU on this image
+    ndev = torch.cuda.device_count()
+    if args.backend == 'nccl' and ndev < args.gpus:
+        print(f'[bench] --gpus {args.gpus} but only {ndev} GPU(s) visible', file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        print(f'[bench] rank processes failed (exit {p.returncode})', file=sys.stderr)
+        return p.returncode or 1
+    if json.loads(line).get('n_gpus') != args.gpus:
+        print(f'[bench] {json.loads(line).get("n_gpus")} ranks joined, expected {args.gpus}', file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU leg (rank 0, N = 1 only): the oracle as reported baseline AND as the checker of the step that was just timed
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_and_parity(cfg, sd, batch, hip_pred, hip_det, train_probe, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference, kind='port') on the host cores, on a bounded sample of the same
+    workload: whole inference path for `batch` images.  Its first pass doubles as the parity check of the timed step:
+    ``hip_pred`` [B,A,8] / ``hip_det`` (count, class_ids, scores, boxes, anchor_idx) are the HIP outputs for the same
+    batch; ``train_probe`` = (gt, hip eval-mode loss vector before the first optimizer step) or None."""
+    import numpy as np
+    import torch
     import oracle
     from squeezedet_pytorch_amd import synthetic
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     x = synthetic.make_images(batch, cfg.input_size, seed=0)
+    keep = {}
 
     def one():
         with torch.no_grad():
@@ -70,23 +107,145 @@ def cpu_baseline(cfg, sd, batch, seconds_budget=25.0):
         for b in range(batch):
             oracle.filter_detections(ids[b].numpy(), sc[b].numpy(), bx[b].numpy(), cfg.keep_top_k, cfg.nms_thresh,
                                      cfg.score_thresh, cfg.num_classes)
+        keep['pred'] = pred
     t0 = time.time(); one(); warm = time.time() - t0
+    parity = None
+    if hip_pred is not None:
+        # (1) backbone: every image of the timed batch vs the oracle; (2) the fused detect kernel given the HIP pred
+        # must keep exactly the anchors the oracle filter keeps on that same pred (index-exact), (3) training: the
+        # eval-mode loss vector of the initial weights vs the oracle loss on the oracle pred
+        ref = keep['pred']
+        max_err = float((hip_pred - ref).abs().max())
+        ids, sc, bx = oracle.inference_head(hip_pred, cfg.anchors, cfg.input_size, cfg.num_classes)
+        cnt, _cls, _sc, _bx, idx = hip_det
+        exact, ndet = True, 0
+        for b in range(batch):
+            d = oracle.filter_detections(ids[b].numpy(), sc[b].numpy(), bx[b].numpy(), cfg.keep_top_k, cfg.nms_thresh,
+                                         cfg.score_thresh, cfg.num_classes)
+            n = int(cnt[b])
+            want = np.zeros(0, np.int64) if d is None else np.asarray(d['anchor_idx'])
+            exact = exact and n == len(want) and bool(np.array_equal(np.asarray(idx[b, :n]), want))
+            ndet += n
+        parity = {'pred_max_abs_err': max_err, 'pred_tol': 1e-4, 'index_exact': exact, 'detections': ndet,
+                  'images_checked': batch, 'ok': bool(max_err <= 1e-4 and exact),
+                  'what': 'pred of the timed batch vs oracle.backbone_forward; kept anchor indices of the fused detect kernel vs '
+                          'oracle.filter_detections on the same pred'}
+        if train_probe is not None:
+            gt, hip_loss = train_probe
+            with torch.no_grad():
+                lo, _ = oracle.multitask_loss(ref, gt, cfg.anchors, cfg.input_size, cfg.num_classes)
+            rel = float(((hip_loss - lo).abs() / lo.abs().clamp_min(1e-12)).max())
+            parity['train_loss_max_rel_err'] = rel
+            parity['ok'] = bool(parity['ok'] and rel <= 1e-4)
     n, t_acc = 0, 0.0
     while n < 3 or (t_acc + warm < seconds_budget and n < 10):
         t0 = time.time(); one(); t_acc += time.time() - t0; n += 1
         if t_acc + warm > seconds_budget:
             break
-    return {'value': round(batch * n / t_acc, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} timed passes (1 warm-up) of the oracle CPU path (torch CPU fp32 backbone + numpy decode/top-k/NMS) '
-                      f'on the same bs={batch} 1248x384 synthetic batch, {threads} threads of {cores} host CPUs'}
+    cpu = {'value': round(batch * n / t_acc, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+           'sample': f'{n} timed passes (1 warm-up) of the oracle CPU path (torch CPU fp32 backbone + numpy decode/top-k/NMS) '
+                     f'on the same bs={batch} 1248x384 synthetic batch, {threads} threads of {cores} host CPUs'}
+    return cpu, parity
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernel from the per-launch HIP-event pass
+# ------------------------------------------------------------------------------------------------------------------
+def measured_traffic(kernel, launches_per_step):
+    """HBM-side bytes per launch of `kernel` from the committed PMC pass (profiles/traffic.json, written by
+    scratch/traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for gfx950) -- only if that pass
+    profiled the SAME launch set (launches of this kernel per step), else None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            t = json.load(f)
+        e = t[kernel]
+        per_step = e.get('launches_per_step')
+        if per_step is not None and int(per_step) != int(launches_per_step):
+            return None
+        return int(e['hbm_bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def roofline_of(summ, ms_per_step, nprof):
+    if not summ:
+        return None, None
+    dominant = max(summ.items(), key=lambda kv: kv[1]['ms'])[0]
+    d = summ[dominant]
+    avg_s = d['ms'] / d['launches'] / 1e3
+    flops_per_launch = d['flops'] / d['launches']
+    bytes_per_launch = d['bytes'] / d['launches']
+    ai = flops_per_launch / max(bytes_per_launch, 1.0)
+    if ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):    # ridge point 19.7 flop/B
+        ach = flops_per_launch / avg_s / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None}
+    else:
+        ach = bytes_per_launch / avg_s / 1e9
+        roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
+    roof['traffic'] = measured_traffic(dominant, int(round(d['launches'])))
+    if dominant.startswith('conv_wino') or dominant.startswith('conv_wgrad_wino'):
+        # Winograd F(2x2,3x3): `achieved` counts the multiply-adds the MFMA pipe executes; the same launch expressed in
+        # direct-form 3x3 flops (what the implicit-GEMM kernel would have to execute) is 2.25x that
+        roof['direct_form_equivalent_tflops'] = round(ach * 2.25, 2)
+    roof.update({'kernel': dominant, 'launches_per_step': int(round(d['launches'])),
+                 'avg_launch_us': round(avg_s * 1e6, 2),
+                 'algorithmic_per_launch': {'gflop': round(flops_per_launch / 1e9, 3), 'mbytes': round(bytes_per_launch / 1e6, 3)},
+                 'share_of_step': round(d['ms'] / ms_per_step, 3),
+                 'how': f'HIP events around every launch of {nprof} eager steps enqueued behind the timed region; median per kernel shape'})
+    kernels = {k: {'ms_per_step': round(v['ms'], 4),
+                   'launches_per_step': int(round(v['launches'])),
+                   'tflops': round(v['flops'] / (v['ms'] / 1e3) / 1e12, 2) if v['ms'] > 0 else 0,
+                   'gbs': round(v['bytes'] / (v['ms'] / 1e3) / 1e9, 1) if v['ms'] > 0 else 0}
+               for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
+    return roof, kernels
+
+
+def layer_families_of(summ):
+    """The two layer families BASELINE.json's north_star asks for: HBM rate of the memory-bound 1x1 squeeze layers,
+    matrix-core rate of the 3x3 expand / ConvDet layers (forward launches of this step; per-shape medians)."""
+    fam = {'squeeze_1x1': [0.0, 0.0, 0.0, 0, 0.0], 'expand3x3_convdet': [0.0, 0.0, 0.0, 0, 0.0]}       # ms, direct flops, bytes, launches, executed flops
+    for kname, v in summ.items():
+        for tag, t in v['tags'].items():
+            m = re.match(r'(\d+)tap C(\d+) N(\d+) ', tag)
+            if not m or len(t) < 4:
+                continue
+            taps, Cc, Nn = int(m.group(1)), int(m.group(2)), int(m.group(3))
+            key = 'squeeze_1x1' if (taps == 1 and Nn < Cc) else ('expand3x3_convdet' if taps == 9 else None)
+            if key is None:
+                continue
+            direct = t[2] * (2.25 if kname.startswith('conv_wino') else 1.0)                  # direct-form flops of the layer
+            f = fam[key]; f[0] += t[1]; f[1] += direct; f[2] += t[3]; f[3] += int(round(t[0])); f[4] += t[2]
+    s, e = fam['squeeze_1x1'], fam['expand3x3_convdet']
+    return {
+        'squeeze_1x1': {'launches_per_step': s[3], 'ms_per_step': round(s[0], 4),
+                        'achieved_gbs': round(s[2] / max(s[0], 1e-9) / 1e6, 1),
+                        'frac_of_hbm_peak': round(s[2] / max(s[0], 1e-9) / 1e6 / PEAK_HBM_GBS, 4),
+                        'note': 'algorithmic bytes (input + output windows + weights) / HIP-event time; includes the squeeze data gradients in training mode'},
+        'expand3x3_convdet': {'launches_per_step': e[3], 'ms_per_step': round(e[0], 4),
+                              'executed_tflops': round(e[4] / max(e[0], 1e-9) / 1e9, 2),
+                              'frac_of_fp32_mfma_peak': round(e[4] / max(e[0], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              'direct_form_tflops': round(e[1] / max(e[0], 1e-9) / 1e9, 2),
+                              'frac_of_fp32_mfma_peak_direct_form': round(e[1] / max(e[0], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              'note': 'executed = multiply-adds the matrix cores perform (Winograd launches: direct form / 2.25); direct_form = the 3x3 convolution flops'},
+    }
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))                  # nothing above this line touches the GPU
+
+    import numpy as np  # noqa: F401
+    import torch
+
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
@@ -97,13 +256,22 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # the number of ranks that actually joined: an all-reduce of ones (not the environment variable)
+        ones = torch.ones(1, device=dev if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(ones)
+        joined = int(ones.item())
+        if joined != args.gpus:
+            raise SystemExit(f'{joined} ranks joined, --gpus {args.gpus}')
+    else:
+        joined = 1
 
     import squeezedet_pytorch_amd as sqd
     from squeezedet_pytorch_amd import ops, synthetic
@@ -114,36 +282,29 @@ def main():
     sd = synthetic.make_state_dict(args.arch, seed=1234)
     B = args.batch if args.batch > 0 else (16 if args.arch == 'squeezedetplus' else 20)
     x = synthetic.make_images(B, cfg.input_size, seed=rank).to(dev)
-
-    if args.mode == 'train':
-        from squeezedet_pytorch_amd.trainer import make_train_step
-        step, describe = make_train_step(cfg, sd, x, rank, world, dist)
-    else:
-        model = SqueezeDet(cfg)
-        model.load_state_dict(sd)
-        det = Detector(model, cfg)
-        out_bufs = ops._det_buffers(B, cfg.keep_top_k, dev, cfg.num_anchors)
-
-        def step():
-            return det.detect_device(x, out=out_bufs)
-        where = '1 MI355X' if world == 1 else f'each of {world} MI355X (independent replicas, no data-path collective)'
-        describe = (f'SqueezeDet KITTI 1248x384 bs={B} inference on {where} (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
-                    else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on {where}')
+    net = 'SqueezeDet' if args.arch == 'squeezedet' else 'SqueezeDet+'
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up (eager), then capture one step into a hipGraph for the timed region ----
-    for _ in range(max(1, args.warmup)):
-        step()
-    torch.cuda.synchronize()
-    graph = None
-    # inference: always a hipGraph of the step.  training: the whole step (fwd, loss, bwd, clip, SGD, weight re-pack) is
-    # captured too on one GPU; with an RCCL all-reduce in the step (world > 1) it stays eager
-    if not args.no_graph and (args.mode == 'infer' or world == 1):
-        try:
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], device=dev if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def measure(step, capture):
+        """W warm-up steps, optional hipGraph capture of one step, then EXACTLY K timed steps bracketed by barrier +
+        synchronize; a second identical window right behind it shows whether the first ran at steady clocks.
+        Returns (seconds for K steps (max over ranks), seconds of the repeat window, 'hipGraph replay' | 'eager launches', run)."""
+        for _ in range(max(1, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        graph = None
+        if capture and not args.no_graph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -155,122 +316,124 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             graph.replay(); graph.replay()
             torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            if args.mode == 'infer':
-                raise
-            print(f'[bench] training step not captured ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
-            graph = None
+        run = graph.replay if graph is not None else step
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        repeat = time.perf_counter() - t0
+        return max_over_ranks(elapsed), max_over_ranks(repeat), ('hipGraph replay' if graph is not None else 'eager launches'), run
+
+    def event_profile(step, run, nprof=5):
+        """Per-kernel HIP-event pass inside the same process right behind the timed region: every kernel of `nprof` eager
+        steps is bracketed on its launch stream.  Un-bracketed steps are enqueued first so the host runs ahead of the GPU
+        and no bracket absorbs a launch gap (brackets are only exact when the GPU is the bottleneck; checked against
+        rocprofv3 --kernel-trace, profiles/)."""
+        timer = ops.KernelTimer()
+        run(); run(); run()
+        ops.set_timer(timer)
+        for _ in range(nprof):
+            step()
+        ops.set_timer(None)
+        torch.cuda.synchronize()
+        return timer.summary(nsteps=nprof), nprof
+
+    result = {}
+    hip_pred = hip_det = train_probe = None
+
+    # ---------------- inference ----------------
+    if args.mode in ('both', 'infer'):
+        model = SqueezeDet(cfg)
+        model.load_state_dict(sd)
+        det = Detector(model, cfg)
+        out_bufs = ops._det_buffers(B, cfg.keep_top_k, dev, cfg.num_anchors)
+
+        def infer_step():
+            return det.detect_device(x, out=out_bufs)
+        elapsed, repeat, how, run = measure(infer_step, capture=True)
+        summ, nprof = event_profile(infer_step, run)
+        ms = elapsed / args.steps * 1e3
+        roof, kernels = roofline_of(summ, ms, nprof)
+        value = B * joined * args.steps / elapsed
+        gf = FWD_GFLOP_PER_IMAGE[args.arch]
+        where = '1 MI355X' if joined == 1 else f'each of {joined} MI355X (independent replicas, no data-path collective)'
+        result['infer'] = {
+            'value': round(value, 1), 'ms_per_step': round(ms, 4), 'timed_with': how,
+            'repeat_window_ms_per_step': round(repeat / args.steps * 1e3, 4),
+            'workload': (f'SqueezeDet KITTI 1248x384 bs={B} inference on {where} (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
+                         else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on {where}'),
+            'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
+            'whole_network': {'tflops': round(value * gf / 1e3, 2),
+                              'frac_of_fp32_mfma_peak': round(value / joined * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              'note': 'direct-form flops of the network; layers run by the Winograd kernel execute 2.25x fewer'},
+        }
+        if rank == 0 and joined == 1 and not args.no_cpu_baseline:
+            # outputs of the step that was timed, for the parity check of the CPU leg: the detections the last replay left
+            # in out_bufs, and pred from one more (bitwise identical: tests/test_headline_gpu.py) eager backbone pass
+            run()
             torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
+            with torch.no_grad():
+                hip_pred = model.base(x).cpu()
+            hip_det = tuple(t.cpu().numpy() for t in out_bufs[:5])
+        del model, det
 
-    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    # ---- per-kernel HIP-event pass, inside the same process right after the timed region: every kernel of
-    # `nprof` eager steps is bracketed on its launch stream.  Two un-bracketed steps are enqueued first so the
-    # host runs ahead of the GPU and no bracket absorbs a launch gap (brackets are only exact when the GPU is
-    # the bottleneck; checked against rocprofv3 --kernel-trace, profiles/). ----
-    nprof = 5
-    timer = ops.KernelTimer()
-    run(); run(); run()
-    ops.set_timer(timer)
-    for _ in range(nprof):
-        step()
-    ops.set_timer(None)
-    torch.cuda.synchronize()
-    summ = timer.summary(nsteps=nprof)               # per-step totals from per-shape medians
-    dominant = max(summ.items(), key=lambda kv: kv[1]['ms'])[0] if summ else None
-
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---------------- training ----------------
+    if args.mode in ('both', 'train'):
+        from squeezedet_pytorch_amd.trainer import make_train_step
+        step, describe, probe = make_train_step(cfg, sd, x, rank, joined, dist, force_exchange=args.force_dist)
+        if rank == 0 and joined == 1 and not args.no_cpu_baseline and args.mode == 'both':
+            train_probe = probe()                    # (gt, eval-mode loss of the initial weights), before any optimizer step
+        # one GPU: the whole step (fwd, loss, bwd, clip, SGD, weight re-pack) replays as a hipGraph; with an RCCL
+        # all-reduce inside the step (N > 1) it stays eager
+        try:
+            elapsed, repeat, how, run = measure(step, capture=(joined == 1 and dist is None))
+        except Exception as e:  # noqa: BLE001
+            print(f'[bench] training step not captured ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
+            torch.cuda.synchronize()
+            args.no_graph = True
+            elapsed, repeat, how, run = measure(step, capture=False)
+        summ, nprof = event_profile(step, run, nprof=3)
+        ms = elapsed / args.steps * 1e3
+        roof, kernels = roofline_of(summ, ms, nprof)
+        result['train'] = {
+            'value': round(B * joined * args.steps / elapsed, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4), 'timed_with': how,
+            'repeat_window_ms_per_step': round(repeat / args.steps * 1e3, 4),
+            'workload': describe, 'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
+        }
 
     if rank == 0:
-        total_images = B * world * args.steps
-        value = total_images / elapsed
-        roof = None
-        if dominant is not None:
-            d = summ[dominant]
-            avg_s = d['ms'] / d['launches'] / 1e3
-            flops_per_launch = d['flops'] / d['launches']
-            bytes_per_launch = d['bytes'] / d['launches']
-            ai = flops_per_launch / max(bytes_per_launch, 1.0)
-            if ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):    # ridge point 19.7 flop/B
-                ach = flops_per_launch / avg_s / 1e12
-                roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None}
-            else:
-                ach = bytes_per_launch / avg_s / 1e9
-                roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
-            roof['traffic'] = measured_traffic(dominant)
-            if dominant.startswith('conv_wino'):
-                # Winograd F(2x2,3x3): `achieved` counts the multiply-adds the MFMA pipe executes; the same launch expressed in
-                # direct-form 3x3 flops (what the implicit-GEMM kernel would have to execute) is 2.25x that
-                roof['direct_form_equivalent_tflops'] = round(ach * 2.25, 2)
-            roof.update({'kernel': dominant, 'launches_per_step': int(round(d['launches'])),
-                         'avg_launch_us': round(avg_s * 1e6, 2),
-                         'algorithmic_per_launch': {'gflop': round(flops_per_launch / 1e9, 3), 'mbytes': round(bytes_per_launch / 1e6, 3)},
-                         'share_of_step': round(d['ms'] / (elapsed / args.steps * 1e3), 3),
-                         'how': f'HIP events around every launch of {nprof} eager steps enqueued behind the timed region; median per kernel shape'})
-        gf = FWD_GFLOP_PER_IMAGE[args.arch]
-        whole = {'tflops': round(value * gf / 1e3, 2),
-                 'frac_of_fp32_mfma_peak': round(value / world * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
-                 'note': 'direct-form flops of the network; layers run by the Winograd kernel execute 2.25x fewer'} if args.mode == 'infer' else None
-        kernels = {k: {'ms_per_step': round(v['ms'], 4),
-                       'launches_per_step': int(round(v['launches'])),
-                       'tflops': round(v['flops'] / (v['ms'] / 1e3) / 1e12, 2) if v['ms'] > 0 else 0,
-                       'gbs': round(v['bytes'] / (v['ms'] / 1e3) / 1e9, 1) if v['ms'] > 0 else 0}
-                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}
-        # the two layer families BASELINE.json's north_star asks for: HBM rate of the memory-bound 1x1 squeeze layers,
-        # matrix-core rate of the 3x3 expand / ConvDet layers (forward launches of this step; per-shape medians)
-        import re as _re
-        fam = {'squeeze_1x1': [0.0, 0.0, 0.0, 0, 0.0], 'expand3x3_convdet': [0.0, 0.0, 0.0, 0, 0.0]}       # ms, direct flops, bytes, launches, executed flops
-        for kname, v in summ.items():
-            for tag, t in v['tags'].items():
-                m = _re.match(r'(\d+)tap C(\d+) N(\d+) ', tag)
-                if not m or len(t) < 4:
-                    continue
-                taps, Cc, Nn = int(m.group(1)), int(m.group(2)), int(m.group(3))
-                key = 'squeeze_1x1' if (taps == 1 and Nn < Cc) else ('expand3x3_convdet' if taps == 9 else None)
-                if key is None:
-                    continue
-                direct = t[2] * (2.25 if kname.startswith('conv_wino') else 1.0)                  # direct-form flops of the layer
-                f = fam[key]; f[0] += t[1]; f[1] += direct; f[2] += t[3]; f[3] += int(round(t[0])); f[4] += t[2]
-        layer_families = {
-            'squeeze_1x1': {'launches_per_step': fam['squeeze_1x1'][3], 'ms_per_step': round(fam['squeeze_1x1'][0], 4),
-                            'achieved_gbs': round(fam['squeeze_1x1'][2] / max(fam['squeeze_1x1'][0], 1e-9) / 1e6, 1),
-                            'frac_of_hbm_peak': round(fam['squeeze_1x1'][2] / max(fam['squeeze_1x1'][0], 1e-9) / 1e6 / PEAK_HBM_GBS, 4),
-                            'note': 'algorithmic bytes (input + output windows + weights) / HIP-event time; includes the squeeze data gradients in training mode'},
-            'expand3x3_convdet': {'launches_per_step': fam['expand3x3_convdet'][3], 'ms_per_step': round(fam['expand3x3_convdet'][0], 4),
-                                  'executed_tflops': round(fam['expand3x3_convdet'][4] / max(fam['expand3x3_convdet'][0], 1e-9) / 1e9, 2),
-                                  'frac_of_fp32_mfma_peak': round(fam['expand3x3_convdet'][4] / max(fam['expand3x3_convdet'][0], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                  'direct_form_tflops': round(fam['expand3x3_convdet'][1] / max(fam['expand3x3_convdet'][0], 1e-9) / 1e9, 2),
-                                  'frac_of_fp32_mfma_peak_direct_form': round(fam['expand3x3_convdet'][1] / max(fam['expand3x3_convdet'][0], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                  'note': 'executed = multiply-adds the matrix cores perform (Winograd launches: direct form / 2.25); direct_form = the 3x3 convolution flops'},
-        }
-        cpu = None
-        if not args.no_cpu_baseline and args.mode == 'infer' and world == 1:      # rank 0 at N = 1 only (bounded sample)
-            cpu = cpu_baseline(cfg, sd, B)
+        cpu = parity = None
+        if joined == 1 and not args.no_cpu_baseline and args.mode != 'train':
+            cpu, parity = cpu_baseline_and_parity(cfg, sd, B, hip_pred, hip_det, train_probe)
+        head = result['infer'] if 'infer' in result else result['train']
+        what = 'inference' if 'infer' in result else 'training'
         line = {
-            'metric': f'images/sec {"SqueezeDet" if args.arch == "squeezedet" else "SqueezeDet+"} 1248x384 bs={B} ' + ('inference' if args.mode == 'infer' else 'training'),
-            'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'metric': f'images/sec {net} 1248x384 bs={B} {what}' + (' (+ training under "train")' if args.mode == 'both' else ''),
+            'value': head['value'], 'unit': 'images/sec', 'n_gpus': joined, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': describe, 'arch': args.arch, 'images_per_gpu_per_step': B, 'global_batch': B * world,
+            'config': {'workload': head['workload'], 'arch': args.arch, 'images_per_gpu_per_step': B, 'global_batch': B * joined,
                        'input': '3x384x1248 fp32 NCHW, HBM resident', 'weights': 'synthetic Kaiming-scale, seed 1234',
-                       'parallelism': f'replicas x{world}' if args.mode == 'infer' else f'dp{world}'},
-            'roofline': roof, 'cpu_baseline': cpu, 'whole_network': whole, 'timed_with': 'hipGraph replay' if graph is not None else 'eager launches',
-            'layer_families': layer_families,
-            'kernels_event_profile': kernels,
+                       'parallelism': (f'replicas x{joined}' if what == 'inference' else f'dp{joined}')},
+            'roofline': head['roofline'], 'cpu_baseline': cpu, 'parity': parity,
+            'whole_network': head.get('whole_network'), 'timed_with': head['timed_with'],
+            'repeat_window_ms_per_step': head['repeat_window_ms_per_step'],
+            'layer_families': head['layer_families'], 'kernels_event_profile': head['kernels_event_profile'],
         }
+        if args.mode == 'both':
+            line['train'] = result['train']
         print(json.dumps(line))
+        if parity is not None and not parity['ok']:
+            print(f'[bench] PARITY FAILED: {parity}', file=sys.stderr)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
     if dist is not None:
         dist.destroy_process_group()
 

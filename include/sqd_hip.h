@@ -72,6 +72,11 @@ int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw,
  * (a record takes ceil((N*taps*C + N) / 64) workgroups; total_blocks = their sum).  Results are bitwise those of the
  * per-layer reduction. */
 int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base, void* stream);
+/* The same for a contiguous range of the table: descs_dev = address of the range's first record, n = records in the
+ * range, block_first = that record's "first workgroup" field, nblocks = workgroups of the range.  Lets the backward of
+ * src/engine/trainer.py:47 hand each finished stage's gradient bucket to the all-reduce early. */
+int sqd_wgrad_reduce_batched_range(const void* descs_dev, int n, int block_first, int nblocks, const float* slab_base,
+                                   float* grad_base, void* stream);
 
 
 /* Stem weight + bias gradient (the image needs no data gradient).  slab: S*(N*3*k*k + N) floats. */
@@ -89,6 +94,10 @@ int sqd_stem_wgrad_pooled(const float* dpool, const float* pooled, const unsigne
  * w is the checkpoint tensor itself (OIHW). */
 int sqd_stem_conv_relu_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
                            int B, int Hin, int Win, int N, int ksize, void* stream);
+/* The same with the activation optional (relu = 0: the bare Conv2d of features[0], src/model/squeezedet.py:34, for
+ * callers that walk the module list layer by layer). */
+int sqd_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
+                      int B, int Hin, int Win, int N, int ksize, int relu, void* stream);
 
 /* Fused features[0..2]: conv + ReLU + MaxPool2d(3,2,ceil_mode=True) (src/model/squeezedet.py:34-36 / :52-54)
  * without materialising the conv output.  y: NHWC [B][Hp][Wp][N]; argmax (uint8, may be NULL) as below. */

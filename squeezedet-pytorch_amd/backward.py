@@ -51,7 +51,29 @@ def run_backbone_backward(base, saved, dpred):
     cin_cd = a_in.shape[3]
     shape_key = (B, H, W) + tuple(tuple(saved[f'fire{i}'][2].shape) for i in range(len(layers)) if layers[i][0] == 'fire')
     wb, slots, total = base.wgrad_batch(lambda: _wgrad_layout(base, saved, B, H, W), shape_key)
-    grad_flat = torch.empty(total, device=dpred.device, dtype=torch.float32)
+    # + 1: the data-parallel exchange carries this rank's image count through the same all-reduce (trainer.GradientExchange)
+    grad_buf = torch.empty(total + 1, device=dpred.device, dtype=torch.float32)
+    grad_flat = grad_buf[:total]
+    sync = getattr(base, 'grad_sync', None)
+    if sync is not None:
+        sync.begin(grad_buf, total, B)
+    # Stages of the backward = runs of layers between two pools.  With a gradient exchange attached, each stage's slabs
+    # are reduced as soon as the stage is done and its slice of the flat buffer (named_parameters order: a stage is a
+    # contiguous range, later stages of the network sit at higher offsets) is handed to the all-reduce; without one, all
+    # slabs are reduced by a single launch at the end.
+    stage = {'row': 0, 'hi': total}
+
+    def close_stage(first_param):
+        """Everything from ``first_param`` to the previous stage's start is final once the pending slabs are reduced."""
+        if sync is None:
+            return
+        row_hi = wb.row_of[first_param.rsplit('.', 1)[0]] + 1 if first_param is not None else wb.nrows
+        if row_hi > stage['row']:
+            wb.reduce(grad_flat, stage['row'], row_hi)
+            stage['row'] = row_hi
+        lo = slots[first_param][0] if first_param is not None else 0
+        sync.ready(lo, stage['hi'])
+        stage['hi'] = lo
 
     def gview(name):
         off, shape = slots[name]
@@ -68,6 +90,7 @@ def run_backbone_backward(base, saved, dpred):
     for i in range(last, 1, -1):
         l = layers[i]
         if l[0] == 'pool':
+            close_stage(f'features.{i + 1}.squeeze.weight')    # the Fire modules behind this pool are done
             if i == 2 and 'stem_pool' in saved:
                 continue                                   # folded into the stem weight gradient below
             am, (Hi, Wi) = saved[f'pool{i}']
@@ -99,7 +122,11 @@ def run_backbone_backward(base, saved, dpred):
         ops.stem_wgrad_pooled(dA, pooled, am, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
     else:
         ops.stem_wgrad(dA, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
-    wb.reduce(grad_flat)                                   # all 31 Fire / ConvDet slab reductions: one launch
+    if sync is None:
+        wb.reduce(grad_flat)                               # all 31 Fire / ConvDet slab reductions: one launch
+    else:
+        close_stage(None)                                  # whatever is left (first stage + stem)
+        sync.finish()
     base.last_grad_flat = grad_flat
     return {n: gview(n) for n in slots}
 

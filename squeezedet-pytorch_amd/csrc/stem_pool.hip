@@ -18,6 +18,7 @@ struct StemArgs {
   float* y;           // [B][Ho][Wo][N]
   int B, Hin, Win, Ho, Wo, N;
   int tiles_x, tiles_y;
+  int relu;           // 0: plain Conv2d (the stand-alone features[0] of the module surface)
 };
 
 template <int KS, int PAD, int NT>
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs a) {
       if (n >= a.N) continue;
       f32x4 v = acc[i][j];
       if (a.bias) v += *(const f32x4*)(a.bias + n);
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       *(f32x4*)(dst + n) = v;
     }
   }
@@ -116,12 +117,12 @@ static int launch_stem(StemArgs a, hipStream_t s) {
 }
 
 // x: NCHW [B,3,Hin,Win]; w: OIHW [N,3,KS,KS]; y: NHWC [B,Ho,Wo,N], Ho = (Hin + 2*pad - KS)/2 + 1.
-extern "C" int sqd_stem_conv_relu_fwd(const float* x, const float* w, const float* bias, float* y,
-                                      int B, int Hin, int Win, int N, int ksize, void* stream) {
+extern "C" int sqd_stem_conv_fwd(const float* x, const float* w, const float* bias, float* y,
+                                 int B, int Hin, int Win, int N, int ksize, int relu, void* stream) {
   SQD_CHECK_ARG(x && w && y && B > 0 && Hin > 0 && Win > 0);
   SQD_CHECK_ARG(((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0));
   StemArgs a;
-  a.x = x; a.w = w; a.bias = bias; a.y = y; a.B = B; a.Hin = Hin; a.Win = Win; a.N = N;
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.B = B; a.Hin = Hin; a.Win = Win; a.N = N; a.relu = relu;
   hipStream_t s = (hipStream_t)stream;
   if (ksize == 3 && N == 64) {
     a.Ho = (Hin + 2 - 3) / 2 + 1; a.Wo = (Win + 2 - 3) / 2 + 1;
@@ -132,6 +133,11 @@ extern "C" int sqd_stem_conv_relu_fwd(const float* x, const float* w, const floa
     return launch_stem<7, 3, 6>(a, s);
   }
   return SQD_ERR_UNSUPPORTED;
+}
+
+extern "C" int sqd_stem_conv_relu_fwd(const float* x, const float* w, const float* bias, float* y,
+                                      int B, int Hin, int Win, int N, int ksize, void* stream) {
+  return sqd_stem_conv_fwd(x, w, bias, y, B, Hin, Win, N, ksize, 1, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

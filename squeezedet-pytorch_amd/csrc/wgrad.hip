@@ -401,16 +401,17 @@ struct WgrDesc { long long slab_off, dw_off, db_off, S, slab_stride, N, C, TAPS,
 
 __global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_batched_kernel(const WgrDesc* __restrict__ descs, int n,
                                                                                    const float* __restrict__ slab_base,
-                                                                                   float* __restrict__ grad_base) {
+                                                                                   float* __restrict__ grad_base, int block_first) {
   __shared__ float red[WGR_PARTS][WGR_OUT];
+  const long long wg = (long long)blockIdx.x + block_first;      // workgroup id in the numbering of the whole table
   int row = 0;
-  while (row + 1 < n && descs[row + 1].block_begin <= (long long)blockIdx.x) ++row;      // uniform (scalar loads)
+  while (row + 1 < n && descs[row + 1].block_begin <= wg) ++row;      // uniform (scalar loads)
   const WgrDesc d = descs[row];
   const float* slab = slab_base + d.slab_off;
   const int S = (int)d.S, C = (int)d.C, TAPS = (int)d.TAPS;
   const long long nw = d.N * d.TAPS * d.C;
   const int o = threadIdx.x & (WGR_OUT - 1), part = threadIdx.x / WGR_OUT;
-  const long long idx = ((long long)blockIdx.x - d.block_begin) * WGR_OUT + o;
+  const long long idx = (wg - d.block_begin) * WGR_OUT + o;
   const bool live = idx < nw + d.N;
   float s = 0.f;
   if (live) {
@@ -436,7 +437,18 @@ extern "C" int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_
                                         void* stream) {
   SQD_CHECK_ARG(descs_dev && n > 0 && n <= 4096 && total_blocks > 0 && slab_base && grad_base);
   hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(WGR_OUT * WGR_PARTS), 0, (hipStream_t)stream,
-                     (const WgrDesc*)descs_dev, n, slab_base, grad_base);
+                     (const WgrDesc*)descs_dev, n, slab_base, grad_base, 0);
+  return sqd_launch_status();
+}
+
+// A contiguous range of the table's records only (the training backward reduces each finished stage as soon as its
+// slabs are written, so that stage's gradient bucket can enter the all-reduce while earlier layers are still being
+// differentiated): descs_dev points at the first record of the range, block_first = that record's first workgroup.
+extern "C" int sqd_wgrad_reduce_batched_range(const void* descs_dev, int n, int block_first, int nblocks, const float* slab_base,
+                                              float* grad_base, void* stream) {
+  SQD_CHECK_ARG(descs_dev && n > 0 && n <= 4096 && block_first >= 0 && nblocks > 0 && slab_base && grad_base);
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)nblocks), dim3(WGR_OUT * WGR_PARTS), 0, (hipStream_t)stream,
+                     (const WgrDesc*)descs_dev, n, slab_base, grad_base, block_first);
   return sqd_launch_status();
 }
 

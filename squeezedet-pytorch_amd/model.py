@@ -26,8 +26,19 @@ from . import ops
 from .synthetic import layer_table, convdet_in_channels
 
 
+def _nhwc_input(x, channels, who):
+    """Stand-alone sub-module calls take the reference's NCHW tensors: checked, detached, viewed NHWC (no copy when the
+    tensor came out of another sub-module, whose NCHW result is a permuted view of an NHWC buffer)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == channels):
+        raise RuntimeError(f'{who}: expected an fp32 CUDA/HIP tensor [B,{channels},H,W] (the layers run on the MI355X kernels only)')
+    return x.detach().permute(0, 2, 3, 1).contiguous()
+
+
 class _ConvParams(nn.Module):
-    """Parameter holder with nn.Conv2d's state_dict layout (``weight`` OIHW, ``bias``)."""
+    """Parameter holder with nn.Conv2d's state_dict layout (``weight`` OIHW, ``bias``).  Inside ``SqueezeDetBase.forward``
+    the layer runs as part of the fused HIP plan; called on its own (``model.base.features[0](x)``, ``fire.squeeze(s)``,
+    as the reference's ``nn.Conv2d`` allows) it launches its kernel stand-alone: NCHW in, NCHW out, no activation,
+    inference only (not differentiable -- training differentiates through the parent module)."""
 
     def __init__(self, cin, cout, ksize, stride=1, padding=0):
         super().__init__()
@@ -35,16 +46,42 @@ class _ConvParams(nn.Module):
         self.kernel_size, self.stride, self.padding = (ksize, ksize), (stride, stride), (padding, padding)
         self.weight = nn.Parameter(torch.empty(cout, cin, ksize, ksize))
         self.bias = nn.Parameter(torch.empty(cout))
+        self._own_plan = None
 
     def extra_repr(self):
         return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}'
 
+    def _plan(self, npix):
+        k = self.kernel_size[0]
+        wc = ops.choose_wino_cfg(self.in_channels, self.out_channels, npix) if k == 3 else None
+        cfg_id = ('w', wc) if wc is not None else ('d', ops.choose_cfg(k * k, self.in_channels, self.out_channels, npix))
+        ver = (cfg_id, self.weight._version, self.weight.data_ptr(), self.bias._version, self.bias.data_ptr())
+        if self._own_plan is None or self._own_plan[0] != ver:
+            plan = ops.WinoPlan(self.weight, self.bias, wc) if wc is not None else ops.ConvPlan(self.weight, self.bias, cfg_id[1])
+            self._own_plan = (ver, plan)
+        return self._own_plan[1]
+
+    def run_nhwc(self, x, relu=False, out=None, out_coff=0):
+        """NHWC in -> NHWC out (channel window ``out_coff`` of ``out`` when given)."""
+        Bq, H, W, _ = x.shape
+        y = out if out is not None else torch.empty(Bq, H, W, self.out_channels, device=x.device, dtype=torch.float32)
+        plan = self._plan(Bq * H * W)
+        if isinstance(plan, ops.WinoPlan):
+            return ops.conv_wino(x, 0, plan, y, out_coff, relu=relu)
+        return ops.conv(x, 0, plan, y, out_coff, relu=relu)
+
     def forward(self, x):
-        raise RuntimeError('layers run fused inside SqueezeDetBase.forward (HIP plan); call the parent module')
+        if self.stride[0] == 2:                           # the stem: reads the NCHW image directly
+            if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+                raise RuntimeError('stem conv: expected an fp32 CUDA/HIP NCHW image')
+            return ops.stem_conv_relu(x.detach(), self.weight, self.bias, relu=False).permute(0, 3, 1, 2)
+        return self.run_nhwc(_nhwc_input(x, self.in_channels, 'conv')).permute(0, 3, 1, 2)
 
 
 class _Marker(nn.Module):
-    """Placeholder keeping the reference's nn.Sequential indices (ReLU / MaxPool2d slots)."""
+    """Keeps the reference's nn.Sequential indices for the ReLU / MaxPool2d slots (fused away inside
+    ``SqueezeDetBase.forward``).  Called on its own it applies that layer: the pool through the HIP kernel, the ReLU as a
+    plain elementwise op."""
 
     def __init__(self, what):
         super().__init__()
@@ -54,7 +91,9 @@ class _Marker(nn.Module):
         return self.what
 
     def forward(self, x):
-        raise RuntimeError('layers run fused inside SqueezeDetBase.forward (HIP plan); call the parent module')
+        if self.what.startswith('ReLU'):
+            return torch.relu(x.detach())
+        return ops.maxpool(_nhwc_input(x, x.shape[1], 'max pool')).permute(0, 3, 1, 2)
 
 
 class Fire(nn.Module):
@@ -65,7 +104,15 @@ class Fire(nn.Module):
         self.expand3x3 = _ConvParams(squeeze_planes, expand3x3_planes, 3, padding=1)
 
     def forward(self, x):
-        raise RuntimeError('Fire runs fused inside SqueezeDetBase.forward (HIP plan); call the parent module')
+        """Stand-alone Fire (src/model/squeezedet.py:17-23): NCHW in, NCHW out; three kernel launches, the two expands
+        write the two halves of one buffer (no ``torch.cat``).  Inference only."""
+        xh = _nhwc_input(x, self.squeeze.in_channels, 'Fire')
+        s = self.squeeze.run_nhwc(xh, relu=True)
+        e1, e3 = self.expand1x1.out_channels, self.expand3x3.out_channels
+        out = torch.empty(*s.shape[:3], e1 + e3, device=s.device, dtype=torch.float32)
+        self.expand1x1.run_nhwc(s, relu=True, out=out, out_coff=0)
+        self.expand3x3.run_nhwc(s, relu=True, out=out, out_coff=e1)
+        return out.permute(0, 3, 1, 2)
 
 
 class SqueezeDetBase(nn.Module):
@@ -94,6 +141,7 @@ class SqueezeDetBase(nn.Module):
         self._wgrad_batches = {}
         self._ones_cache = {}
         self.last_grad_flat = None                # flat gradient buffer of the latest backward (every .grad is a view of it)
+        self.grad_sync = None                     # trainer.GradientExchange when data parallel (attach_data_parallel)
         self.use_winograd = True                  # 3x3 forward convs: Winograd F(2x2,3x3) kernel where tuning.json says it is faster
         self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
         # inference forward: pool 2 / 3 folded into the following squeeze (ops.pool_squeeze).  Off by default: measured equal
@@ -172,6 +220,15 @@ class SqueezeDetBase(nn.Module):
             return ops.conv_wino(dy, dy_coff, self.wino_plan(name, mod, wc, 'dgrad'), dx, 0, accumulate=accumulate, ymask=ymask, ymul=ymul)
         return ops.conv(dy, dy_coff, self.plan(name, mod, ops.choose_cfg(9, C, N, Bq * H * W), 'dgrad'), dx, 0,
                         accumulate=accumulate, ymask=ymask, ymul=ymul)
+
+    def invalidate_plans(self):
+        """Drop every packed / transformed weight copy.  The caches notice optimizer steps, ``load_state_dict``, ``.to()``
+        and any other in-place op on the parameters (version counter / data pointer); a write through ``param.data``
+        (EMA, manual ``p.data.copy_``) moves neither -- call this after one."""
+        self._plans.clear(); self._fused_plans.clear(); self._wino_plans.clear()
+        for m in self.modules():
+            if isinstance(m, _ConvParams):
+                m._own_plan = None
 
     def refresh_plans(self):
         """Re-pack every cached plan whose parameter changed since it was packed (after an optimizer step that

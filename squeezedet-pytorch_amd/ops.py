@@ -495,8 +495,9 @@ def stem_out_size(h, w, ksize):
     return (h + 2 * pad - ksize) // 2 + 1, (w + 2 * pad - ksize) // 2 + 1
 
 
-def stem_conv_relu(image, weight, bias, out=None):
-    """image NCHW [B,3,H,W]; weight OIHW [N,3,k,k] (the checkpoint tensor as is); -> NHWC [B,Ho,Wo,N]."""
+def stem_conv_relu(image, weight, bias, out=None, relu=True):
+    """image NCHW [B,3,H,W]; weight OIHW [N,3,k,k] (the checkpoint tensor as is); -> NHWC [B,Ho,Wo,N]
+    (``relu=False``: the bare convolution)."""
     if image.dim() != 4 or image.shape[1] != 3 or image.dtype != torch.float32 or not image.is_cuda:
         raise ValueError(f'stem: image must be fp32 CUDA NCHW with 3 channels, got {tuple(image.shape)}')
     image = image.contiguous()
@@ -513,9 +514,9 @@ def stem_conv_relu(image, weight, bias, out=None):
     b = None if bias is None else bias.detach().contiguous()
     br = _Bracket(f'stem_conv<{k}>', f'stem {H}x{W}', 2.0 * B * Ho * Wo * N * 3 * k * k,
                   4.0 * (B * 3 * H * W + B * Ho * Wo * N)) if _timer is not None else None
-    rc = nat.lib().sqd_stem_conv_relu_fwd(nat.ptr(image), nat.ptr(w), nat.ptr(b), nat.ptr(out), B, H, W, N, k,
-                                          nat.stream_handle(image.device))
-    nat.check(rc, 'sqd_stem_conv_relu_fwd')
+    rc = nat.lib().sqd_stem_conv_fwd(nat.ptr(image), nat.ptr(w), nat.ptr(b), nat.ptr(out), B, H, W, N, k, int(bool(relu)),
+                                     nat.stream_handle(image.device))
+    nat.check(rc, 'sqd_stem_conv_fwd')
     if br is not None:
         br.done()
     return out
@@ -786,13 +787,16 @@ class WgradBatch:
 
     def __init__(self, entries, device):
         rows, self.slabs, off, blk = [], {}, 0, 0
+        self.row_blocks = [0]                  # first workgroup of every record (+ the total at the end)
         for key, N, C, taps, B, H, W, dw_off, db_off in entries:
             S, stride = wgrad_split(N, C, taps, B, H, W)
             rows.append([off, dw_off, db_off, S, stride, N, C, taps, blk])
             self.slabs[key] = (off, S * stride)
             off += S * stride
             blk += -(-stride // _WGR_OUT)
+            self.row_blocks.append(blk)
         self.total_blocks = blk
+        self.row_of = {key: i for i, (key, *_rest) in enumerate(entries)}
         self.workspace = torch.empty(off, device=device, dtype=torch.float32)
         self.table = torch.tensor(rows, dtype=torch.int64).to(device)
         self.nrows = len(rows)
@@ -802,10 +806,20 @@ class WgradBatch:
         off, n = self.slabs[key]
         return self.workspace[off:off + n]
 
-    def reduce(self, grad_flat):
-        br = _Bracket('wgrad_reduce_batched', f'{self.nrows} layers', 0.0, self.bytes) if _timer is not None else None
-        rc = nat.lib().sqd_wgrad_reduce_batched(nat.ptr(self.table), self.nrows, self.total_blocks, nat.ptr(self.workspace),
-                                                nat.ptr(grad_flat), nat.stream_handle(grad_flat.device))
+    def reduce(self, grad_flat, row_lo=0, row_hi=None):
+        """Reduce the slabs of records [row_lo, row_hi) (default: all) into ``grad_flat``."""
+        row_hi = self.nrows if row_hi is None else row_hi
+        if not (0 <= row_lo < row_hi <= self.nrows):
+            raise ValueError('WgradBatch.reduce: bad record range')
+        nrec = row_hi - row_lo
+        b0, b1 = self.row_blocks[row_lo], self.row_blocks[row_hi]
+        br = _Bracket('wgrad_reduce_batched', f'{nrec} layers', 0.0, self.bytes * (b1 - b0) / max(self.total_blocks, 1)) if _timer is not None else None
+        if nrec == self.nrows:
+            rc = nat.lib().sqd_wgrad_reduce_batched(nat.ptr(self.table), self.nrows, self.total_blocks, nat.ptr(self.workspace),
+                                                    nat.ptr(grad_flat), nat.stream_handle(grad_flat.device))
+        else:
+            rc = nat.lib().sqd_wgrad_reduce_batched_range(nat.c_p(self.table.data_ptr() + row_lo * 9 * 8), nrec, b0, b1 - b0,
+                                                          nat.ptr(self.workspace), nat.ptr(grad_flat), nat.stream_handle(grad_flat.device))
         nat.check(rc, 'sqd_wgrad_reduce_batched')
         if br is not None:
             br.done()

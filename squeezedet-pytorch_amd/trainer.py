@@ -1,167 +1,312 @@
-"""``Trainer`` with the reference's interface (src/engine/trainer.py:9-92) and process-per-GPU data
-parallelism over RCCL/xGMI in place of the reference's single-process ``DataParallel``
-(src/utils/data_parallel.py:46-156).
+"""Training-side plumbing of the hot path: the data-parallel gradient exchange and a ``Trainer`` with the
+reference's interface.
 
-Reference semantics kept: ``loss = loss.mean()`` over the GLOBAL per-sample loss vector
-(trainer.py:43; DataParallel gathers the per-sample vectors to GPU 0 first), ``zero_grad`` ->
-``backward`` -> ``clip_grad_norm_(params, cfg.grad_norm)`` -> ``optimizer.step()`` (:46-50), StepLR per
-epoch (:67-68).  With W ranks each holding b = B/W images the global mean's gradient is
-(1/W) * sum_r grad(mean_local_r): one all-reduce(SUM) of the flattened gradient (2,082,120 floats =
-8.33 MB for SqueezeDet) per step, then a 1/W scale; the clip then sees the same global norm on every
-rank and the SGD step is local and deterministic, so replicas stay bit-identical.  There is no
-per-step weight broadcast (the reference's ``replicate``) and no data-path collective in inference.
+What the reference does (src/engine/trainer.py:18-92, src/utils/data_parallel.py:46-156): ONE Python process
+replicates the module onto every GPU each step, scatters the batch by ``chunk_sizes``, gathers the per-sample loss
+vectors on GPU 0 and back-propagates ``loss.mean()`` of that gathered vector through the replicas.
+
+What runs here: one process per GPU (``torch.distributed`` over RCCL / xGMI), weights replicated once, and the
+gradient of that same GLOBAL mean assembled by an all-reduce that the backward itself drives:
+
+* ``attach_data_parallel(model)`` hangs a ``GradientExchange`` on the model's ``SqueezeDetBase``.  From then on
+  ``loss.backward()`` leaves the global-mean gradient in every ``p.grad`` -- the reference's own
+  ``src/engine/trainer.py`` loop (``zero_grad -> backward -> clip_grad_norm_ -> step``) runs unchanged on top of it.
+* The backward (``backward.py``) reports each finished slice of its flat gradient buffer -- ConvDet + the 24x78 Fire
+  modules first (86 % of the parameters), then the 48x156 and the 96x312 stages -- and the exchange all-reduces that
+  bucket on a side stream while the remaining layers are still being differentiated.
+* Shards may be unequal: every rank scales its bucket by its local image count, one extra float at the end of the
+  buffer carries that count through the same all-reduce, and the sum is divided by the global count on the device --
+  exactly ``mean`` over the gathered vector (trainer.py:43) for any ``chunk_sizes``, with no extra collective and no
+  host sync.  ``clip_grad_norm_`` then sees the same global norm on every rank, SGD is local and deterministic.
 """
 from __future__ import annotations
 
 import time
 
 import torch
-import torch.nn as nn
-
-EPSILON = 1e-10
 
 
-class MetricLogger(object):
-    """Running average (src/utils/misc.py:29-40)."""
-
-    def __init__(self):
-        self.val = 0
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
-
-    def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / (self.count + EPSILON)
-
-
-def _dist():
+def _dist(group=None):
     import torch.distributed as dist
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
 def shard_sizes(batch_size, world):
-    """Per-rank chunk sizes for a global batch, first ranks take the remainder -- the equal-split case
-    of the reference's ``chunk_sizes`` (src/utils/config.py:102-110)."""
-    base, rem = divmod(batch_size, world)
-    return [base + (1 if r < rem else 0) for r in range(world)]
+    """Images per rank for a global batch (first ranks take the remainder): the even-split case of the
+    reference's ``chunk_sizes`` (src/utils/config.py:102-110)."""
+    q, r = divmod(int(batch_size), int(world))
+    return [q + (i < r) for i in range(world)]
 
 
-def allreduce_gradients(params, world=None, group=None):
-    """Sum-all-reduce the gradients of ``params`` as ONE flat bucket and divide by the world size.
-    Works for any backend (RCCL on GPUs, gloo in the CPU tests).  Returns the flat bucket."""
-    dist = _dist()
+class GradientExchange:
+    """All-reduce of the flat gradient buffer in buckets, overlapped with the backward that fills it.
+
+    Driven by ``backward.run_backbone_backward``: ``begin(flat, total, local_batch)`` once the buffer exists (``flat``
+    holds ``total`` gradient floats plus one trailing count slot), ``ready(lo, hi)`` whenever the slice ``[lo, hi)`` is
+    final on the current stream, ``finish()`` before the gradients are handed to autograd.  Works on any backend;
+    the side stream is only used for CUDA/HIP buffers."""
+
+    def __init__(self, group=None, overlap=True):
+        self.group = group
+        self.overlap = overlap
+        self.force = False                     # run the collectives even in a one-rank group (bench.py --force-dist)
+        self._side = None
+        self._flat = None
+        self._pending = []
+        self.buckets_last_step = []            # [(lo, hi)] of the latest backward, for tests / logging
+
+    def world(self):
+        d = _dist()
+        return d.get_world_size(self.group) if d is not None else 1
+
+    def begin(self, flat, total, local_batch):
+        self._flat, self._total, self._b = flat, int(total), float(local_batch)
+        self._pending = []
+        self.buckets_last_step = []
+        self._active = self.world() > 1 or (self.force and _dist() is not None)
+        if self._active:
+            flat[total:].fill_(self._b)
+            if flat.is_cuda and self.overlap and self._side is None:
+                self._side = torch.cuda.Stream(device=flat.device)
+
+    def ready(self, lo, hi):
+        if not self._active or hi <= lo:
+            return
+        d = _dist()
+        if hi == self._total:
+            hi = self._flat.numel()             # the count slot travels with the tail bucket
+        self.buckets_last_step.append((int(lo), int(hi)))
+        grad_hi = min(hi, self._total)
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                self._flat[lo:grad_hi].mul_(self._b)
+                work = d.all_reduce(self._flat[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._flat[lo:grad_hi].mul_(self._b)
+            work = d.all_reduce(self._flat[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append(work)
+
+    def finish(self):
+        if not self._active:
+            return
+        for w in self._pending:
+            w.wait()                            # CUDA: the current stream waits for the collective; CPU: blocks
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._pending = []
+        flat, total = self._flat, self._total
+        flat[:total].div_(flat[total])          # global image count, summed by the same all-reduce
+        self._flat = None
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Identical weights on every rank, ONE broadcast of a flat copy (not one per tensor); written back with
+    ``copy_`` so version counters move and the packed-weight caches of the HIP plan refresh."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return
+    params = [p for p in module.parameters()]
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        d.broadcast(flat, src=src, group=group)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+
+def find_base(model):
+    """The ``SqueezeDetBase`` inside ``model`` (``SqueezeDetWithLoss`` / ``SqueezeDet`` / the base itself / a ``.module``
+    wrapper)."""
+    from .model import SqueezeDetBase
+    for m in model.modules():
+        if isinstance(m, SqueezeDetBase):
+            return m
+    raise TypeError('no SqueezeDetBase inside the model')
+
+
+def attach_data_parallel(model, optimizer=None, group=None, overlap=True, broadcast=True, seed_offset=True):
+    """Process-per-GPU replacement of the reference's ``DataParallel`` wrapper (src/engine/trainer.py:83-85): after this
+    call ``loss.mean().backward()`` on the local shard leaves the gradient of the GLOBAL batch mean in ``p.grad`` on every
+    rank.  Also replicates rank 0's weights (and optimizer state tensors) once and de-correlates the dropout streams of
+    the ranks.  No-op without an initialised process group.  Returns the ``GradientExchange`` (or None)."""
+    d = _dist()
+    base = find_base(model)
+    if d is None:
+        base.grad_sync = None
+        return None
+    ex = GradientExchange(group=group, overlap=overlap)
+    base.grad_sync = ex
+    if broadcast:
+        broadcast_parameters(model, 0, group)
+        if optimizer is not None:
+            tensors = [v for st in optimizer.state.values() for v in st.values() if isinstance(v, torch.Tensor) and v.is_floating_point()]
+            if tensors:
+                with torch.no_grad():
+                    flat = torch.cat([t.reshape(-1) for t in tensors])
+                    d.broadcast(flat, src=0, group=group)
+                    off = 0
+                    for t in tensors:
+                        t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
+    if seed_offset:
+        rank = d.get_rank(group)
+        if rank:
+            torch.manual_seed(torch.initial_seed() + rank)     # seeds the CPU and every GPU generator of this process
+    return ex
+
+
+def detach_data_parallel(model):
+    find_base(model).grad_sync = None
+
+
+def allreduce_gradients(params, world=None, group=None, local_batch=None):
+    """Stand-alone form for gradients that did NOT come out of the HIP backward (tests with oracle gradients, foreign
+    modules): averages ``p.grad`` over the ranks as one flat bucket -- weighted by ``local_batch`` when given (exact
+    global mean for unequal shards), else a plain mean over ranks.  Consecutive views of one buffer (what the HIP
+    backward emits) are reduced in place.  Returns the flat bucket."""
+    d = _dist()
     params = [p for p in params if p.grad is not None]
     if not params:
         return None
     if world is None:
-        world = dist.get_world_size(group) if dist is not None else 1
-    # The HIP backward already emits every gradient as a view of one flat buffer (named_parameters order): all-reduce
-    # that buffer in place -- no gather copy, no scatter back.
+        world = d.get_world_size(group) if d is not None else 1
     g0 = params[0].grad
-    off, contiguous_views = 0, g0.is_contiguous()
+    off, in_place = 0, g0.is_contiguous()
     for p in params:
         g = p.grad
-        if not (contiguous_views and g.is_contiguous() and g.dtype == g0.dtype and g.device == g0.device
+        if not (in_place and g.is_contiguous() and g.dtype == g0.dtype and g.device == g0.device
                 and g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr()
                 and g.storage_offset() == g0.storage_offset() + off):
-            contiguous_views = False
+            in_place = False
             break
         off += g.numel()
-    if contiguous_views:
-        flat = g0.as_strided((off,), (1,), g0.storage_offset()) if off != g0.numel() else g0.reshape(-1)
-        if dist is not None and world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if in_place:
+        flat = g0.as_strided((off,), (1,), g0.storage_offset())
+    else:
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+    if d is not None and world > 1:
+        if local_batch is None:
+            d.all_reduce(flat, op=d.ReduceOp.SUM, group=group)
             flat.mul_(1.0 / world)
-        return flat
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    if dist is not None and world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.mul_(1.0 / world)
-    off = 0
-    views = []
-    for p in params:
-        n = p.numel()
-        views.append(flat[off:off + n].view_as(p))
-        off += n
-    torch._foreach_copy_([p.grad for p in params], views)
+        else:
+            cnt = torch.full((1,), float(local_batch), dtype=flat.dtype, device=flat.device)
+            flat.mul_(float(local_batch))
+            d.all_reduce(flat, op=d.ReduceOp.SUM, group=group)
+            d.all_reduce(cnt, op=d.ReduceOp.SUM, group=group)
+            flat.div_(cnt)
+    if not in_place:
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
     return flat
 
 
+def encode_sparse_batch(batch, cfg):
+    """Collate helper: a batch carrying sparse annotations (``gt_boxes`` / ``gt_class_ids``: per-image lists, network-input
+    coordinates) instead of the dense ``gt`` gets the dense tensor built ON THE GPU (``annotations.encode_annotations``;
+    the reference does it per image in DataLoader workers, src/datasets/base.py:61-76).  Dense batches pass through."""
+    if 'gt' in batch or 'gt_boxes' not in batch:
+        return batch
+    from .annotations import encode_annotations
+    out = {k: v for k, v in batch.items() if k not in ('gt_boxes', 'gt_class_ids')}
+    out['gt'] = encode_annotations(batch['gt_class_ids'], batch['gt_boxes'], cfg.anchors, cfg.num_classes, device=cfg.device)
+    return out
+
+
+class _Mean:
+    """Weighted running mean of a logged quantity."""
+    __slots__ = ('last', 'total', 'weight')
+
+    def __init__(self):
+        self.last, self.total, self.weight = 0.0, 0.0, 0.0
+
+    def add(self, value, weight=1.0):
+        self.last = value
+        self.total += value * weight
+        self.weight += weight
+
+    @property
+    def mean(self):
+        return self.total / self.weight if self.weight else 0.0
+
+
+LOSS_KEYS = ('loss', 'class_loss', 'score_loss', 'bbox_loss')
+
+
 class Trainer(object):
+    """Same constructor, ``train_epoch`` / ``val_epoch`` / ``run_epoch`` / ``set_device`` surface and return values as the
+    reference's ``Trainer`` (src/engine/trainer.py:9-92).  Differences underneath: process-per-GPU gradient exchange
+    (``attach_data_parallel``) instead of the DataParallel wrapper, sparse annotations are encoded on the GPU, and the
+    four logged losses cost ONE host sync per iteration (one stacked copy) instead of four ``.item()`` calls."""
+
     def __init__(self, model, optimizer, lr_scheduler, cfg):
-        self.model = model
-        self.optimizer = optimizer
-        self.lr_scheduler = lr_scheduler
-        self.cfg = cfg
+        self.model, self.optimizer, self.lr_scheduler, self.cfg = model, optimizer, lr_scheduler, cfg
+        self.metrics = list(LOSS_KEYS)
         self.set_device(cfg.gpus, cfg.chunk_sizes, cfg.device)
-        self.metrics = ['loss', 'class_loss', 'score_loss', 'bbox_loss']
+
+    def set_device(self, gpus, chunk_sizes, device):
+        """``gpus`` / ``chunk_sizes`` describe the global job as in the reference; this process only owns ``device``.
+        Multi-GPU = a process group initialised by the launcher (torchrun)."""
+        d = _dist()
+        self.world = d.get_world_size() if d is not None else 1
+        self.rank = d.get_rank() if d is not None else 0
+        self.model = self.model.to(device)
+        for st in self.optimizer.state.values():
+            for name, v in list(st.items()):
+                if isinstance(v, torch.Tensor):
+                    st[name] = v.to(device=device, non_blocking=True)
+        self.exchange = attach_data_parallel(self.model, self.optimizer)
+
+    def _to_device(self, batch):
+        batch = encode_sparse_batch(batch, self.cfg)
+        return {k: (v.to(device=self.cfg.device, non_blocking=True) if ('image_meta' not in k and isinstance(v, torch.Tensor)) else v)
+                for k, v in batch.items()}
+
+    def _iteration(self, batch, train):
+        per_image_loss, parts = self.model(batch)
+        if train:
+            self.optimizer.zero_grad()
+            per_image_loss.mean().backward()       # local shard mean; the gradient exchange turns it into the global mean
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], self.cfg.grad_norm)
+            self.optimizer.step()
+        n = per_image_loss.shape[0]
+        logged = torch.stack([parts[k].detach().sum() for k in self.metrics] + [per_image_loss.new_tensor(float(n))])
+        if self.world > 1:
+            _dist().all_reduce(logged)             # 5 floats: global sums and the global image count
+        logged = logged.tolist()                   # the iteration's single host sync
+        return [v / logged[-1] for v in logged[:-1]], n
 
     def run_epoch(self, phase, epoch, data_loader):
-        start_time = time.time()
-        if phase == 'train':
-            self.model.train()
-        else:
-            self.model.eval()
-            torch.cuda.empty_cache()
-
-        metric_loggers = {m: MetricLogger() for m in self.metrics}
-        data_timer, net_timer = MetricLogger(), MetricLogger()
-        num_iters = len(data_loader) if self.cfg.num_iters < 0 else self.cfg.num_iters
-        end = time.time()
-        params = [p for p in self.model.parameters() if p.requires_grad]
-
-        for iter_id, batch in enumerate(data_loader):
-            if iter_id >= num_iters:
+        t_epoch = time.time()
+        train = phase == 'train'
+        self.model.train(train)
+        means = {k: _Mean() for k in self.metrics}
+        limit = len(data_loader) if self.cfg.num_iters < 0 else self.cfg.num_iters
+        t_mark = time.time()
+        for it, batch in enumerate(data_loader):
+            if it >= limit:
                 break
-            if 'gt' not in batch and 'gt_boxes' in batch:
-                # sparse annotations (per-image lists of xyxy boxes / class ids): encode the dense gt on the GPU
-                # instead of in DataLoader workers (prepare_annotations, src/datasets/base.py:61-76)
-                from .annotations import encode_annotations
-                batch = dict(batch)
-                batch['gt'] = encode_annotations(batch.pop('gt_class_ids'), batch.pop('gt_boxes'), self.cfg.anchors,
-                                                 self.cfg.num_classes, device=self.cfg.device)
-            for k in batch:
-                if 'image_meta' not in k and isinstance(batch[k], torch.Tensor):
-                    batch[k] = batch[k].to(device=self.cfg.device, non_blocking=True)
-            data_timer.update(time.time() - end)
-            end = time.time()
-
-            loss, loss_stats = self.model(batch)
-            loss = loss.mean()                       # local shard mean; the all-reduce below makes it the global mean
-
-            if phase == 'train':
-                self.optimizer.zero_grad()
-                loss.backward()
-                if self.world > 1:
-                    allreduce_gradients(params, self.world)
-                nn.utils.clip_grad_norm_(params, self.cfg.grad_norm)
-                self.optimizer.step()
-
-            msg = 'epoch {0:<3s} {1:<5s} [{2}/{3}] '.format(str(epoch) + ':', phase, iter_id, num_iters)
-            stats = torch.stack([loss_stats[m].mean() for m in metric_loggers]).detach()
-            if self.world > 1:                       # 4 floats: log the global means like the gathered vector would
-                _dist().all_reduce(stats)
-                stats /= self.world
-            stats = stats.tolist()                   # ONE host sync per iteration (the reference does four .item())
-            for m, value in zip(metric_loggers, stats):
-                metric_loggers[m].update(value, batch['image'].shape[0])
-                msg += '| {} {:.3f} '.format(m, value)
-
-            net_timer.update(time.time() - end)
-            end = time.time()
-            msg += '| data {:.1f}ms | net {:.1f}ms'.format(1000. * data_timer.val, 1000. * net_timer.val)
-            if iter_id % self.cfg.print_interval == 0 and self.rank == 0:
-                print(msg)
-            del loss, loss_stats
-
-        if phase == 'train':
+            batch = self._to_device(batch)
+            t_data = time.time() - t_mark
+            values, n = self._iteration(batch, train)
+            for k, v in zip(self.metrics, values):
+                means[k].add(v, n)
+            t_net = time.time() - t_mark - t_data
+            if self.rank == 0 and it % self.cfg.print_interval == 0:
+                losses = ' '.join(f'| {k} {v:.3f}' for k, v in zip(self.metrics, values))
+                print(f'epoch {epoch}: {phase:<5s} [{it}/{limit}] {losses} | data {1e3 * t_data:.1f}ms | net {1e3 * t_net:.1f}ms')
+            t_mark = time.time()
+        if train:
             self.lr_scheduler.step()
-        stats = {k: v.avg for k, v in metric_loggers.items()}
-        stats.update({'epoch_time': (time.time() - start_time) / 60.})
-        return stats
+        out = {k: m.mean for k, m in means.items()}
+        out['epoch_time'] = (time.time() - t_epoch) / 60.0
+        return out
 
     def train_epoch(self, epoch, data_loader):
         return self.run_epoch('train', epoch, data_loader)
@@ -170,25 +315,12 @@ class Trainer(object):
     def val_epoch(self, epoch, data_loader):
         return self.run_epoch('val', epoch, data_loader)
 
-    def set_device(self, gpus, chunk_sizes, device):
-        """One process per GPU: ``gpus``/``chunk_sizes`` describe the global job like in the reference, but this
-        process only ever owns ``device``.  Multi-GPU = torch.distributed already initialised by the launcher."""
-        dist = _dist()
-        self.world = dist.get_world_size() if dist is not None else 1
-        self.rank = dist.get_rank() if dist is not None else 0
-        self.model = self.model.to(device)
-        if self.world > 1:                           # identical initial weights on every rank (once, not per step)
-            for p in self.model.parameters():
-                dist.broadcast(p.data, src=0)
-        for state in self.optimizer.state.values():
-            for k, v in state.items():
-                if isinstance(v, torch.Tensor):
-                    state[k] = v.to(device=device, non_blocking=True)
 
-
-def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1):
-    """Benchmark helper: returns (step_fn, description).  A step = fwd + loss + bwd (+ RCCL all-reduce)
-    + clip_grad_norm_(5.0) + SGD(lr .01, momentum .9, wd 1e-4) on a device-resident batch."""
+def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1, force_exchange=False):
+    """Benchmark helper: returns (step_fn, description, probe_fn).  A step = fwd + loss + bwd (with the bucketed RCCL
+    gradient exchange when a process group exists) + clip_grad_norm_(5.0) + SGD(lr .01, momentum .9, wd 1e-4) on a
+    device-resident batch.  ``probe_fn()`` -> (gt on the CPU, eval-mode per-image loss of the current weights on the CPU):
+    what bench.py's CPU leg checks against the oracle before the first optimizer step."""
     from . import synthetic
     from .model import SqueezeDetWithLoss
     model = SqueezeDetWithLoss(cfg)
@@ -196,20 +328,31 @@ def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1):
     model = model.to(image.device).train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
-    gt = synthetic.make_gt(image.shape[0], cfg.anchors, cfg.input_size, cfg.num_classes, seed=gt_seed + rank).to(image.device)
+    gt_cpu = synthetic.make_gt(image.shape[0], cfg.anchors, cfg.input_size, cfg.num_classes, seed=gt_seed + rank)
+    gt = gt_cpu.to(image.device)
     batch = {'image': image, 'gt': gt}
+    ex = attach_data_parallel(model, opt) if dist is not None else None
+    if ex is not None:
+        ex.force = bool(force_exchange)
 
     def step():
         loss, stats = model(batch)
         loss = loss.mean()
         opt.zero_grad()
         loss.backward()
-        if world > 1:
-            allreduce_gradients(params, world)
-        nn.utils.clip_grad_norm_(params, cfg.grad_norm)
+        torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm)
         opt.step()
         return loss
 
-    desc = (f'{"SqueezeDet" if cfg.arch == "squeezedet" else "SqueezeDet+"} KITTI 1248x384 bs={image.shape[0]}/GPU training: fwd + multi-task loss + bwd + clip(5.0) + SGD'
-            + (f' + RCCL grad all-reduce over {world} GPUs' if world > 1 else ''))
-    return step, desc
+    def probe():
+        model.eval()
+        with torch.no_grad():
+            lv, _ = model(batch)
+        model.train()
+        return gt_cpu, lv.detach().cpu()
+
+    net = 'SqueezeDet' if cfg.arch == 'squeezedet' else 'SqueezeDet+'
+    desc = f'{net} KITTI 1248x384 bs={image.shape[0]}/GPU training: fwd + multi-task loss + bwd + clip(5.0) + SGD'
+    if ex is not None:
+        desc += f' + RCCL gradient all-reduce over {world} GPU(s) in 3 buckets overlapped with backward'
+    return step, desc, probe

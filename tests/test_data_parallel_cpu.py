@@ -64,6 +64,90 @@ def test_gloo_world2_gradient_allreduce_equals_global_mean(tmp_path):
         assert (g0[k] - ref).abs().max().item() <= 1e-4 * max(float(ref.abs().max()), 1e-3), k
 
 
+def _exchange_worker(rank, world, port, out_dir):
+    """Unequal shards (B = 5 on 2 ranks: 3 + 2) through trainer.GradientExchange exactly as backward.py drives it:
+    begin -> ready(tail bucket) -> ready(middle) -> ready(head) -> finish; then the same gradients as ONE bucket."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd import synthetic
+    from squeezedet_pytorch_amd.trainer import GradientExchange, allreduce_gradients, shard_sizes
+    size = (64, 96)
+    cfg = sqd.make_cfg(input_size=size, device='cpu')
+    sd = synthetic.make_state_dict('squeezedet', seed=1234)
+    B = 5
+    x = synthetic.make_images(B, size, seed=3)
+    gt = synthetic.make_gt(B, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3)
+    sizes = shard_sizes(B, world)
+    lo = sum(sizes[:rank]); hi = lo + sizes[rank]
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred = oracle.backbone_forward(x[lo:hi], params)
+    loss_vec, _ = oracle.multitask_loss(pred, gt[lo:hi], cfg.anchors, size)
+    loss_vec.mean().backward()                                     # local shard mean, as the Trainer does
+    names = list(params)
+    total = sum(p.numel() for p in params.values())
+    local = torch.cat([params[k].grad.reshape(-1) for k in names])
+    offs, o = {}, 0
+    for k in names:
+        offs[k] = o; o += params[k].numel()
+    results = {}
+    for label, cuts in (('three', [offs['base.features.9.squeeze.weight'], offs['base.features.6.squeeze.weight'], 0]), ('one', [0])):
+        flat = torch.empty(total + 1)
+        flat[:total] = local
+        ex = GradientExchange()
+        ex.begin(flat, total, sizes[rank])
+        top = total
+        for c in cuts:                                              # tail first, like the backward walk
+            ex.ready(c, top); top = c
+        ex.finish()
+        results[label] = flat[:total].clone()
+        assert len(ex.buckets_last_step) == len(cuts) and ex.buckets_last_step[0][1] == total + 1
+    assert torch.equal(results['three'], results['one'])            # bucketed == single bucket, bitwise
+    # the stand-alone helper with the same weighting
+    plist = list(params.values())
+    allreduce_gradients(plist, world, local_batch=sizes[rank])
+    torch.save({'flat': results['three'], 'names': names, 'helper': torch.cat([p.grad.reshape(-1) for p in plist])},
+               os.path.join(out_dir, f'e{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gloo_world2_bucketed_exchange_unequal_shards(tmp_path):
+    """B = 5 over 2 ranks (3 + 2 images): the bucketed, count-weighted exchange reproduces the gradient of the mean over
+    the GLOBAL batch (src/engine/trainer.py:43 on the gathered vector), identically on both ranks."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    import oracle
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd import synthetic
+    size = (64, 96)
+    cfg = sqd.make_cfg(input_size=size, device='cpu')
+    sd = synthetic.make_state_dict('squeezedet', seed=1234)
+    x = synthetic.make_images(5, size, seed=3)
+    gt = synthetic.make_gt(5, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3)
+    _, _, grads, _, _, _ = oracle.train_step_reference(sd, None, x, gt, cfg.anchors, size)
+    e0 = torch.load(os.path.join(tmp_path, 'e0.pt'))
+    e1 = torch.load(os.path.join(tmp_path, 'e1.pt'))
+    assert torch.equal(e0['flat'], e1['flat'])
+    ref = torch.cat([grads[k].reshape(-1) for k in e0['names']])
+    scale = float(ref.abs().max())
+    assert (e0['flat'] - ref).abs().max().item() <= 1e-4 * scale
+    assert (e0['helper'] - ref).abs().max().item() <= 1e-4 * scale
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """``bench.py --gpus N`` without a launcher starts the ranks itself; with fewer than N GPUs visible (none here) it must
+    exit non-zero instead of printing a one-GPU number."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+
+
 def test_shard_sizes():
     from squeezedet_pytorch_amd.trainer import shard_sizes
     assert shard_sizes(160, 8) == [20] * 8
