@@ -354,7 +354,10 @@ def main():
         det = Detector(model, cfg)
         out_bufs = ops._det_buffers(B, cfg.keep_top_k, dev, cfg.num_anchors)
 
+        eager_steps = [0]
+
         def infer_step():
+            eager_steps[0] += 1
             return det.detect_device(x, out=out_bufs)
         elapsed, repeat, how, run = measure(infer_step, capture=True)
         summ, nprof = event_profile(infer_step, run)
@@ -366,6 +369,7 @@ def main():
         result['infer'] = {
             'value': round(value, 1), 'ms_per_step': round(ms, 4), 'timed_with': how,
             'repeat_window_ms_per_step': round(repeat / args.steps * 1e3, 4),
+            'eager_steps_launched': eager_steps[0],      # (profiling scripts divide launch counts by this; with --no-graph = every step)
             'workload': (f'SqueezeDet KITTI 1248x384 bs={B} inference on {where} (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
                          else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on {where}'),
             'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
@@ -426,6 +430,8 @@ def main():
             'repeat_window_ms_per_step': head['repeat_window_ms_per_step'],
             'layer_families': head['layer_families'], 'kernels_event_profile': head['kernels_event_profile'],
         }
+        if 'eager_steps_launched' in head:
+            line['eager_steps_launched'] = head['eager_steps_launched']
         if args.mode == 'both':
             line['train'] = result['train']
         print(json.dumps(line))

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 REPO=$PWD
 cd /tmp
-timeout -k 10 150 rocprofv3 --pmc $@ --output-format csv -d $OUT -o pmc -- python3 ${SQD_PMC_PROG:-$REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph} $SQD_PMC_ARGS > $OUT/out.json 2> $OUT/stderr.log
+timeout -k 10 150 rocprofv3 --pmc $@ --output-format csv -d $OUT -o pmc -- python3 ${SQD_PMC_PROG:-$REPO/bench.py --mode infer --steps 3 --warmup 2 --no-cpu-baseline --no-graph} $SQD_PMC_ARGS > $OUT/out.json 2> $OUT/stderr.log
 cd $REPO
 python3 - <<PY
 import csv, glob, collections

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 REPO=$PWD
 for C in FETCH_SIZE WRITE_SIZE; do
   OUT=$REPO/gpurun_out/pmc_${TAG}_$C; mkdir -p $OUT; cd /tmp
-  rocprofv3 --pmc $C --output-format csv -d $OUT -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $OUT/out.json 2> $OUT/stderr.log
+  rocprofv3 --pmc $C --output-format csv -d $OUT -o pmc -- python3 $REPO/bench.py --mode infer --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $OUT/out.json 2> $OUT/stderr.log
   cd $REPO
 done
 python3 - <<PY
@@ -35,13 +35,20 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         k = short_name(r["Kernel_Name"])
         res[k][C] += float(r["Counter_Value"]); res[k]["n"][C] += 1
 out = {}
+# steps the profiled process launched eagerly (bench.py prints it): launches per step = launches profiled / steps
+steps = json.loads([l for l in open("gpurun_out/pmc_${TAG}_FETCH_SIZE/out.json") if l.startswith("{")][-1])["eager_steps_launched"]
 for k, v in res.items():
     nf, nw = max(v["n"]["FETCH_SIZE"], 1), max(v["n"]["WRITE_SIZE"], 1)
     fetch_kb, write_kb = v["FETCH_SIZE"] / nf, v["WRITE_SIZE"] / nw
     out[k] = {"launches_profiled": nf, "fetch_size_kb_raw": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
               "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
               "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); average over all launches of this kernel"}
+    if nf % steps == 0:
+        out[k]["launches_per_step"] = nf // steps      # the launch set this average was taken over (checked by tests/test_profiles.py)
+out["_meta"] = {"workload": "python bench.py --mode infer --steps 3 --warmup 2 --no-cpu-baseline --no-graph (SqueezeDet bs=20 1248x384 inference)",
+                "eager_steps_profiled": steps,
+                "counters": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units; fabric-side L2 request counters: Infinity-Cache hits are included (MI355X_MICROARCH.md, HBM section), so these are L2<->fabric bytes, an upper bound of HBM bytes"}
 json.dump(out, open("gpurun_out/traffic_${TAG}.json", "w"), indent=1, sort_keys=True)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:16]:
+for k, v in sorted(((k, v) for k, v in out.items() if k != "_meta"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:16]:
     print(f'{k[:60]:60s} {v["hbm_bytes_per_launch"]/1e6:9.1f} MB/launch  (fetch raw {v["fetch_size_kb_raw"]/1e3:.1f} MB, write {v["write_size_kb"]/1e3:.1f} MB)')
 PY

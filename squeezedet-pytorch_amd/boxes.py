@@ -111,24 +111,28 @@ def prepare_annotations(class_ids, boxes, anchors, num_classes):
 
 
 def boxes_postprocess(boxes, image_meta):
-    """Map boxes from network-input coordinates back to the original image (in place, like the
-    reference).  Handles the keys the eval path produces (``scales``, ``drifts``) and the
-    train-time ones (``padding``, ``crops``, ``flipped``) with the reference's semantics."""
+    """Undo, in place, the geometric pre-processing recorded in ``image_meta`` so that ``boxes`` ([n,4] xyxy, network-input
+    coordinates) land in original-image coordinates; returns ``boxes``.  Same transforms, order and float arithmetic as
+    src/utils/boxes.py:138-168: un-scale (``scales`` = (sy, sx)), un-pad, un-crop (both (top, bottom, left, right)),
+    mirror back if ``flipped``, un-drift (``drifts`` = (dy, dx)).  The eval path only ever carries ``scales`` and zero
+    ``drifts``; the device path folds that division into the detect kernel."""
+    xs, ys = boxes[:, 0::2], boxes[:, 1::2]            # strided views: (x1, x2) and (y1, y2) columns
     if 'scales' in image_meta:
-        boxes[:, [0, 2]] /= image_meta['scales'][1]
-        boxes[:, [1, 3]] /= image_meta['scales'][0]
-    if 'padding' in image_meta:
-        boxes[:, [0, 2]] -= image_meta['padding'][2]
-        boxes[:, [1, 3]] -= image_meta['padding'][0]
-    if 'crops' in image_meta:
-        boxes[:, [0, 2]] += image_meta['crops'][2]
-        boxes[:, [1, 3]] += image_meta['crops'][0]
+        sy, sx = image_meta['scales'][0], image_meta['scales'][1]
+        xs /= sx
+        ys /= sy
+    for key, sign in (('padding', -1.0), ('crops', 1.0)):
+        if key in image_meta:
+            top, left = image_meta[key][0], image_meta[key][2]
+            xs += sign * left
+            ys += sign * top
     if image_meta.get('flipped', False):
-        width = image_meta['drifted_size'][1] if 'drifted_size' in image_meta else image_meta['orig_size'][1]
-        bw = boxes[:, 2] - boxes[:, 0] + 1.
-        boxes[:, 0] = width - 1 - boxes[:, 2]
-        boxes[:, 2] = boxes[:, 0] + bw - 1.
+        size = image_meta['drifted_size'] if 'drifted_size' in image_meta else image_meta['orig_size']
+        extent = boxes[:, 2] - boxes[:, 0] + 1.
+        boxes[:, 0] = size[1] - 1 - boxes[:, 2]
+        boxes[:, 2] = boxes[:, 0] + extent - 1.
     if 'drifts' in image_meta:
-        boxes[:, [0, 2]] += image_meta['drifts'][1]
-        boxes[:, [1, 3]] += image_meta['drifts'][0]
+        dy, dx = image_meta['drifts'][0], image_meta['drifts'][1]
+        xs += dx
+        ys += dy
     return boxes

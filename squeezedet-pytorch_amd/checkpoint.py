@@ -81,14 +81,37 @@ def save_model(model, path, epoch):
     torch.save({'epoch': epoch, 'state_dict': _unwrap(model).state_dict()}, path)
 
 
-def _is_rank0():
+def _dist():
     import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def _is_rank0():
+    d = _dist()
+    return d is None or d.get_rank() == 0
+
+
+def _rng_state_here():
+    """This process's random streams: the CPU generator and the generator of the GPU it computes on."""
+    st = {'torch': torch.get_rng_state()}
+    if torch.cuda.is_available():
+        st['cuda'] = torch.cuda.get_rng_state(torch.cuda.current_device())
+    return st
 
 
 def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, rng=True, extra=None):
     """Reference-compatible file plus optimizer / scheduler / RNG state.  Tensors are moved to the CPU; written
-    atomically (tmp + rename) by rank 0 only."""
+    atomically (tmp + rename) by rank 0.  With a process group EVERY rank must call this (it is a collective): the
+    random streams differ per rank (dropout masks), so each rank's state is gathered into the file."""
+    d = _dist()
+    rng_states = None
+    if rng:
+        mine = _rng_state_here()
+        if d is not None and d.get_world_size() > 1:
+            rng_states = [None] * d.get_world_size() if d.get_rank() == 0 else None
+            d.gather_object(mine, rng_states, dst=0)
+        else:
+            rng_states = [mine]
     if not _is_rank0():
         return
     data = {'epoch': epoch,
@@ -98,8 +121,7 @@ def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, rng
     if lr_scheduler is not None:
         data['lr_scheduler'] = lr_scheduler.state_dict()
     if rng:
-        data['rng'] = {'torch': torch.get_rng_state(),
-                       'cuda': torch.cuda.get_rng_state_all() if torch.cuda.is_available() else []}
+        data['rng'] = {'per_rank': rng_states}
     if extra:
         data['extra'] = extra
     tmp = path + '.tmp'
@@ -108,19 +130,30 @@ def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, rng
 
 
 def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, restore_rng=True, verbose=False):
-    """Inverse of ``save_checkpoint``; also accepts plain reference checkpoints (then only the weights and the
-    epoch come back).  Returns the epoch stored in the file."""
+    """Inverse of ``save_checkpoint`` (every rank reads the file and takes ITS random streams back); also accepts plain
+    reference checkpoints (then only the weights and the epoch come back).  Returns the epoch stored in the file."""
+    import warnings
     ckpt = torch.load(path, map_location='cpu', weights_only=False)
-    state_dict, _ = _reconcile(model, _strip_module_prefix(ckpt['state_dict']), verbose)
-    _unwrap(model).load_state_dict(state_dict, strict=False)
+    target = _unwrap(model)
+    state_dict, _ = _reconcile(target, _strip_module_prefix(ckpt['state_dict']), verbose)
+    target.load_state_dict(state_dict, strict=False)
     if optimizer is not None and 'optimizer' in ckpt:
         optimizer.load_state_dict(ckpt['optimizer'])            # torch casts the state to each parameter's device
     if lr_scheduler is not None and 'lr_scheduler' in ckpt:
         lr_scheduler.load_state_dict(ckpt['lr_scheduler'])
     if restore_rng and 'rng' in ckpt:
-        torch.set_rng_state(ckpt['rng']['torch'])
-        if torch.cuda.is_available() and ckpt['rng']['cuda']:
-            states = ckpt['rng']['cuda']
-            if len(states) == torch.cuda.device_count():
-                torch.cuda.set_rng_state_all(states)
+        d = _dist()
+        rank = d.get_rank() if d is not None else 0
+        world = d.get_world_size() if d is not None else 1
+        states = ckpt['rng'].get('per_rank')
+        if states is None:                                      # files written before the per-rank format
+            cuda = ckpt['rng'].get('cuda') or []
+            states = [{'torch': ckpt['rng']['torch'], **({'cuda': cuda[0]} if len(cuda) else {})}]
+        if len(states) != world:
+            warnings.warn(f'checkpoint holds the random streams of {len(states)} rank(s), this job has {world}: '
+                          f'rank {rank} resumes from stream {rank % len(states)} (not an exact resume)')
+        st = states[rank % len(states)]
+        torch.set_rng_state(st['torch'])
+        if torch.cuda.is_available() and 'cuda' in st:
+            torch.cuda.set_rng_state(st['cuda'], torch.cuda.current_device())
     return ckpt['epoch']

@@ -8,12 +8,12 @@
 //
 // pred is [B][A][C+5] fp32 (anchor-major: C class logits, 1 confidence logit, 4 deltas), anchors
 // [A][4] (cx,cy,w,h) fp32.  The reference runs ~15 elementwise launches plus a Python loop with
-// >=10 host syncs per image; here two launches do everything on the device for the whole batch:
-//   1. score_keys_kernel (whole chip): score = max_c softmax_c * sigmoid(conf) per anchor; key = fp32 score bits
-//      (non-negative floats order like uint32) if score > score_thresh else 0,
-//   2. select_nms_kernel (one workgroup per image): stable compaction of the non-zero keys into LDS, 4-pass
-//      8-bit radix select of the K-th largest; ties at that key taken in ascending anchor order (the build's
-//      documented tie rule),
+// >=10 host syncs per image; here ONE launch (detect_kernel) does everything on the device for the whole batch:
+//   1. every workgroup scores one slice of one image (the whole chip works on this phase): score = max_c softmax_c *
+//      sigmoid(conf) per anchor; key = fp32 score bits (non-negative floats order like uint32) if score > score_thresh
+//      else 0; the LAST workgroup of an image to finish (device-scope counter) carries on alone with that image:
+//   2. stable compaction of the non-zero keys into LDS, 4-pass 8-bit radix select of the K-th largest; ties at that
+//      key taken in ascending anchor order (the build's documented tie rule),
 //   3. one wave ranks the <=64 candidates (score desc, anchor index asc), decodes their boxes,
 //      builds the 64x64 suppression bit matrix (one 64-bit row per lane) and runs greedy NMS with
 //      a wave-uniform alive mask; survivors are compacted in class order 0..C-1, each class in
@@ -135,10 +135,13 @@ extern "C" int sqd_resolve_fwd(const float* pred, const float* anchors, float* p
 }
 
 // ---- fused detection ----
-// Two launches on the stream: (1) score_keys_kernel spreads the per-anchor scoring (4 exp + 2 div each) over
-// the whole chip and writes one uint32 key per anchor -- the fp32 score bits if score > score_thresh, else 0;
-// (2) select_nms_kernel, one workgroup per image, compacts the non-zero keys (stable, ascending anchor index),
-// selects the top K, ranks them, runs class-wise NMS and writes the compact result.
+// One launch of B x S workgroups.  Phase 1 spreads the per-anchor scoring (4 exp + 2 div each) over the whole chip:
+// workgroup (b, s) writes one uint32 key per anchor of its slice -- the fp32 score bits if score > score_thresh, else 0 --
+// then publishes them (device-scope fence) and bumps the image's arrival counter.  The workgroup that observes the
+// count S - 1 is the last one of image b: it acquires the other slices' keys and runs phase 2 for that image alone --
+// compacts the non-zero keys (stable, ascending anchor index), selects the top K, ranks them, runs class-wise NMS and
+// writes the compact result.  The counters live behind the keys in the workspace, start at zero and are reset by the
+// workgroup that consumed them, so the workspace is reusable launch after launch (and across hipGraph replays).
 // Why pre-filtering by the threshold is exact: Detector.filter thresholds AFTER NMS, but a box at or below the
 // threshold can only suppress boxes with lower scores, which are dropped by the same threshold -- so the kept set
 // is that of NMS over the top-K of the above-threshold anchors.
@@ -148,38 +151,55 @@ extern "C" int sqd_resolve_fwd(const float* pred, const float* anchors, float* p
 struct DetArgs {
   const float* pred; const float* anchors; const float* scales;   // scales [B][2] = (sy, sx) or null
   const long long* in_class; const float* in_score; const float* in_box;   // dense inputs (filter mode) or null
-  unsigned* keys;                                                 // workspace [B][A]
+  unsigned* keys;                                                 // workspace [B][A] keys + [B] arrival counters (zero between launches)
+  int S, per;                                                     // scoring slices per image, anchors per slice
   int* det_count; long long* det_class; float* det_score; float* det_box; int* det_anchor;
   int B, A, C, K;
   float wmax, hmax, nms_thresh, score_thresh;
 };
 
-__global__ __launch_bounds__(256) void score_keys_kernel(DetArgs a) {
-  const long long total = (long long)a.B * a.A;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    float s; int c;
-    if (a.in_score) s = a.in_score[i];
-    else anchor_score(a.pred + i * (a.C + 5), a.C, s, c);
-    a.keys[i] = (s > a.score_thresh) ? __float_as_uint(s) : 0u;   // scores are >= 0: bit patterns order like the floats
-  }
-}
-
-__global__ __launch_bounds__(DET_THREADS) void select_nms_kernel(DetArgs a) {
+__global__ __launch_bounds__(DET_THREADS) void detect_kernel(DetArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* keysL = (unsigned*)smem_raw;                      // [A4] all keys of this image (A rounded up to 4)
   unsigned short* cidx = (unsigned short*)(smem_raw + (size_t)((a.A + 3) & ~3) * 4);   // [A] candidate anchor indices
   __shared__ unsigned hist[256];
-  __shared__ unsigned s_prefix, s_need, s_cnt;
+  __shared__ unsigned s_prefix, s_need, s_cnt, s_last;
   __shared__ unsigned wave_tot[DET_THREADS / 64];
   __shared__ unsigned cand_key[DET_K];
   __shared__ int cand_idx[DET_K];
   __shared__ int sorted_pos[DET_K];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x, A = a.A, C = a.C, K = a.K;
+  const int b = (int)blockIdx.x / a.S, slice = (int)blockIdx.x - b * a.S;
+  const int A = a.A, C = a.C, K = a.K;
   const float* pred = a.pred ? a.pred + (long long)b * A * (C + 5) : nullptr;
-  const unsigned* keys = a.keys + (long long)b * A;
+  unsigned* keys = a.keys + (long long)b * A;
   const bool dense = a.in_score != nullptr;
+
+  // 1. score this workgroup's slice of the image
+  {
+    const int lo = slice * a.per, hi = min(A, lo + a.per);
+    for (int i = lo + tid; i < hi; i += DET_THREADS) {
+      float s; int c;
+      if (dense) s = a.in_score[(long long)b * A + i];
+      else anchor_score(pred + (long long)i * (C + 5), C, s, c);
+      keys[i] = (s > a.score_thresh) ? __float_as_uint(s) : 0u;   // scores are >= 0: bit patterns order like the floats
+    }
+  }
+  // publish the slice, count the arrival; only the last workgroup of the image continues.  Release: every thread's key
+  // stores are made visible device-wide (other XCDs' L2s included) before the counter moves; acquire on the other side.
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    unsigned* counter = a.keys + (long long)a.B * A + b;
+    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old == (unsigned)(a.S - 1)) ? 1u : 0u;
+    if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+
   // 0. all keys of the image -> LDS, coalesced (16-byte loads when the row is 16-byte aligned)
   if ((((long long)b * A) & 3) == 0) {
     const uint4* k4 = (const uint4*)keys;
@@ -366,18 +386,22 @@ static int launch_detect(DetArgs a, hipStream_t stream) {
   if (a.A > 65535 || lds > 150 * 1024) return SQD_ERR_UNSUPPORTED;        // A <= 25600 anchors per image
   static size_t lds_enabled = 48 * 1024;                                   // raise the dynamic-LDS cap once per size class
   if (lds > lds_enabled) {
-    if (hipFuncSetAttribute((const void*)select_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
       return SQD_ERR_LAUNCH;
     lds_enabled = 150 * 1024;
   }
-  const long long total = (long long)a.B * a.A;
-  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(score_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(select_nms_kernel, dim3((unsigned)a.B), dim3(DET_THREADS), lds, stream, a);
+  // scoring slices per image: about 1024 workgroups in all (the phase is exp / divide bound), at most 64 per image
+  int S = (1024 + a.B - 1) / a.B;
+  if (S > 64) S = 64;
+  if (S > (a.A + 255) / 256) S = (a.A + 255) / 256;
+  if (S < 1) S = 1;
+  a.S = S; a.per = (a.A + S - 1) / S;
+  hipLaunchKernelGGL(detect_kernel, dim3((unsigned)(a.B * S)), dim3(DET_THREADS), lds, stream, a);
   return sqd_launch_status();
 }
 
-// Fused decode + Detector.filter for a batch, straight from pred.  keys_ws: B*A uint32 workspace.  Outputs are fixed-capacity
+// Fused decode + Detector.filter for a batch, straight from pred.  keys_ws: (B*A + B) uint32 workspace whose last B words
+// (arrival counters) are zero before the first call; the kernel leaves them zero.  Outputs are fixed-capacity
 // [B][K]; rows >= det_count[b] are left untouched.  scales ([B][2] = (sy,sx), may be null) folds
 // boxes_postprocess' division into the store.
 extern "C" int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, unsigned* keys_ws, int* det_count,

@@ -639,8 +639,14 @@ def _det_buffers(B, K, device, A=None):
             torch.zeros(B, K, device=device, dtype=torch.float32), torch.zeros(B, K, 4, device=device, dtype=torch.float32),
             torch.zeros(B, K, device=device, dtype=torch.int32))
     if A is not None:
-        bufs = bufs + (torch.empty(B * A, device=device, dtype=torch.int32),)
+        bufs = bufs + (_det_workspace(B, A, device),)
     return bufs
+
+
+def _det_workspace(B, A, device):
+    """Score keys [B*A] followed by the per-image arrival counters [B] of the one-launch detect kernel: zeroed once, the
+    kernel leaves the counters zero, so the buffer is reusable (also across hipGraph replays)."""
+    return torch.zeros(B * A + B, device=device, dtype=torch.int32)
 
 
 def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3, scales=None, out=None):
@@ -656,10 +662,10 @@ def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4
         raise ValueError('detect: scales must be fp32 [B,2] (sy, sx)')
     bufs = out if out is not None else _det_buffers(B, keep_top_k, pred.device, A)
     if len(bufs) == 5:
-        bufs = tuple(bufs) + (torch.empty(B * A, device=pred.device, dtype=torch.int32),)
+        bufs = tuple(bufs) + (_det_workspace(B, A, pred.device),)
     cnt, cls, sc, bx, idx, keys = bufs
-    if keys.numel() < B * A or keys.dtype != torch.int32 or keys.device != pred.device:
-        raise ValueError('detect: keys workspace must be int32 with at least B*A elements')
+    if keys.numel() != B * A + B or keys.dtype != torch.int32 or keys.device != pred.device or not keys.is_contiguous():
+        raise ValueError('detect: workspace must be the int32 [B*A + B] buffer of _det_workspace (zero-initialised counters)')
     br = _Bracket('detect', f'detect A{A}', 0.0, 4.0 * B * A * (num_classes + 5)) if _timer is not None else None
     rc = nat.lib().sqd_detect_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(keys), nat.ptr(cnt), nat.ptr(cls),
                                   nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes, int(input_size[0]),

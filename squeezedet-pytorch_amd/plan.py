@@ -1,0 +1,62 @@
+"""The launch plan of one inference step, computed on the host WITHOUT a GPU: which kernel instance (tile
+configuration from the measured table ``tuning.json``) every layer of ``SqueezeDetBase.forward`` + the fused detect
+launches for a given architecture / batch / input size.  It mirrors the decisions of ``autograd.run_backbone_forward``
+(a GPU test asserts the two agree launch for launch) and exists so that profiles can be checked against the code that
+shipped: ``profiles/traffic.json`` records the launch set it was measured on, and a CPU test recomputes that set here.
+
+Reference for the layer sequence: src/model/squeezedet.py:33-87, src/engine/detector.py:20-50.
+"""
+from __future__ import annotations
+
+from collections import Counter
+
+from . import ops
+from .synthetic import convdet_in_channels, layer_table
+
+
+def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
+                          use_winograd=True, fuse_expand=True):
+    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order."""
+    layers = layer_table(arch)
+    H, W = ops.stem_out_size(input_size[0], input_size[1], layers[0][3])
+    C = layers[0][2]
+    plan = []
+    first = 2
+    if layers[2][0] == 'pool':
+        plan.append((f'stem_pool<{layers[0][3]}>', f'stem+pool {input_size[0]}x{input_size[1]}'))
+        H, W = ops.pool_out_size(H, W)
+        first = 3
+    else:
+        plan.append((f'stem_conv<{layers[0][3]}>', f'stem {input_size[0]}x{input_size[1]}'))
+
+    def conv3x3(Cin, N):
+        npix = batch * H * W
+        wc = ops.choose_wino_cfg(Cin, N, npix) if use_winograd else None
+        if wc is not None:
+            bn, wv = ops.wino_cfgs()[wc % 1000]
+            return (f'conv_wino<{bn // 16},{wv}>', f'9tap C{Cin} N{N} {H}x{W}')
+        return (ops.cfg_kernel_name(ops.choose_cfg(9, Cin, N, npix)), f'9tap C{Cin} N{N} {H}x{W}')
+
+    for l in layers[first:]:
+        if l[0] == 'pool':
+            plan.append(('maxpool_fwd', f'pool C{C} {H}x{W}'))
+            H, W = ops.pool_out_size(H, W)
+            continue
+        _, cin, s, e1, e3 = l
+        npix = batch * H * W
+        plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, cin, s, npix)), f'1tap C{cin} N{s} {H}x{W}'))
+        fcfg = ops.choose_fused_cfg(s, e1, npix) if (fuse_expand and e1 == e3) else None
+        if fcfg is not None:
+            plan.append((ops.cfg_kernel_name(fcfg).replace('conv_dma', 'fire_expand'), f'expand C{s} E{e1} {H}x{W}'))
+        else:
+            plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, s, e1, npix)), f'1tap C{s} N{e1} {H}x{W}'))
+            plan.append(conv3x3(s, e3))
+        C = e1 + e3
+    plan.append(conv3x3(convdet_in_channels(arch), anchors_per_grid * (num_classes + 5)))
+    plan.append(('detect', f'detect A{H * W * anchors_per_grid}'))
+    return plan
+
+
+def launches_per_kernel(plan):
+    """{kernel name: launches per step}."""
+    return dict(Counter(name for name, _ in plan))

@@ -139,3 +139,46 @@ def test_exact_resume_squeezedet_training_gpu(tmp_path):
     tail2 = [step(cfg2, m2, opt2, sched2, it) for it in range(2, 4)]
     assert tail == tail2                                                         # bitwise: same losses ...
     assert all(torch.equal(a, b) for a, b in zip(want, m2.state_dict().values()))   # ... and same weights
+
+
+def _resume_worker(rank, world, port, path, out_dir):
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from squeezedet_pytorch_amd import checkpoint as ckp
+    torch.manual_seed(100 + rank)                                   # every rank its own dropout stream
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Dropout(0.5))
+
+    class Wrapped(torch.nn.Module):                                  # a `.module` wrapper like (Distributed)DataParallel
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+    torch.rand(3)                                                    # advance the stream a little
+    ckp.save_checkpoint(path, Wrapped(net), epoch=3)                 # collective: every rank calls it
+    want = torch.rand(8)                                             # what an uninterrupted run draws next
+    torch.manual_seed(999)                                           # "restart": streams are somewhere else entirely
+    net2 = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Dropout(0.5))
+    dist.barrier()
+    assert ckp.load_checkpoint(path, Wrapped(net2)) == 3
+    got = torch.rand(8)
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values())) or rank != 0
+    torch.save({'want': want, 'got': got}, os.path.join(out_dir, f'r{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_resume_restores_each_ranks_random_stream(tmp_path):
+    """Multi-process resume: save_checkpoint gathers every rank's RNG state, load_checkpoint hands each rank ITS stream
+    back (rank 1 must not continue with rank 0's dropout masks); weights load into ``.module`` wrappers."""
+    import torch.multiprocessing as mp
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    path = str(tmp_path / 'dp_resume.pth')
+    mp.spawn(_resume_worker, args=(world, port, path, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(str(tmp_path / 'r0.pt')); r1 = torch.load(str(tmp_path / 'r1.pt'))
+    assert torch.equal(r0['want'], r0['got']) and torch.equal(r1['want'], r1['got'])
+    assert not torch.equal(r0['got'], r1['got'])
+    ckpt = torch.load(path, weights_only=False)
+    assert len(ckpt['rng']['per_rank']) == 2 and set(ckpt['state_dict']) == {'0.weight', '0.bias'}

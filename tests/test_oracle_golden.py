@@ -197,3 +197,19 @@ def test_train_step_small(golden_dir):
     np.testing.assert_allclose(grads["base.features.0.weight"].numpy() * coef, g["stem_w_grad"], rtol=1e-2, atol=1e-6)
     ps = np.array([float(new_p[k].double().abs().sum()) for k in names])
     np.testing.assert_allclose(ps, g["new_param_abs"], rtol=1e-5)
+
+
+def test_boxes_postprocess_vs_reference_golden(golden_dir):
+    """Host-side box un-mapping (src/utils/boxes.py:138-168), all 64 combinations of the image_meta keys: bit-equal to the
+    reference's own outputs (tests/golden/make_golden_postprocess.py); the oracle's eval-path subset agrees where it applies."""
+    g = load(golden_dir, "boxes_postprocess.npz")
+    keys = ('orig_size', 'scales', 'padding', 'crops', 'flipped', 'drifted_size', 'drifts')
+    for n in range(int(g['n'])):
+        meta = {k: g[f'meta{n}_{k}'] for k in keys if f'meta{n}_{k}' in g.files}
+        meta['flipped'] = bool(meta['flipped'])
+        boxes = g[f'in{n}'].copy()
+        out = sqd.boxes.boxes_postprocess(boxes, meta)
+        assert out is boxes                                   # in place, like the reference
+        assert np.array_equal(out, g[f'out{n}']), (n, sorted(meta))
+        if set(meta) <= {'orig_size', 'scales', 'flipped'} and not meta['flipped'] and 'scales' in meta:
+            assert np.array_equal(oracle.boxes_postprocess(g[f'in{n}'].copy(), meta['scales']), g[f'out{n}'])
