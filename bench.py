@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle leg (baseline timing + parity check)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
+    ap.add_argument('--layers', action='store_true', help='add per-layer (kernel, shape) event times to the line')
     ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even at N=1 (exercises the RCCL path on one GPU)')
     return ap.parse_args()
 
@@ -373,6 +374,7 @@ def main():
             'workload': (f'SqueezeDet KITTI 1248x384 bs={B} inference on {where} (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
                          else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on {where}'),
             'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
+            'layers': {f'{k} | {tag}': round(t[1] * 1e3, 1) for k, v in summ.items() for tag, t in v['tags'].items()},      # us per step
             'whole_network': {'tflops': round(value * gf / 1e3, 2),
                               'frac_of_fp32_mfma_peak': round(value / joined * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                               'note': 'direct-form flops of the network; layers run by the Winograd kernel execute 2.25x fewer'},
@@ -409,12 +411,14 @@ def main():
             'value': round(B * joined * args.steps / elapsed, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4), 'timed_with': how,
             'repeat_window_ms_per_step': round(repeat / args.steps * 1e3, 4),
             'workload': describe, 'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
+            'layers': {f'{k} | {tag}': round(t[1] * 1e3, 1) for k, v in summ.items() for tag, t in v['tags'].items()},
         }
 
     if rank == 0:
         cpu = parity = None
         if joined == 1 and not args.no_cpu_baseline and args.mode != 'train':
             cpu, parity = cpu_baseline_and_parity(cfg, sd, B, hip_pred, hip_det, train_probe)
+        layer_detail = {m: r.pop('layers', None) for m, r in result.items()}
         head = result['infer'] if 'infer' in result else result['train']
         what = 'inference' if 'infer' in result else 'training'
         line = {
@@ -432,6 +436,8 @@ def main():
         }
         if 'eager_steps_launched' in head:
             line['eager_steps_launched'] = head['eager_steps_launched']
+        if args.layers:
+            line['layers'] = layer_detail
         if args.mode == 'both':
             line['train'] = result['train']
         print(json.dumps(line))

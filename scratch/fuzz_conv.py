@@ -62,7 +62,7 @@ while time.time() - t0 < budget:
         n_ok += 1
     # Winograd form of the same 3x3 layer (C % 8 == 0), same windows; the epilogue options need y's own geometry
     if taps == 9 and C % 8 == 0:
-        wc = int(rs.choice(list(ops.wino_cfgs()))) + 1000 * int(rs.choice([0, 0, 1]))
+        wc = int(rs.choice([c for c in ops.wino_cfgs() if ops.wino_cfg_ok(c, C) and ops.wino_cfg_ok(c, N)])) + 1000 * int(rs.choice([0, 0, 1]))
         wmode = int(rs.randint(0, 4)); wrelu = bool(rs.randint(0, 2))
         yw = y0.clone().cuda(); wkw = {}; wref = nhwc(ref)
         if wmode in (1, 3):

@@ -14,7 +14,7 @@ import threading
 import torch  # noqa: F401  (loads the process-wide HIP runtime, libamdhip64.so.7, before our library)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-_LIB_PATH = os.path.join(_CSRC, 'libsqdhip.so')
+_LIB_PATH = os.environ.get('SQD_HIP_LIBRARY') or os.path.join(_CSRC, 'libsqdhip.so')     # (override: A/B builds of the same ABI)
 _lock = threading.Lock()
 _lib = None
 

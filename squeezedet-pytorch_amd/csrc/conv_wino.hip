@@ -28,6 +28,20 @@
 // of a slice is a set of contiguous runs (sqd_pack_wino_weight; host: ops.WinoPlan).
 #include "sqd_common.h"
 #include <type_traits>
+#ifndef SQD_WINO_DIAG
+#define SQD_WINO_DIAG 0           /* ablation builds only (scratch/diag/build_wino_diag.sh): bit 0 = no MFMA, 1 = no input transform,
+                                     2 = no DMA inside the chunk loop, 3 = no output stores.  0 in the product library. */
+#endif
+#ifndef SQD_WINO_DMA_STEPS
+#define SQD_WINO_DMA_STEPS 8      /* the next stage's DMA instructions are spread over the first this-many of the 8 MFMA steps.
+                                     4 (+ SQD_WINO_U_FIRST) measured 7-12 % faster with each layer timed in a loop of its own
+                                     (profiles/r02c_wino_dma_timing.log) but 1 % SLOWER inside the network (A/B of the whole
+                                     step in one process, profiles/r02f_ab_uf4.log): 8 / 0 stay the defaults */
+#endif
+#ifndef SQD_WINO_U_FIRST
+#define SQD_WINO_U_FIRST 0        /* 1: the next stage's U slice is requested right behind the stage barrier (its buffer is free from
+                                     there on), ahead of the input transform; only the patch refill waits for the transform's reads */
+#endif
 #ifndef SQD_WINO_DMA_EARLY
 #define SQD_WINO_DMA_EARLY 0      /* 1: issue the whole next stage at the first MFMA step -- measured 5-8 % slower than spreading it */
 #endif
@@ -203,6 +217,9 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       const f32x4 m = *(const f32x4*)mask;
       v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
     }
+#if SQD_WINO_DIAG & 8
+    if (v.x == 123.456f)
+#endif
     *(f32x4*)dst = wino_relu4(v, relu_lo);
   };
   auto flush = [&](const GPos gp) {
@@ -251,9 +268,17 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       // whose per-lane offsets replace this group's now (its own last stage is already in LDS)
       if (last) group_offsets(nxt);
       const unsigned nsoff = (last ? nxt.soff : cur.soff) + (unsigned)ncc * 32u;
+#if SQD_WINO_U_FIRST
+#pragma unroll
+      for (int it = 0; it < U_IT; ++it) dma_u_one(it, ncc, ubuf ^ 1);
+#endif
 
       // ---- input transform: V = B^T d B for (tile tt, channels 2cp, 2cp+1) ----
       f32x2 vv[16];                          // V[pos] for (tile lr, channels 2g, 2g+1): this lane's B operands of the chunk
+#if SQD_WINO_DIAG & 2
+#pragma unroll
+      for (int i = 0; i < 16; ++i) vv[i] = (f32x2){(float)(lane + i + cc), 1.f};
+#else
       {
         f32x2 t[4][4];
 #pragma unroll
@@ -268,6 +293,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
           vv[i * 4 + 2] = t[i][2] - t[i][1]; vv[i * 4 + 3] = t[i][1] - t[i][3];
         }
       }
+#endif
       // The patch buffer is refilled (LDS-DMA, below) for the next chunk: its reads above must have returned, and neither
       // the compiler nor the machine scheduler may move a DMA issue across this point (the DMA's LDS side is invisible to
       // them).
@@ -292,7 +318,12 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const f32x4 c0v = (FIRST && t == 0) ? ((p == 5) ? biasv[j] : (f32x4){0.f, 0.f, 0.f, 0.f}) : acc[p][j];
+#if SQD_WINO_DIAG & 1
+            asm volatile("" ::"v"(afr[j][2 * h + t]), "v"(vv[p][t]));      // operands materialised, no matrix instruction
+            acc[p][j] = c0v;
+#else
             acc[p][j] = mfma16(afr[j][2 * h + t], vv[p][t], c0v);
+#endif
           }
       };
       f32x4 af0[NT], af1[NT];
@@ -300,8 +331,9 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 #pragma unroll
       for (int step = 0; step < NSTEP; ++step) {
 #pragma unroll
-        for (int q = 0; q < NDMA; ++q) {
-          if (((SQD_WINO_DMA_EARLY) ? 0 : q * NSTEP / NDMA) != step) continue;
+        for (int q = 0; q < (SQD_WINO_U_FIRST ? RAW_IT : NDMA); ++q) {
+          if (((SQD_WINO_DMA_EARLY) ? 0 : q * (SQD_WINO_DMA_STEPS) / (SQD_WINO_U_FIRST ? RAW_IT : NDMA)) != step) continue;
+          if (SQD_WINO_DIAG & 4) continue;
           if (q < RAW_IT) dma_raw_one(q < RAW_IT ? q : 0, nsoff);
           else dma_u_one(q - RAW_IT, ncc, ubuf ^ 1);
         }
@@ -369,6 +401,365 @@ static int wino_num_cus() {
     if (cus <= 0) cus = 256;
   }
   return cus;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Deep-prefetch variant (cfg ids 4..7): the same decomposition and arithmetic (bit-identical results), but the staging
+// runs TWO K chunks ahead of the matrix work instead of one.  Measured on the kernel above (scratch/diag/run_wino_diag.py,
+// profiles/r02c_wino_ablation.log): with the MFMAs compiled out a chunk still takes 1.3-2.2 us -- one memory round trip
+// of the LDS-DMA under load -- against 0.85-1.7 us of matrix work per chunk, so with a prefetch distance of one chunk
+// every stage barrier waits for memory.  Here:
+//   * U lives in a ring of THREE buffers, the wave-private raw patch in a ring of TWO; chunk k+2 is requested while
+//     chunk k is multiplied: its U slice right behind the stage barrier (U[(k+2)%3] = U[(k-1)%3] is free from there on),
+//     its patch as soon as the transform has read chunk k's (same buffer);
+//   * the stage wait is a COUNTED s_waitcnt vmcnt(N) that leaves the younger chunk's DMA (and a finished tile's stores)
+//     in flight -- vector-memory operations retire in issue order (MI355X_MICROARCH.md) -- and the stage barrier is a raw
+//     s_barrier (a __syncthreads() would drain the DMA queue with vmcnt(0));
+//   * the LDS for the extra buffers comes from dropping the output parking area: a finished tile is inverse-transformed
+//     and stored straight from registers behind its last chunk; with counted waits those stores never block a stage.
+// 4 waves x (2 x 4 KB patch) + 3 x 16 KB U = 80 KB: still two workgroups per CU.
+// USTAT = true (cfg ids 8..11, layers with C <= 64): the slice's WHOLE transformed weight set (C/8 chunks) is fetched into LDS
+// once per workgroup and stays there, so the chunk loop needs neither U requests nor a workgroup barrier -- the patch ring
+// is wave-private -- and the waves of a workgroup run free of each other: the transform of one overlaps the matrix work
+// of its SIMD neighbour instead of all waves meeting at a barrier 2..8 times per tile.
+template <int NT, int WV, bool USTAT>
+__global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wino_pipe_kernel(WinoArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NTHR = WV * 64;
+  constexpr int BN = 16 * NT;
+  constexpr int RP = 113;
+  constexpr int RAW_IT = 4;
+  constexpr int USLOTS = 32 * BN;
+  static_assert(USLOTS % NTHR == 0, "U slice must be whole workgroup passes");
+  constexpr int U_IT = USLOTS / NTHR;
+  constexpr int NDMA = RAW_IT + (USTAT ? 0 : U_IT);      // DMA instructions per wave and chunk
+  constexpr int NST = 4 * NT;                 // store instructions of a whole tile's plain epilogue
+  constexpr int NSTEP = 8;
+  constexpr int RAW_STEPS = 4;                // the patch refill is spread over the first MFMA steps
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const rawB = smem;                                 // [2][WV][256][4]
+  float* const UB = rawB + 2 * WV * 256 * 4;                // [3][USLOTS][4] ring, or (USTAT) [C/8][USLOTS][4] resident
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int wgq = (int)blockIdx.x >> 3;
+  const int n0 = (wgq % a.nslices) * BN;
+  const int tstride = a.gx;
+  const int nchunks = a.C >> 3;
+  const int ntiles = a.ntiles;
+  int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
+  if (tile >= ntiles) return;
+  const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+
+  constexpr unsigned OOB = 0x80000000u;
+  int r_offB[RAW_IT], r_key[RAW_IT];
+#pragma unroll
+  for (int it = 0; it < RAW_IT; ++it) {
+    const int slot = it * 64 + lane;
+    const int kq = slot / RP, pix = slot - kq * RP;
+    const bool real = kq < 2 && pix < 108;
+    const int r = pix / 18, c = pix - r * 18;
+    r_key[it] = real ? (r << 8 | c) : -1;
+    r_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * kq) * 4 : 0;
+  }
+  int u_offB[U_IT];
+#pragma unroll
+  for (int it = 0; it < U_IT; ++it) {
+    const int slot = it * NTHR + tid;
+    const int pp = slot / (4 * BN), rem = slot - pp * (4 * BN);
+    u_offB[it] = ((pp * a.Npad + n0) * 16 + rem * 4) * 4;
+  }
+  const unsigned u_chunkB = 16u * a.Npad * 8u * 4u;
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + a.x_coff - (long long)(a.W + 1) * a.x_pitch), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, 0x7ffffff0, 0x00020000);
+
+  struct GPos { int y0, x0, inner, valid; long long p0; unsigned soff; };
+  auto group_pos = [&](int t) {
+    GPos gp;
+    int q = t * WV + wv_s;
+    gp.valid = (int)((unsigned)(q - a.ngroups) >> 31);
+    q = gp.valid ? q : a.ngroups - 1;
+    const int gxi = q % a.gxn; q /= a.gxn;
+    const int gyi = q % a.gyn; const int b = q / a.gyn;
+    gp.y0 = gyi * 4; gp.x0 = gxi * 16;
+    gp.p0 = ((long long)b * a.H + gp.y0) * a.W + gp.x0;
+    gp.soff = (unsigned)(gp.p0 * a.x_pitch * 4);
+    gp.inner = (int)(((unsigned)(-gp.y0) & (unsigned)(gp.y0 + 4 - a.H) & (unsigned)(-gp.x0) & (unsigned)(gp.x0 + 16 - a.W)) >> 31);
+    return gp;
+  };
+  int r_offG[RAW_IT];                                        // per-lane patch offsets of the group at the PREFETCH cursor
+  auto group_offsets = [&](int y0, int x0, int inner) {
+    if (inner) {
+#pragma unroll
+      for (int it = 0; it < RAW_IT; ++it) r_offG[it] = r_offB[it];
+      return;
+    }
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+      const int key = r_key[it];
+      const bool ok = key >= 0 && (unsigned)(y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(x0 + (key & 255) - 1) < (unsigned)a.W;
+      r_offG[it] = ok ? r_offB[it] : (int)OOB;
+    }
+  };
+  float* const rawW = rawB + wv_s * 256 * 4;                 // this wave's patch buffer 0 (buffer 1: + WV*256*4 floats)
+  auto dma_raw_one = [&](int it, unsigned soff, int rb) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_w_t)(rawW + (rb * WV * 256 + it * 64) * 4), 16, r_offG[it], (int)soff, 0, 0);
+  };
+  auto dma_u_one = [&](int it, int cc, int ub) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ures, (lds_ptr_w_t)(UB + (ub * USLOTS + it * NTHR + wv_s * 64) * 4), 16, u_offB[it],
+                                             (int)(cc * u_chunkB), 0, 0);
+  };
+
+  f32x4 acc[16][NT];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 biasv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + 4 * g;
+    biasv[j] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int ty = lr >> 3, tx = lr & 7;
+  // output addressing through buffer resources too (base = the slice's first channel of y; wave-uniform SGPR byte offset
+  // of the tile + the lane's 32-bit byte offset + an immediate): no 64-bit per-lane address arithmetic is kept alive
+  // across the chunk loop (eight hoisted 64-bit offsets spilled the first version into scratch)
+  int o_offB[4];
+#pragma unroll
+  for (int px = 0; px < 4; ++px) o_offB[px] = (((2 * ty + (px >> 1)) * a.W + 2 * tx + (px & 1)) * a.y_pitch + 4 * g) * 4;
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff + n0), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mulres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ymul ? a.ymul + a.y_coff + n0 : a.y), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t maskres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ymask ? a.ymask + a.y_coff + n0 : a.y), 0, 0x7ffffff0, 0x00020000);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  // A 16-byte MUBUF store whose soffset is an SGPR, directly followed by a VALU write of its first data register, stored
+  // the NEW value in the last four lanes of every 16-lane row on this chip (found as rare wrong outputs, always component
+  // 0 of tile columns 12..15; the compiler only pads this write-after-read hazard when soffset is NOT a register): two
+  // wait states behind every such store, pinned in place.
+  auto store16 = [&](f32x4 v, __amdgpu_buffer_rsrc_t res, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), res, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const float relu_lo = a.relu ? 0.f : -__builtin_inff();
+  const int tt = lr, cp = g;
+  const int rawL_off = (((cp >> 1) * RP + (2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 4 + 2 * (cp & 1));
+  const float* const uR0 = UB + g * 64 + lr * 4;
+  const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
+  const bool plain_epi = !acc_i && !has_mul && !has_mask;
+
+  // ---- prefetch cursor: two chunks ahead of the compute cursor; clamps on this workgroup's last tile (the two stages
+  // requested past the end re-read its chunks 0 / 1 into idle buffers and are retired by the final vmcnt(0)) ----
+  GPos cur = group_pos(tile);
+  int ptile = tile, pcc = 0;
+  unsigned psoff = cur.soff;
+  group_offsets(cur.y0, cur.x0, cur.inner);
+  auto advance = [&]() {
+    ++pcc;
+    if (pcc == nchunks) {
+      pcc = 0;
+      ptile = (ptile + tstride < ntiles) ? ptile + tstride : ptile;
+      const GPos pf = group_pos(ptile);
+      psoff = pf.soff;
+      group_offsets(pf.y0, pf.x0, pf.inner);
+    }
+  };
+  if (USTAT) {                            // the whole slice of U, once; published by the only barrier of the kernel
+    for (int c = 0; c < nchunks; ++c)
+#pragma unroll
+      for (int it = 0; it < U_IT; ++it) dma_u_one(it, c, c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // prologue: chunks 0 and 1
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (!USTAT) {
+#pragma unroll
+      for (int it = 0; it < U_IT; ++it) dma_u_one(it, pcc, s);
+    }
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) dma_raw_one(it, psoff + (unsigned)pcc * 32u, s);
+    advance();
+  }
+  int ub = 0, rb = 0;                    // ring slots of the chunk about to be computed
+  int stores_behind = 0;                 // the previous chunk ended a tile with exactly NST stores behind its DMA requests
+
+  for (;;) {
+    const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);
+    const bool more = more_i != 0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+      // chunk k's DMA (this wave's share) has landed; chunk k+1's requests -- and a just-finished tile's stores, all younger
+      // -- stay in flight.  Vector-memory operations retire in issue order, so "all but the N youngest" is exact; when
+      // the store count of the previous chunk is not known (border tiles, read-modify-write epilogues) the smaller N is
+      // merely conservative.
+      if (__builtin_amdgcn_readfirstlane(stores_behind)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      if (!USTAT) __builtin_amdgcn_s_barrier();      // every wave's share of U[ub] is in LDS; every wave has left U[(ub+2)%3]
+      asm volatile("" ::: "memory");
+      stores_behind = 0;
+      const int last_i = 1 - (int)((unsigned)(cc + 1 - nchunks) >> 31);
+      const bool last = last_i != 0;
+      const int ub2 = (ub >= 1) ? ub - 1 : 2;                   // (ub + 2) % 3
+      // U slice of chunk k+2: its ring slot is free from the barrier on
+      if (!USTAT) {
+#pragma unroll
+        for (int it = 0; it < U_IT; ++it) dma_u_one(it, pcc, ub2);
+      }
+      const unsigned nsoff = psoff + (unsigned)pcc * 32u;
+
+      // ---- input transform of chunk k from patch buffer rb ----
+      f32x2 vv[16];
+      {
+        const float* const rawL = rawW + rb * WV * 256 * 4 + rawL_off;
+        f32x2 t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * 4), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * 4);
+          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * 4), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * 4);
+          t[0][j] = d0 - d2; t[1][j] = d1 + d2; t[2][j] = d2 - d1; t[3][j] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vv[i * 4 + 0] = t[i][0] - t[i][2]; vv[i * 4 + 1] = t[i][1] + t[i][2];
+          vv[i * 4 + 2] = t[i][2] - t[i][1]; vv[i * 4 + 3] = t[i][1] - t[i][3];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the patch reads have returned: buffer rb may be refilled
+      __builtin_amdgcn_sched_barrier(0);
+      const float* const uR = uR0 + (USTAT ? cc : ub) * USLOTS * 4;
+
+      auto load_ops = [&](int step, f32x4 (&afr)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) afr[j] = *(const f32x4*)(uR + (step * NT + j) * 256);
+      };
+      auto mfma_phase = [&](auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        auto mfma_pos = [&](int step, const f32x4 (&afr)[NT], int h) {
+          const int p = 2 * step + h;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const f32x4 c0v = (FIRST && t == 0) ? ((p == 5) ? biasv[j] : (f32x4){0.f, 0.f, 0.f, 0.f}) : acc[p][j];
+              acc[p][j] = mfma16(afr[j][2 * h + t], vv[p][t], c0v);
+            }
+        };
+        f32x4 af0[NT], af1[NT];
+        load_ops(0, af0);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+#pragma unroll
+          for (int q = 0; q < RAW_IT; ++q)
+            if (q * RAW_STEPS / RAW_IT == step) dma_raw_one(q, nsoff, rb);       // patch of chunk k+2 into the buffer just read
+          if (step & 1) {
+            mfma_pos(step, af1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < NSTEP) load_ops(step + 1, af0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_pos(step, af1, 1);
+          } else {
+            mfma_pos(step, af0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < NSTEP) load_ops(step + 1, af1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_pos(step, af0, 1);
+          }
+        }
+      };
+      if (cc == 0) mfma_phase(std::true_type{}); else mfma_phase(std::false_type{});
+      advance();                             // the prefetch cursor moves on (per-lane offsets change only at a tile switch)
+
+      if (last && cur.valid) {               // inverse transform Y = A^T M A on register pairs, stored straight away
+        const int ysoff = (int)(unsigned)(cur.p0 * a.y_pitch * 4);            // host-checked < 4 GiB
+        const bool whole = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W && n0 + BN <= a.N;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          auto inv = [&](auto half, auto put) {
+            f32x2 sx[4][2];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+              const f32x2 m0 = half(acc[xi * 4 + 0][j]), m1 = half(acc[xi * 4 + 1][j]);
+              const f32x2 m2 = half(acc[xi * 4 + 2][j]), m3 = half(acc[xi * 4 + 3][j]);
+              sx[xi][0] = m0 + m1 + m2;
+              sx[xi][1] = m1 - (m2 + m3);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              put(0 * 2 + b, sx[0][b] + sx[1][b] + sx[2][b]);
+              put(1 * 2 + b, sx[1][b] - (sx[2][b] + sx[3][b]));
+            }
+          };
+          f32x4 ov[4];
+          inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
+          inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
+          if (whole && plain_epi) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+              store16(wino_relu4(ov[px], relu_lo), yres, o_offB[px] + j * 64, ysoff);
+          } else {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+              const bool valid = cur.y0 + 2 * ty + (px >> 1) < a.H && cur.x0 + 2 * tx + (px & 1) < a.W;
+              if (!valid || n0 + j * 16 + 4 * g >= a.N) continue;
+              const int off = o_offB[px] + j * 64;
+              f32x4 v = ov[px];
+              if (acc_i) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, off, ysoff, 0));
+              if (has_mul) v *= __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mulres, off, ysoff, 0));
+              if (has_mask) {
+                const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(maskres, off, ysoff, 0));
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+              }
+              store16(wino_relu4(v, relu_lo), yres, off, ysoff);
+            }
+          }
+        }
+        stores_behind = (whole && plain_epi) ? 1 : 0;
+      }
+      ub = (ub == 2) ? 0 : ub + 1;
+      rb ^= 1;
+    }
+    if (!more) break;
+    tile += tstride;
+    cur = group_pos(tile);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may still be in flight when the LDS is released
+#endif
+}
+
+template <int NT, int WV, bool USTAT = false>
+static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
+  constexpr int BN = 16 * NT, NTHR = WV * 64;
+  constexpr size_t lds_ring = (size_t)(2 * WV * 256 * 4 + 3 * 32 * BN * 4) * sizeof(float);
+  static_assert(lds_ring <= 160 * 1024, "LDS budget");
+  // U-stationary: the patch ring + C/8 chunks of the slice's U
+  const size_t lds = USTAT ? (size_t)(2 * WV * 256 * 4 + (a.C >> 3) * 32 * BN * 4) * sizeof(float) : lds_ring;
+  if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
+  auto kern = conv_wino_pipe_kernel<NT, WV, USTAT>;
+  // 32-bit SGPR byte offset of a tile's output origin / per-lane byte offsets inside a group (buffer-resource stores)
+  if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  int nb = 0;              // occupancy depends on the (C-dependent) LDS size of the stationary variant: ask per launch
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
+  const int wgs_per_cu = nb > 4 ? 4 : nb;
+  a.gxn = sqd_cdiv(a.W, 16); a.gyn = sqd_cdiv(a.H, 4);
+  a.ngroups = a.B * a.gxn * a.gyn;
+  a.ntiles = sqd_cdiv(a.ngroups, WV);
+  const int nslices = sqd_cdiv(a.N, BN);
+  if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;
+  const int slots = wino_num_cus() * ((a.wg_cap > 0 && a.wg_cap < wgs_per_cu) ? a.wg_cap : wgs_per_cu);
+  int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
+  const int per_wg = sqd_cdiv(a.ntiles, gx_max);
+  const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;
+  a.nslices = nslices; a.gx = gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(gx * nslices)), dim3(NTHR), lds, stream, a);
+  return sqd_launch_status();
 }
 
 template <int NT, int WV>
@@ -467,7 +858,9 @@ extern "C" int sqd_pack_wino_weight(const float* w_oihw, float* u_packed, int No
 
 // Winograd configurations: cfg_id -> (channel blocks per slice NT, waves per workgroup WV)
 struct WinoCfg { int nt, wv; };
-static const WinoCfg kWinoCfgs[] = {{2, 8}, {1, 8}, {2, 4}, {1, 4}};
+// ids 4..7: the same tilings on the deep-prefetch kernel (conv_wino_pipe_kernel); 8..11: its U-stationary, barrier-free
+// form (the slice's whole U must fit the LDS next to the patch ring: C <= 64 at 32-channel slices, else "unsupported")
+static const WinoCfg kWinoCfgs[] = {{2, 8}, {1, 8}, {2, 4}, {1, 4}, {2, 8}, {1, 8}, {2, 4}, {1, 4}, {2, 8}, {1, 8}, {2, 4}, {1, 4}};
 static const int kNumWinoCfgs = (int)(sizeof(kWinoCfgs) / sizeof(kWinoCfgs[0]));
 
 extern "C" int sqd_wino_num_cfgs() { return kNumWinoCfgs; }
@@ -503,6 +896,14 @@ extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const fl
     case 1: return launch_wino<1, 8>(a, s);
     case 2: return launch_wino<2, 4>(a, s);
     case 3: return launch_wino<1, 4>(a, s);
+    case 4: return launch_wino_pipe<2, 8>(a, s);
+    case 5: return launch_wino_pipe<1, 8>(a, s);
+    case 6: return launch_wino_pipe<2, 4>(a, s);
+    case 7: return launch_wino_pipe<1, 4>(a, s);
+    case 8: return launch_wino_pipe<2, 8, true>(a, s);
+    case 9: return launch_wino_pipe<1, 8, true>(a, s);
+    case 10: return launch_wino_pipe<2, 4, true>(a, s);
+    case 11: return launch_wino_pipe<1, 4, true>(a, s);
   }
   return SQD_ERR_UNSUPPORTED;
 }

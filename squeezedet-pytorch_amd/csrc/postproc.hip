@@ -186,9 +186,10 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(DetArgs a) {
       keys[i] = (s > a.score_thresh) ? __float_as_uint(s) : 0u;   // scores are >= 0: bit patterns order like the floats
     }
   }
-  // publish the slice, count the arrival; only the last workgroup of the image continues.  Release: every thread's key
-  // stores are made visible device-wide (other XCDs' L2s included) before the counter moves; acquire on the other side.
-  __threadfence();
+  // publish the slice, count the arrival; only the last workgroup of the image continues.  The barrier orders every
+  // thread's key stores before thread 0's device-scope RELEASE (one L2 write-back per workgroup, not one per wave), which
+  // makes them visible to the other XCDs before the counter moves; the last arriver's ACQUIRE (same atomic) + the second
+  // barrier order the reads of phase 2 behind it for the whole workgroup.
   __syncthreads();
   if (tid == 0) {
     unsigned* counter = a.keys + (long long)a.B * A + b;
@@ -198,7 +199,6 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(DetArgs a) {
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
 
   // 0. all keys of the image -> LDS, coalesced (16-byte loads when the row is 16-byte aligned)
   if ((((long long)b * A) & 3) == 0) {
@@ -390,9 +390,9 @@ static int launch_detect(DetArgs a, hipStream_t stream) {
       return SQD_ERR_LAUNCH;
     lds_enabled = 150 * 1024;
   }
-  // scoring slices per image: about 1024 workgroups in all (the phase is exp / divide bound), at most 64 per image
-  int S = (1024 + a.B - 1) / a.B;
-  if (S > 64) S = 64;
+  // scoring slices per image: about one workgroup per CU in all (each costs one L2 write-back), at most 16 per image
+  int S = (256 + a.B - 1) / a.B;
+  if (S > 16) S = 16;
   if (S > (a.A + 255) / 256) S = (a.A + 255) / 256;
   if (S < 1) S = 1;
   a.S = S; a.per = (a.A + S - 1) / S;

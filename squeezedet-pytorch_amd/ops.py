@@ -113,7 +113,7 @@ def _tuning():
     if _TUNING is None:
         import json
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning.json')
+        path = os.environ.get('SQD_TUNING_JSON') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning.json')     # (override: A/B of tables)
         try:
             with open(path) as f:
                 # F: (fused expand) and W: (Winograd) entries carry the time of the alternative they were measured against;
@@ -360,6 +360,16 @@ def wino_cfgs():
         nat.check(nat.lib().sqd_wino_cfg_info(i, ctypes.byref(bn), ctypes.byref(wv)), 'sqd_wino_cfg_info')
         out[i] = (bn.value, wv.value)
     return out
+
+
+def wino_cfg_ok(cfg_id, C):
+    """Whether Winograd configuration ``cfg_id`` can run a layer with ``C`` input channels: ids 8..11 (U-stationary kernel)
+    keep the slice's whole transformed weight set in LDS next to the patch ring."""
+    c = cfg_id % 1000
+    if c < 8:
+        return True
+    bn, wv = wino_cfgs()[c]
+    return (2 * wv * 256 * 4 + (C // 8) * 32 * bn * 4) * 4 <= 160 * 1024
 
 
 def choose_wino_cfg(C, N, npix):

@@ -111,6 +111,7 @@ def main():
     ap.add_argument('--batch', type=int, default=20)
     ap.add_argument('--size', type=int, nargs=2, default=[384, 1248])
     ap.add_argument('--out', default=os.path.join(ROOT, 'squeezedet-pytorch_amd', 'tuning.json'))
+    ap.add_argument('--all-wino', action='store_true', help='also time the deep-prefetch Winograd ids 4..7 (isolated timing flatters them: profiles/r02f_ab_table_pipe.log)')
     ap.add_argument('--only', default='', help="'wino': keep the direct-kernel entries of the existing table, re-measure only the Winograd (W:) and fused-expand (F:) keys")
     args = ap.parse_args()
     B = args.batch
@@ -153,6 +154,8 @@ def main():
         res = []
         for cid, (bn, wv) in ops.wino_cfgs().items():
             if -(-N // bn) * bn > 2 * N and bn > 16:
+                continue
+            if not ops.wino_cfg_ok(cid, C) or (4 <= cid < 8 and not args.all_wino):
                 continue
             for cap in (0, 1):
                 try:
