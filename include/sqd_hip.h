@@ -129,8 +129,8 @@ int sqd_resolve_fwd(const float* pred, const float* anchors, float* probs, float
  * class-wise NMS, score threshold, compacted in class order.  Fixed-capacity outputs [B][keep_top_k];
  * det_count[b] rows are valid.  det_anchor = anchor index of every kept detection (not returned by the
  * reference; this is what "box indices bit-exact" is asserted on).  scales [B][2]=(sy,sx) or NULL.
- * ONE kernel launch.  keys_ws: workspace of B*A + B uint32 -- per-anchor score keys, then one arrival counter per image;
- * the B counters must be zero before the first call and are left zero by every call (allocate zeroed once, reuse). */
+ * ONE kernel launch (one workgroup per image; scores, selection and NMS never leave the LDS).  keys_ws: unused, may be
+ * NULL (kept so that callers of the earlier two-launch version need not change). */
 int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, unsigned* keys_ws, int* det_count,
                    long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
                    int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,

@@ -8,10 +8,9 @@
 //
 // pred is [B][A][C+5] fp32 (anchor-major: C class logits, 1 confidence logit, 4 deltas), anchors
 // [A][4] (cx,cy,w,h) fp32.  The reference runs ~15 elementwise launches plus a Python loop with
-// >=10 host syncs per image; here ONE launch (detect_kernel) does everything on the device for the whole batch:
-//   1. every workgroup scores one slice of one image (the whole chip works on this phase): score = max_c softmax_c *
-//      sigmoid(conf) per anchor; key = fp32 score bits (non-negative floats order like uint32) if score > score_thresh
-//      else 0; the LAST workgroup of an image to finish (device-scope counter) carries on alone with that image:
+// >=10 host syncs per image; here ONE launch (detect_kernel, one workgroup per image) does everything on the device:
+//   1. 16 waves score the image's anchors into LDS: score = max_c softmax_c * sigmoid(conf) per anchor; key = fp32 score
+//      bits (non-negative floats order like uint32) if score > score_thresh else 0; then 4 waves carry on:
 //   2. stable compaction of the non-zero keys into LDS, 4-pass 8-bit radix select of the K-th largest; ties at that
 //      key taken in ascending anchor order (the build's documented tie rule),
 //   3. one wave ranks the <=64 candidates (score desc, anchor index asc), decodes their boxes,
@@ -135,13 +134,12 @@ extern "C" int sqd_resolve_fwd(const float* pred, const float* anchors, float* p
 }
 
 // ---- fused detection ----
-// One launch of B x S workgroups.  Phase 1 spreads the per-anchor scoring (4 exp + 2 div each) over the whole chip:
-// workgroup (b, s) writes one uint32 key per anchor of its slice -- the fp32 score bits if score > score_thresh, else 0 --
-// then publishes them (device-scope fence) and bumps the image's arrival counter.  The workgroup that observes the
-// count S - 1 is the last one of image b: it acquires the other slices' keys and runs phase 2 for that image alone --
-// compacts the non-zero keys (stable, ascending anchor index), selects the top K, ranks them, runs class-wise NMS and
-// writes the compact result.  The counters live behind the keys in the workspace, start at zero and are reset by the
-// workgroup that consumed them, so the workspace is reusable launch after launch (and across hipGraph replays).
+// One launch, one workgroup per image.  Phase 1 (1024 threads) scores the anchors into LDS keys -- the fp32 score bits if
+// score > score_thresh, else 0; phase 2 (the first 256 threads) compacts the non-zero keys (stable, ascending anchor
+// index), selects the top K, ranks them, runs class-wise NMS and writes the compact result.  (Tried and dropped in
+// round 2: spreading phase 1 over the whole chip and handing the keys to the last-arriving workgroup of each image
+// through global memory -- the device-scope release / acquire pair across the XCDs' L2s cost 12-100 us, more than the
+// 20 idle-chip microseconds it saved; profiles/r02_detect_variants.log.)
 // Why pre-filtering by the threshold is exact: Detector.filter thresholds AFTER NMS, but a box at or below the
 // threshold can only suppress boxes with lower scores, which are dropped by the same threshold -- so the kept set
 // is that of NMS over the top-K of the above-threshold anchors.
@@ -151,63 +149,72 @@ extern "C" int sqd_resolve_fwd(const float* pred, const float* anchors, float* p
 struct DetArgs {
   const float* pred; const float* anchors; const float* scales;   // scales [B][2] = (sy, sx) or null
   const long long* in_class; const float* in_score; const float* in_box;   // dense inputs (filter mode) or null
-  unsigned* keys;                                                 // workspace [B][A] keys + [B] arrival counters (zero between launches)
-  int S, per;                                                     // scoring slices per image, anchors per slice
+  unsigned* keys;                                                 // (unused since the keys live in LDS; kept in the ABI)
+  int S, per;
   int* det_count; long long* det_class; float* det_score; float* det_box; int* det_anchor;
   int B, A, C, K;
   float wmax, hmax, nms_thresh, score_thresh;
 };
 
-__global__ __launch_bounds__(DET_THREADS) void detect_kernel(DetArgs a) {
+#define DET_SCORE_THREADS 1024      // phase 1 (scoring) runs 16 waves wide; phase 2 continues on the first DET_THREADS threads
+
+__global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* keysL = (unsigned*)smem_raw;                      // [A4] all keys of this image (A rounded up to 4)
   unsigned short* cidx = (unsigned short*)(smem_raw + (size_t)((a.A + 3) & ~3) * 4);   // [A] candidate anchor indices
   __shared__ unsigned hist[256];
-  __shared__ unsigned s_prefix, s_need, s_cnt, s_last;
+  __shared__ unsigned s_prefix, s_need, s_cnt, s_nlive;
   __shared__ unsigned wave_tot[DET_THREADS / 64];
   __shared__ unsigned cand_key[DET_K];
   __shared__ int cand_idx[DET_K];
   __shared__ int sorted_pos[DET_K];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = (int)blockIdx.x / a.S, slice = (int)blockIdx.x - b * a.S;
+  const int b = (int)blockIdx.x;
   const int A = a.A, C = a.C, K = a.K;
   const float* pred = a.pred ? a.pred + (long long)b * A * (C + 5) : nullptr;
-  unsigned* keys = a.keys + (long long)b * A;
   const bool dense = a.in_score != nullptr;
 
-  // 1. score this workgroup's slice of the image
-  {
-    const int lo = slice * a.per, hi = min(A, lo + a.per);
-    for (int i = lo + tid; i < hi; i += DET_THREADS) {
-      float s; int c;
-      if (dense) s = a.in_score[(long long)b * A + i];
-      else anchor_score(pred + (long long)i * (C + 5), C, s, c);
-      keys[i] = (s > a.score_thresh) ? __float_as_uint(s) : 0u;   // scores are >= 0: bit patterns order like the floats
+  // 1. score every anchor of the image straight into LDS (no key workspace in global memory, no second launch, no
+  //    cross-workgroup hand-off).  Two passes keep the exp / divide work dense:
+  //    1a. confidence only: score = max_c softmax_c * conf <= conf (softmax_c <= 1 and the products round monotonically), so
+  //        conf <= threshold already decides key = 0 -- exactly; the others are listed in LDS (any order);
+  //    1b. the listed anchors (typically ~15 %) get the full score.
+  if (tid == 0) s_nlive = 0u;
+  __syncthreads();
+  for (int i0 = 0; i0 < A; i0 += DET_SCORE_THREADS) {
+    const int i = i0 + tid;
+    bool live = false;
+    if (i < A) {
+      if (dense) {
+        const float s = a.in_score[(long long)b * A + i];
+        keysL[i] = (s > a.score_thresh) ? __float_as_uint(s) : 0u;
+      } else {
+        const float conf = 1.f / (1.f + expf(-pred[(long long)i * (C + 5) + C]));
+        live = conf > a.score_thresh;
+        if (!live) keysL[i] = 0u;
+      }
+    }
+    const unsigned long long m = __ballot(live);
+    if (m) {
+      unsigned base = 0u;
+      if (lane == 0) base = atomicAdd(&s_nlive, (unsigned)__popcll(m));
+      base = __shfl(base, 0);
+      if (live) cidx[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
     }
   }
-  // publish the slice, count the arrival; only the last workgroup of the image continues.  The barrier orders every
-  // thread's key stores before thread 0's device-scope RELEASE (one L2 write-back per workgroup, not one per wave), which
-  // makes them visible to the other XCDs before the counter moves; the last arriver's ACQUIRE (same atomic) + the second
-  // barrier order the reads of phase 2 behind it for the whole workgroup.
   __syncthreads();
-  if (tid == 0) {
-    unsigned* counter = a.keys + (long long)a.B * A + b;
-    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (old == (unsigned)(a.S - 1)) ? 1u : 0u;
-    if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  {
+    const int nlive = (int)s_nlive;
+    for (int j = tid; j < nlive; j += DET_SCORE_THREADS) {
+      const int i = cidx[j];
+      float s; int c;
+      anchor_score(pred + (long long)i * (C + 5), C, s, c);
+      keysL[i] = (s > a.score_thresh) ? __float_as_uint(s) : 0u;   // scores are >= 0: bit patterns order like the floats
+    }
   }
   __syncthreads();
-  if (!s_last) return;
-
-  // 0. all keys of the image -> LDS, coalesced (16-byte loads when the row is 16-byte aligned)
-  if ((((long long)b * A) & 3) == 0) {
-    const uint4* k4 = (const uint4*)keys;
-    for (int i = tid; i < (A >> 2); i += DET_THREADS) ((uint4*)keysL)[i] = k4[i];
-    for (int i = (A & ~3) + tid; i < A; i += DET_THREADS) keysL[i] = keys[i];
-  } else {
-    for (int i = tid; i < A; i += DET_THREADS) keysL[i] = keys[i];
-  }
+  if (tid >= DET_THREADS) return;            // phase 2 runs on 4 waves (its barriers only count the waves still alive)
 
   if (tid < DET_K) { cand_key[tid] = 0u; cand_idx[tid] = 0x7fffffff - DET_K + tid; }   // distinct sentinels: ranks stay a permutation
   if (tid == 0) { s_prefix = 0u; s_need = (unsigned)K; s_cnt = 0u; }
@@ -381,7 +388,6 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(DetArgs a) {
 
 static int launch_detect(DetArgs a, hipStream_t stream) {
   if (a.K < 1 || a.K > DET_K) return SQD_ERR_UNSUPPORTED;                 // one wave holds the NMS bit matrix
-  if (!a.keys) return SQD_ERR_BAD_ARG;
   const size_t lds = (size_t)((a.A + 3) & ~3) * 4 + (size_t)a.A * 2 + 16;  // keys + uint16 candidate indices
   if (a.A > 65535 || lds > 150 * 1024) return SQD_ERR_UNSUPPORTED;        // A <= 25600 anchors per image
   static size_t lds_enabled = 48 * 1024;                                   // raise the dynamic-LDS cap once per size class
@@ -390,18 +396,13 @@ static int launch_detect(DetArgs a, hipStream_t stream) {
       return SQD_ERR_LAUNCH;
     lds_enabled = 150 * 1024;
   }
-  // scoring slices per image: about one workgroup per CU in all (each costs one L2 write-back), at most 16 per image
-  int S = (256 + a.B - 1) / a.B;
-  if (S > 16) S = 16;
-  if (S > (a.A + 255) / 256) S = (a.A + 255) / 256;
-  if (S < 1) S = 1;
-  a.S = S; a.per = (a.A + S - 1) / S;
-  hipLaunchKernelGGL(detect_kernel, dim3((unsigned)(a.B * S)), dim3(DET_THREADS), lds, stream, a);
+  a.S = 1; a.per = a.A;
+  hipLaunchKernelGGL(detect_kernel, dim3((unsigned)a.B), dim3(DET_SCORE_THREADS), lds, stream, a);
   return sqd_launch_status();
 }
 
-// Fused decode + Detector.filter for a batch, straight from pred.  keys_ws: (B*A + B) uint32 workspace whose last B words
-// (arrival counters) are zero before the first call; the kernel leaves them zero.  Outputs are fixed-capacity
+// Fused decode + Detector.filter for a batch, straight from pred.  keys_ws: unused (may be NULL; earlier versions kept
+// the per-anchor keys in global memory).  Outputs are fixed-capacity
 // [B][K]; rows >= det_count[b] are left untouched.  scales ([B][2] = (sy,sx), may be null) folds
 // boxes_postprocess' division into the store.
 extern "C" int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, unsigned* keys_ws, int* det_count,

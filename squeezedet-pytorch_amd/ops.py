@@ -654,9 +654,8 @@ def _det_buffers(B, K, device, A=None):
 
 
 def _det_workspace(B, A, device):
-    """Score keys [B*A] followed by the per-image arrival counters [B] of the one-launch detect kernel: zeroed once, the
-    kernel leaves the counters zero, so the buffer is reusable (also across hipGraph replays)."""
-    return torch.zeros(B * A + B, device=device, dtype=torch.int32)
+    """Placeholder for the ABI's ``keys_ws`` argument (the one-launch detect kernel keeps its keys in LDS)."""
+    return torch.zeros(4, device=device, dtype=torch.int32)
 
 
 def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3, scales=None, out=None):
@@ -674,8 +673,8 @@ def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4
     if len(bufs) == 5:
         bufs = tuple(bufs) + (_det_workspace(B, A, pred.device),)
     cnt, cls, sc, bx, idx, keys = bufs
-    if keys.numel() != B * A + B or keys.dtype != torch.int32 or keys.device != pred.device or not keys.is_contiguous():
-        raise ValueError('detect: workspace must be the int32 [B*A + B] buffer of _det_workspace (zero-initialised counters)')
+    if keys.dtype != torch.int32 or keys.device != pred.device:
+        raise ValueError('detect: workspace must be an int32 tensor on the same device')
     br = _Bracket('detect', f'detect A{A}', 0.0, 4.0 * B * A * (num_classes + 5)) if _timer is not None else None
     rc = nat.lib().sqd_detect_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(keys), nat.ptr(cnt), nat.ptr(cls),
                                   nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes, int(input_size[0]),
