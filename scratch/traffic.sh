@@ -23,9 +23,13 @@ def short_name(k):
         return f"{base}<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>"
     m = re.match(r"conv_wino_kernel<(\d+), (\d+)>", short)
     if m: return f"conv_wino<{m.group(1)},{m.group(2)}>"
+    m = re.match(r"conv_wino_pipe_kernel<(\d+), (\d+), (true|false)>", short)
+    if m: return f"conv_wino_{'us' if m.group(3) == 'true' else 'dp'}<{m.group(1)},{m.group(2)}>"
+    m = re.match(r"(maxpool_fwd|maxpool_bwd)_kernel", short)
+    if m: return m.group(1)
     m = re.match(r"(stem_pool|stem_conv|stem_wgrad)_kernel<(\d+),", short)
     if m: return f"{m.group(1)}<{m.group(2)}>"
-    return {"maxpool_fwd_kernel": "maxpool_fwd", "maxpool_bwd_kernel": "maxpool_bwd", "detect_kernel": "detect"}.get(short, short)
+    return {"maxpool_fwd_kernel": "maxpool_fwd", "maxpool_bwd_kernel": "maxpool_bwd", "detect_kernel": "detect", "detect_kernel(DetArgs)": "detect"}.get(short, short)
 
 res = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": collections.Counter()})
 for C in ("FETCH_SIZE", "WRITE_SIZE"):

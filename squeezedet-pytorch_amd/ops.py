@@ -362,6 +362,14 @@ def wino_cfgs():
     return out
 
 
+def wino_kernel_name(cfg_id):
+    """Name of a Winograd configuration as bench.py / the profiles print it: conv_wino<NT,WAVES> (ids 0..3),
+    conv_wino_dp<..> (4..7: deep-prefetch staging), conv_wino_us<..> (8..11: U-stationary, barrier-free)."""
+    c = cfg_id % 1000
+    bn, wv = wino_cfgs()[c]
+    return f'conv_wino{("", "_dp", "_us")[c // 4]}<{bn // 16},{wv}>'
+
+
 def wino_cfg_ok(cfg_id, C):
     """Whether Winograd configuration ``cfg_id`` can run a layer with ``C`` input channels: ids 8..11 (U-stationary kernel)
     keep the slice's whole transformed weight set in LDS next to the patch ring."""
@@ -452,10 +460,9 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=No
     br = None
     if _timer is not None:
         npix = B * H * W
-        bn, wv = wino_cfgs()[plan.cfg_id % 1000]
         # flops = what the MFMA pipe executes (16 element-wise GEMMs per 2x2 tile = direct form / 2.25): the roofline
         # fraction of this kernel is against that; bench.py also quotes the direct-form equivalent
-        br = _Bracket(f'conv_wino<{bn // 16},{wv}>', f'9tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * 4,
+        br = _Bracket(wino_kernel_name(plan.cfg_id), f'9tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * 4,
                       4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * 16))
     for t, nm in ((ymask, 'ymask'), (ymul, 'ymul')):
         if t is not None:

