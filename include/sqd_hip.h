@@ -217,6 +217,18 @@ int sqd_loss_bwd(const float* pred, const float* gt, const float* anchors, const
                  float* dpred, int B, int A, int num_classes, int input_h, int input_w, float w_class,
                  float w_pos, float w_neg, float w_bbox, void* stream);
 
+/* Fire.forward's two expand convolutions + torch.cat (src/model/squeezedet.py:18-22) in ONE Winograd launch (inference):
+ * y[..., y_coff3 : +N3] = ReLU(conv3x3(x, w3) + b3), y[..., y_coff1 : +N1] = ReLU(conv1x1(x, w1) + b1).  A 1x1 convolution only
+ * occupies the four inner Winograd positions, so expand1x1 rides along as extra workgroup slices (128 channels x 4 positions
+ * each) that reuse the squeeze tile's staging instead of a second launch re-reading it.
+ * sqd_pack_wino_fire: w3 OIHW [N3][C][3][3] + w1 OIHW [N1][C][1][1] -> u_packed of (C/8)*16*Npad_total*8 floats,
+ * Npad_total = ceil32(N3) + 32*ceil(N1/128).  cfg_id of sqd_fire_wino_fwd: 4 / 6 (streamed U, 8 / 4 waves), 8 / 10
+ * (U-stationary: whole U in LDS, needs (C/8)*16 KB + patch ring <= 160 KB), + 1000*k = workgroups-per-CU cap. */
+int sqd_pack_wino_fire(const float* w3_oihw, const float* w1_oihw, float* u_packed, int N3, int N1, int C, int Npad_total, void* stream);
+int sqd_fire_wino_fwd(const float* x, const float* u_packed, const float* bias3, const float* bias1, float* y, int B, int H, int W,
+                      int C, int x_pitch, int x_coff, int N3, int y_coff3, int N1, int y_coff1, int Npad_total, int y_pitch,
+                      int cfg_id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

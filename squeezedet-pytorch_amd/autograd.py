@@ -80,9 +80,14 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
             else:
                 ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
             out = torch.empty(Bq, H, W, e1 + e3, device=a.device, dtype=torch.float32)
-            fcfg = ops.choose_fused_cfg(s, e1, npix) if (not save and base.fuse_expand and e1 == e3 and
-                                                         not (drop_mask is not None and i == len(layers) - 1)) else None
-            if fcfg is not None:
+            fusable = not save and not (drop_mask is not None and i == len(layers) - 1)
+            xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fusable and base.fuse_expand_wino and base.use_winograd) else None
+            fcfg = ops.choose_fused_cfg(s, e1, npix) if (fusable and xcfg is None and base.fuse_expand and e1 == e3) else None
+            if xcfg is not None:
+                # inference: both expands in ONE Winograd launch (expand1x1 = the four inner transform positions, riding
+                # along as extra channel slices on the same staged squeeze tile)
+                ops.fire_wino(sq, 0, base.fire_wino_plan(i, fire, xcfg), out, 0, e1)
+            elif fcfg is not None:
                 # inference: both expands in one launch (they read the same squeeze tile; the 1x1 rides along as extra
                 # channel groups that only run the centre tap)
                 ops.fire_expand(sq, 0, base.fused_expand_plan(i, fire, fcfg), out, 0)

@@ -57,6 +57,10 @@ struct WinoArgs {
   int ngroups, ntiles;          // B*gyn*gxn groups; ntiles = super-groups of WV groups
   int nslices, gx;              // persistent grid: gx tile streams x nslices channel slices
   int wg_cap;
+  // fused Fire expand (sqd_fire_wino_fwd): slices [0, nslices3) are expand3x3 slices of 32 channels (N, y_coff, bias as above);
+  // slices [nslices3, nslices) are expand1x1 slices of 128 channels (N1, y_coff1, bias1) riding in the same launch
+  int nslices3, N1, y_coff1;
+  const float* bias1;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w_t;
@@ -422,9 +426,14 @@ static int wino_num_cus() {
 // once per workgroup and stays there, so the chunk loop needs neither U requests nor a workgroup barrier -- the patch ring
 // is wave-private -- and the waves of a workgroup run free of each other: the transform of one overlaps the matrix work
 // of its SIMD neighbour instead of all waves meeting at a barrier 2..8 times per tile.
-template <int NT, int WV, bool USTAT>
-__global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wino_pipe_kernel(WinoArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
+// E1 = true: the workgroup is an expand1x1 slice of the fused Fire launch (sqd_fire_wino_fwd).  A 1x1 convolution in the
+// Winograd domain only touches the four inner positions (1,1), (1,2), (2,1), (2,2) (U = +-0.25 w there, 0 elsewhere), so such a
+// slice carries 128 channels x 4 positions instead of 32 channels x 16 positions: the same 32 accumulators, the same 64
+// MFMAs and the same 16 KB of U per chunk -- "virtual" position p' = 4 q + r, block j stands for position q, channel block
+// 2 r + j -- and only the operand selection, the bias injection and the inverse transform differ.
+template <int NT, int WV, bool USTAT, bool E1>
+__device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
+  static_assert(!E1 || NT == 2, "expand1x1 slices are built on the 32-channel tiling");
   constexpr int NTHR = WV * 64;
   constexpr int BN = 16 * NT;
   constexpr int RP = 113;
@@ -520,7 +529,20 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + j * 16 + 4 * g;
-    biasv[j] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    biasv[j] = (!E1 && a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // expand1x1 slice: its first channel, and the bias as MFMA operands -- one extra rank-1 product per accumulator of
+  // position (1,1) at the start of a tile, A[n][k] = bias[n] for k = 0, B[k][tile] = 1 for k = 0: nine registers instead of
+  // the 32 a per-lane copy of the slice's 128 biases would take
+  const int e1_c0 = E1 ? (n0 - a.nslices3 * BN) * 4 : 0;
+  float e1_biasA[E1 ? 8 : 1];
+  const float e1_oneB = (g == 0) ? 1.f : 0.f;
+  if constexpr (E1) {
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+      const int ch = e1_c0 + blk * 16 + lr;
+      e1_biasA[blk] = (g == 0 && a.bias1 && ch < a.N1) ? a.bias1[ch] : 0.f;
+    }
   }
   const int ty = lr >> 3, tx = lr & 7;
   // output addressing through buffer resources too (base = the slice's first channel of y; wave-uniform SGPR byte offset
@@ -529,7 +551,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
   int o_offB[4];
 #pragma unroll
   for (int px = 0; px < 4; ++px) o_offB[px] = (((2 * ty + (px >> 1)) * a.W + 2 * tx + (px & 1)) * a.y_pitch + 4 * g) * 4;
-  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff + n0), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)(E1 ? a.y + a.y_coff1 + e1_c0 : a.y + a.y_coff + n0), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t mulres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ymul ? a.ymul + a.y_coff + n0 : a.y), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t maskres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ymask ? a.ymask + a.y_coff + n0 : a.y), 0, 0x7ffffff0, 0x00020000);
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -585,7 +607,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
     advance();
   }
   int ub = 0, rb = 0;                    // ring slots of the chunk about to be computed
-  int stores_behind = 0;                 // the previous chunk ended a tile with exactly NST stores behind its DMA requests
+  int stores_behind = 0;                 // store instructions the previous chunk issued behind its DMA requests (0 = unknown)
 
   for (;;) {
     const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);
@@ -595,8 +617,13 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
       // -- stay in flight.  Vector-memory operations retire in issue order, so "all but the N youngest" is exact; when
       // the store count of the previous chunk is not known (border tiles, read-modify-write epilogues) the smaller N is
       // merely conservative.
-      if (__builtin_amdgcn_readfirstlane(stores_behind)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + NST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      {
+        const int sb = __builtin_amdgcn_readfirstlane(stores_behind);
+        if (sb == NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + NST) : "memory");
+        else if (E1 && sb == 32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 32) : "memory");
+        else if (E1 && sb == 16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 16) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // unknown / other counts: the smaller N is merely conservative
+      }
       if (!USTAT) __builtin_amdgcn_s_barrier();      // every wave's share of U[ub] is in LDS; every wave has left U[(ub+2)%3]
       asm volatile("" ::: "memory");
       stores_behind = 0;
@@ -612,7 +639,14 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 
       // ---- input transform of chunk k from patch buffer rb ----
       f32x2 vv[16];
-      {
+      if constexpr (E1) {
+        // only the four inner positions are needed: rows 1, 2 x columns 1, 2 of the tile's 4x4 patch
+        const float* const rawL = rawW + rb * WV * 256 * 4 + rawL_off;
+        const f32x2 d11 = *(const f32x2*)(rawL + (1 * 18 + 1) * 4), d12 = *(const f32x2*)(rawL + (1 * 18 + 2) * 4);
+        const f32x2 d21 = *(const f32x2*)(rawL + (2 * 18 + 1) * 4), d22 = *(const f32x2*)(rawL + (2 * 18 + 2) * 4);
+        const f32x2 t11 = d11 + d21, t12 = d12 + d22, t21 = d21 - d11, t22 = d22 - d12;      // column transform rows 1, 2
+        vv[5] = t11 + t12; vv[6] = t12 - t11; vv[9] = t21 + t22; vv[10] = t22 - t21;
+      } else {
         const float* const rawL = rawW + rb * WV * 256 * 4 + rawL_off;
         f32x2 t[4][4];
 #pragma unroll
@@ -643,8 +677,20 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-              const f32x4 c0v = (FIRST && t == 0) ? ((p == 5) ? biasv[j] : (f32x4){0.f, 0.f, 0.f, 0.f}) : acc[p][j];
-              acc[p][j] = mfma16(afr[j][2 * h + t], vv[p][t], c0v);
+              // expand1x1 slice: virtual position p = 4 q + r uses the transformed input of inner position q
+              const int pv = E1 ? ((p >> 2) == 0 ? 5 : (p >> 2) == 1 ? 6 : (p >> 2) == 2 ? 9 : 10) : p;
+              f32x4 c0v;
+              if (FIRST && t == 0) {
+                if constexpr (E1) {
+                  c0v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                  if (p < 4) c0v = mfma16(e1_biasA[(p & 3) * 2 + j], e1_oneB, c0v);      // bias enters all four outputs through m11
+                } else {
+                  c0v = (p == 5) ? biasv[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+              } else {
+                c0v = acc[p][j];
+              }
+              acc[p][j] = mfma16(afr[j][2 * h + t], vv[pv][t], c0v);
             }
         };
         f32x4 af0[NT], af1[NT];
@@ -674,6 +720,28 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
 
       if (last && cur.valid) {               // inverse transform Y = A^T M A on register pairs, stored straight away
         const int ysoff = (int)(unsigned)(cur.p0 * a.y_pitch * 4);            // host-checked < 4 GiB
+        if constexpr (E1) {
+          // M is non-zero only at the inner 2x2: y00 = m11+m12+m21+m22, y01 = m11-m12+m21-m22, y10 = m11+m12-m21-m22,
+          // y11 = m11-m12-m21+m22; block blk = 2 r + j lives in accumulators [4 q + r][j], q = 0..3
+          const bool wholexy = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W;
+          int nst = 0;
+#pragma unroll
+          for (int blk = 0; blk < 8; ++blk) {
+            if (e1_c0 + blk * 16 >= a.N1) continue;                          // (uniform) partial last slice
+            const f32x4 m0 = acc[0 + (blk >> 1)][blk & 1], m1 = acc[4 + (blk >> 1)][blk & 1];
+            const f32x4 m2 = acc[8 + (blk >> 1)][blk & 1], m3 = acc[12 + (blk >> 1)][blk & 1];
+            const f32x4 s01 = m0 + m1, d01 = m0 - m1, s23 = m2 + m3, d23 = m2 - m3;
+            const f32x4 ov[4] = {s01 + s23, d01 + d23, s01 - s23, d01 - d23};
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+              const bool valid = wholexy || (cur.y0 + 2 * ty + (px >> 1) < a.H && cur.x0 + 2 * tx + (px & 1) < a.W);
+              if (!valid || e1_c0 + blk * 16 + 4 * g >= a.N1) continue;
+              store16(wino_relu4(ov[px], relu_lo), yres, o_offB[px] + blk * 64, ysoff);
+            }
+            nst += 4;
+          }
+          stores_behind = (wholexy && (a.N1 & 15) == 0) ? nst : 0;
+        } else {
         const bool whole = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W && n0 + BN <= a.N;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -716,7 +784,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
             }
           }
         }
-        stores_behind = (whole && plain_epi) ? 1 : 0;
+        stores_behind = (whole && plain_epi) ? NST : 0;
+        }
       }
       ub = (ub == 2) ? 0 : ub + 1;
       rb ^= 1;
@@ -726,10 +795,19 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
     cur = group_pos(tile);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may still be in flight when the LDS is released
+}
+
+template <int NT, int WV, bool USTAT, bool FIRE>
+__global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wino_pipe_kernel(WinoArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (FIRE) {
+    if ((((int)blockIdx.x >> 3) % a.nslices) >= a.nslices3) { wino_pipe_body<NT, WV, USTAT, true>(a); return; }
+  }
+  wino_pipe_body<NT, WV, USTAT, false>(a);
 #endif
 }
 
-template <int NT, int WV, bool USTAT = false>
+template <int NT, int WV, bool USTAT = false, bool FIRE = false>
 static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
   constexpr int BN = 16 * NT, NTHR = WV * 64;
   constexpr size_t lds_ring = (size_t)(2 * WV * 256 * 4 + 3 * 32 * BN * 4) * sizeof(float);
@@ -737,7 +815,7 @@ static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
   // U-stationary: the patch ring + C/8 chunks of the slice's U
   const size_t lds = USTAT ? (size_t)(2 * WV * 256 * 4 + (a.C >> 3) * 32 * BN * 4) * sizeof(float) : lds_ring;
   if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
-  auto kern = conv_wino_pipe_kernel<NT, WV, USTAT>;
+  auto kern = conv_wino_pipe_kernel<NT, WV, USTAT, FIRE>;
   // 32-bit SGPR byte offset of a tile's output origin / per-lane byte offsets inside a group (buffer-resource stores)
   if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
   static bool attr_set = false;
@@ -751,8 +829,11 @@ static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
   a.gxn = sqd_cdiv(a.W, 16); a.gyn = sqd_cdiv(a.H, 4);
   a.ngroups = a.B * a.gxn * a.gyn;
   a.ntiles = sqd_cdiv(a.ngroups, WV);
-  const int nslices = sqd_cdiv(a.N, BN);
+  // fused Fire launch: every 32-wide slice of the packed (virtual) channel axis is a workgroup stream -- first the
+  // expand3x3 slices, then the expand1x1 slices (128 real channels each)
+  const int nslices = FIRE ? a.Npad / BN : sqd_cdiv(a.N, BN);
   if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;
+  if (!FIRE) a.nslices3 = nslices;
   const int slots = wino_num_cus() * ((a.wg_cap > 0 && a.wg_cap < wgs_per_cu) ? a.wg_cap : wgs_per_cu);
   int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
   const int per_wg = sqd_cdiv(a.ntiles, gx_max);
@@ -856,6 +937,50 @@ extern "C" int sqd_pack_wino_weight(const float* w_oihw, float* u_packed, int No
   return sqd_launch_status();
 }
 
+// ---- fused Fire expand in Winograd form (sqd_fire_wino_fwd) ----
+// Packed weights: the expand3x3 set as above in channels [0, Npad3) of a tensor Npad_total = Npad3 + Npad1v channels
+// wide, followed by the expand1x1 weights as "virtual" channels: slice s (32 virtual = 128 real channels), virtual position
+// p' = 4 q + r, virtual block j, row n  <->  inner position q in ((1,1), (1,2), (2,1), (2,2)), real channel
+// 128 s + (2 r + j) 16 + n, value G g G^T at that position = +0.25 w, -0.25 w, -0.25 w, +0.25 w.
+__global__ void pack_wino_e1_kernel(const float* __restrict__ w1, float* __restrict__ u, int N1, int C, int Npad3, int Npad_total) {
+  const int nv = Npad_total - Npad3;                         // virtual channels of the expand1x1 part
+  const long long total = (long long)(C >> 3) * nv * 8;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = (int)(idx & 7);
+  const int nvi = (int)((idx >> 3) % nv);
+  const int chunk = (int)((idx >> 3) / nv);
+  const int c = chunk * 8 + c8;
+  const int s = nvi >> 5, j = (nvi >> 4) & 1, n = nvi & 15;
+  const int nvirt = Npad3 + nvi;
+  const long long pps = (long long)Npad_total * 16;            // floats per position pair
+#pragma unroll
+  for (int pv = 0; pv < 16; ++pv) {
+    const int q = pv >> 2, r = pv & 3;
+    const int ch = 128 * s + (2 * r + j) * 16 + n;
+    const float sgn = (q == 0 || q == 3) ? 0.25f : -0.25f;
+    const float val = (ch < N1) ? sgn * w1[(long long)ch * C + c] : 0.f;
+    float* dst = u + (((((long long)chunk * 8 + (pv >> 1)) * (Npad_total >> 4) + (nvirt >> 4)) * 4 + (c8 >> 1)) * 16 + (nvirt & 15)) * 4 + (c8 & 1) + 2 * (pv & 1);
+    (void)pps;
+    *dst = val;
+  }
+}
+
+// w3 [N3][C][3][3], w1 [N1][C][1][1] (the two checkpoint tensors of a Fire's expand pair) -> u [C/8][8][Npad_total/16][4][16][2][2]
+// with Npad_total = ceil32(N3) + 32 * ceil(N1 / 128).
+extern "C" int sqd_pack_wino_fire(const float* w3_oihw, const float* w1_oihw, float* u_packed, int N3, int N1, int C, int Npad_total,
+                                  void* stream) {
+  SQD_CHECK_ARG(w3_oihw && w1_oihw && u_packed && N3 > 0 && N1 > 0 && C > 0 && C % 8 == 0);
+  const int Npad3 = sqd_cdiv(N3, 32) * 32, nv = sqd_cdiv(N1, 128) * 32;
+  SQD_CHECK_ARG(Npad_total == Npad3 + nv);
+  int rc = sqd_pack_wino_weight(w3_oihw, u_packed, N3, C, Npad_total, 0, stream);      // (zero-fills every channel >= N3)
+  if (rc != SQD_OK) return rc;
+  const long long total = (long long)(C >> 3) * nv * 8;
+  hipLaunchKernelGGL(pack_wino_e1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1_oihw, u_packed,
+                     N1, C, Npad3, Npad_total);
+  return sqd_launch_status();
+}
+
 // Winograd configurations: cfg_id -> (channel blocks per slice NT, waves per workgroup WV)
 struct WinoCfg { int nt, wv; };
 // ids 4..7: the same tilings on the deep-prefetch kernel (conv_wino_pipe_kernel); 8..11: its U-stationary, barrier-free
@@ -904,6 +1029,37 @@ extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const fl
     case 9: return launch_wino_pipe<1, 8, true>(a, s);
     case 10: return launch_wino_pipe<2, 4, true>(a, s);
     case 11: return launch_wino_pipe<1, 4, true>(a, s);
+  }
+  return SQD_ERR_UNSUPPORTED;
+}
+
+// Fire.forward's two expand convolutions + torch.cat (src/model/squeezedet.py:18-22) in ONE Winograd launch: y[..., y_coff3 :
+// y_coff3 + N3] = ReLU(conv3x3(x) + b3), y[..., y_coff1 : y_coff1 + N1] = ReLU(conv1x1(x) + b1).  u_packed from
+// sqd_pack_wino_fire; cfg_id: a 32-channel-slice id of the deep-prefetch family (4, 6: streamed U; 8, 10: U-stationary, C <= 64
+// at 4 waves / C <= 32 at 8), + 1000 k = workgroups-per-CU cap.  Inference forward (plain epilogue: bias + ReLU).
+extern "C" int sqd_fire_wino_fwd(const float* x, const float* u_packed, const float* bias3, const float* bias1, float* y, int B, int H,
+                                 int W, int C, int x_pitch, int x_coff, int N3, int y_coff3, int N1, int y_coff1, int Npad_total,
+                                 int y_pitch, int cfg_id, void* stream) {
+  SQD_CHECK_ARG(x && u_packed && y && B > 0 && H > 0 && W > 0 && C > 0 && N3 > 0 && N1 > 0);
+  SQD_CHECK_ARG(C % 8 == 0 && N3 % 4 == 0 && N1 % 16 == 0);
+  SQD_CHECK_ARG(x_pitch % 4 == 0 && x_coff % 4 == 0 && y_pitch % 4 == 0 && y_coff3 % 4 == 0 && y_coff1 % 4 == 0);
+  SQD_CHECK_ARG(x_coff >= 0 && x_coff + C <= x_pitch && y_coff3 >= 0 && y_coff3 + N3 <= y_pitch && y_coff1 >= 0 && y_coff1 + N1 <= y_pitch);
+  SQD_CHECK_ARG(Npad_total == sqd_cdiv(N3, 32) * 32 + sqd_cdiv(N1, 128) * 32);
+  SQD_CHECK_ARG((long long)W * 6 * (x_pitch > y_pitch ? x_pitch : y_pitch) * 4 < (1ll << 30));
+  SQD_CHECK_ARG((long long)B * H * W * x_pitch * 4 < (1ll << 32) - (1ll << 30));
+  SQD_CHECK_ARG((long long)(C >> 3) * 16 * Npad_total * 8 * 4 < (1ll << 32));
+  const int cap = cfg_id / 1000; cfg_id %= 1000;
+  WinoArgs a{};
+  a.x = x; a.u = u_packed; a.bias = bias3; a.bias1 = bias1; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.N = N3; a.Npad = Npad_total; a.y_pitch = y_pitch; a.y_coff = y_coff3; a.relu = 1; a.wg_cap = cap;
+  a.N1 = N1; a.y_coff1 = y_coff1; a.nslices3 = sqd_cdiv(N3, 32);
+  hipStream_t s = (hipStream_t)stream;
+  switch (cfg_id) {
+    case 4: return launch_wino_pipe<2, 8, false, true>(a, s);
+    case 6: return launch_wino_pipe<2, 4, false, true>(a, s);
+    case 8: return launch_wino_pipe<2, 8, true, true>(a, s);
+    case 10: return launch_wino_pipe<2, 4, true, true>(a, s);
   }
   return SQD_ERR_UNSUPPORTED;
 }

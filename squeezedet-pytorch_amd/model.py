@@ -144,6 +144,7 @@ class SqueezeDetBase(nn.Module):
         self.grad_sync = None                     # trainer.GradientExchange when data parallel (attach_data_parallel)
         self.use_winograd = True                  # 3x3 forward convs: Winograd F(2x2,3x3) kernel where tuning.json says it is faster
         self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
+        self.fuse_expand_wino = True              # ... in Winograd form (ops.fire_wino) where the table has an X: row
         # inference forward: pool 2 / 3 folded into the following squeeze (ops.pool_squeeze).  Off by default: measured equal
         # to the two separate kernels (0.174 vs 0.18 ms) -- both are bound by the 9x L2 read amplification of the window gather
         self.fuse_pool_squeeze = False
@@ -180,6 +181,19 @@ class SqueezeDetBase(nn.Module):
         if hit is not None and hit[0] == ver:
             return hit[1]
         p = ops.FusedExpandPlan(fire.expand1x1.weight, fire.expand1x1.bias, fire.expand3x3.weight, fire.expand3x3.bias, cfg_id)
+        self._fused_plans[key] = (ver, p)
+        return p
+
+    def fire_wino_plan(self, idx, fire, cfg_id):
+        """Packed weights of ``fire``'s expand pair for the one-launch Winograd form (inference forward); rebuilt when either
+        module's parameters change."""
+        key = ('firewino', idx, cfg_id)
+        mods = (fire.expand1x1, fire.expand3x3)
+        ver = tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()))
+        hit = self._fused_plans.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        p = ops.FireWinoPlan(fire.expand1x1.weight, fire.expand1x1.bias, fire.expand3x3.weight, fire.expand3x3.bias, cfg_id)
         self._fused_plans[key] = (ver, p)
         return p
 

@@ -478,6 +478,67 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=No
     return y
 
 
+FIRE_WINO_CFGS = (4, 6, 8, 10)      # 32-channel-slice ids of the deep-prefetch / U-stationary Winograd family
+
+
+def fire_wino_cfg_ok(cfg_id, C):
+    return cfg_id % 1000 in FIRE_WINO_CFGS and wino_cfg_ok(cfg_id, C)
+
+
+def choose_fire_wino_cfg(C, E1, E3, npix):
+    """Configuration for the fused Winograd Fire expand (key ``X:C:E3:npix`` of the measured table) or None: only where the
+    table says the one launch beats expand1x1 + Winograd expand3x3 inside the step."""
+    if C % 8 or E1 % 16 or E3 % 4:
+        return None
+    hit = _tuning().get(f'X:{C}:{E3}:{npix}')
+    return hit if (hit is not None and hit >= 0 and fire_wino_cfg_ok(hit, C)) else None
+
+
+class FireWinoPlan:
+    """Transformed weights of a Fire's expand pair for ``fire_wino``: expand3x3's U followed by expand1x1's four inner
+    positions as virtual channels (csrc/conv_wino.hip, sqd_pack_wino_fire)."""
+    __slots__ = ('cfg_id', 'C', 'N3', 'N1', 'Npad', 'w', 'b3', 'b1')
+
+    def __init__(self, w1, b1, w3, b3, cfg_id):
+        N3, C = w3.shape[0], w3.shape[1]
+        N1 = w1.shape[0]
+        if tuple(w3.shape) != (N3, C, 3, 3) or tuple(w1.shape) != (N1, C, 1, 1) or C % 8 or N1 % 16 or N3 % 4:
+            raise ValueError(f'fire_wino: need expand3x3 [N3,C,3,3] and expand1x1 [N1,C,1,1], C % 8 == 0, got {tuple(w3.shape)}, {tuple(w1.shape)}')
+        if not fire_wino_cfg_ok(cfg_id, C):
+            raise ValueError(f'fire_wino: configuration {cfg_id} cannot run C={C}')
+        self.cfg_id, self.C, self.N3, self.N1 = cfg_id, C, N3, N1
+        self.Npad = -(-N3 // 32) * 32 + -(-N1 // 128) * 32
+        self.w = torch.empty(C // 8, 16, self.Npad, 8, device=w3.device, dtype=torch.float32)
+        nat.check(nat.lib().sqd_pack_wino_fire(nat.ptr(w3.detach().contiguous()), nat.ptr(w1.detach().contiguous()), nat.ptr(self.w),
+                                               N3, N1, C, self.Npad, nat.stream_handle(w3.device)), 'sqd_pack_wino_fire')
+        self.b3 = None if b3 is None else b3.detach().contiguous()
+        self.b1 = None if b1 is None else b1.detach().contiguous()
+
+
+def fire_wino(x, x_coff, plan, y, y_coff1, y_coff3):
+    """y[..., y_coff1:+N1] = relu(expand1x1(x)), y[..., y_coff3:+N3] = relu(expand3x3(x)) in ONE Winograd launch."""
+    _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
+    B, H, W, xp = x.shape
+    if tuple(y.shape[:3]) != (B, H, W):
+        raise ValueError('fire_wino: x and y disagree on B,H,W')
+    yp = y.shape[3]
+    if x_coff < 0 or x_coff + plan.C > xp or min(y_coff1, y_coff3) < 0 or y_coff1 + plan.N1 > yp or y_coff3 + plan.N3 > yp:
+        raise ValueError('fire_wino: channel window out of range')
+    if not (y_coff1 + plan.N1 <= y_coff3 or y_coff3 + plan.N3 <= y_coff1):
+        raise ValueError('fire_wino: output windows overlap')
+    br = None
+    if _timer is not None:
+        npix = B * H * W
+        br = _Bracket(wino_kernel_name(plan.cfg_id).replace('conv_wino', 'fire_wino'), f'fire C{plan.C} E{plan.N1}+{plan.N3} {H}x{W}',
+                      2.0 * npix * plan.C * (4 * plan.N3 + plan.N1), 4.0 * (npix * (plan.C + plan.N1 + plan.N3) + plan.C * (16 * plan.N3 + plan.N1)))
+    rc = nat.lib().sqd_fire_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.b3), nat.ptr(plan.b1), nat.ptr(y), B, H, W, plan.C, xp, x_coff,
+                                     plan.N3, y_coff3, plan.N1, y_coff1, plan.Npad, yp, plan.cfg_id, nat.stream_handle(x.device))
+    nat.check(rc, 'sqd_fire_wino_fwd')
+    if br is not None:
+        br.done()
+    return y
+
+
 POOL_SQUEEZE_CFG = 28        # 1x1 tiling with KC = 32, 16-channel slices: its packed weights are [C/4][ceil16(N)][4]
 
 

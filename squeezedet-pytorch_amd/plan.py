@@ -44,8 +44,11 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
         _, cin, s, e1, e3 = l
         npix = batch * H * W
         plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, cin, s, npix)), f'1tap C{cin} N{s} {H}x{W}'))
-        fcfg = ops.choose_fused_cfg(s, e1, npix) if (fuse_expand and e1 == e3) else None
-        if fcfg is not None:
+        xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fuse_expand and use_winograd) else None
+        fcfg = ops.choose_fused_cfg(s, e1, npix) if (xcfg is None and fuse_expand and e1 == e3) else None
+        if xcfg is not None:
+            plan.append((ops.wino_kernel_name(xcfg).replace('conv_wino', 'fire_wino'), f'fire C{s} E{e1}+{e3} {H}x{W}'))
+        elif fcfg is not None:
             plan.append((ops.cfg_kernel_name(fcfg).replace('conv_dma', 'fire_expand'), f'expand C{s} E{e1} {H}x{W}'))
         else:
             plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, s, e1, npix)), f'1tap C{s} N{e1} {H}x{W}'))

@@ -279,3 +279,33 @@ def test_golden_forward_through_winograd_kernels(golden_dir, force_winograd):
     np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
     np.testing.assert_allclose(pred1[0].cpu().numpy()[gk["top_idx"]], gk["pred_top"], atol=TOL, rtol=0)
     assert force_winograd['n'] >= 22                         # 10 expand3x3 + ConvDet, both models
+
+
+def test_golden_forward_through_one_launch_winograd_fire(golden_dir, monkeypatch):
+    """The reference-generated goldens with every Fire's expand pair forced onto the ONE-launch Winograd form (expand1x1 as the
+    four inner transform positions; the shipped table has no X: rows because the separate launches measured faster, so
+    the default path never takes it): same 1e-4 bound."""
+    from squeezedet_pytorch_amd import ops
+    used = {'n': 0}
+
+    def always(C, E1, E3, npix):
+        if C % 8 or E1 % 16:
+            return None
+        used['n'] += 1
+        return 10 if ops.fire_wino_cfg_ok(10, C) else 6
+    monkeypatch.setattr(ops, 'choose_fire_wino_cfg', always)
+    monkeypatch.setattr(ops, 'choose_wino_cfg', lambda C, N, npix: (2 if C % 8 == 0 else None))
+    g = np.load(os.path.join(golden_dir, "backbone_small.npz"))
+    for arch in ("squeezedet", "squeezedetplus"):
+        cfg, m, sd = _model(arch, (64, 96))
+        x = synthetic.make_images(2, (64, 96), seed=3)
+        with torch.no_grad():
+            pred = m.base(x.cuda())
+        np.testing.assert_allclose(pred.cpu().numpy(), g[f"{arch}_pred"], atol=TOL, rtol=0)
+    gk = np.load(os.path.join(golden_dir, "kitti_full.npz"))
+    cfg, m, sd = _model('squeezedet', (384, 1248))
+    x1 = synthetic.make_images(1, (384, 1248), seed=0)
+    with torch.no_grad():
+        pred1 = m.base(x1.cuda())
+    np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
+    assert used['n'] >= 30

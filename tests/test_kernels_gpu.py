@@ -335,3 +335,39 @@ def test_conv_wgrad_winograd(C, N, B, H, W):
     assert (dw - dw0).abs().max().item() <= 1e-4 * sc and (db - db0).abs().max().item() <= 1e-4 * sc
     dw2, db2 = ops.conv_wgrad(dyb.cuda(), 4, N, xb.cuda(), 4, C, 9, wino=True)        # fixed-order sums: bitwise reproducible
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("C,E1,E3,B,H,W", [
+    (16, 64, 64, 2, 12, 20), (32, 128, 128, 1, 9, 33), (48, 192, 192, 1, 24, 78), (64, 256, 256, 2, 6, 18), (96, 384, 384, 1, 5, 17),
+    (16, 64, 64, 6, 96, 312), (96, 384, 384, 20, 24, 78), (8, 16, 20, 3, 4, 16), (24, 48, 40, 2, 7, 35),
+])
+def test_fire_expand_winograd_one_launch(C, E1, E3, B, H, W):
+    """Fire's expand pair in ONE Winograd launch (expand1x1 as the four inner transform positions): both halves of the concat
+    == the two fp32 convolutions of the reference (src/model/squeezedet.py:18-22), every usable configuration, odd sizes,
+    partial expand1x1 slices (E1 not a multiple of 128), bytes outside the two windows untouched; and bit-identical to the
+    separate Winograd launch for the expand3x3 half (same arithmetic)."""
+    ops = _ops()
+    x = F.relu(_rand(B, C, H, W, seed=41))
+    w1 = _rand(E1, C, 1, 1, seed=42, scale=(2.0 / C) ** 0.5); b1 = _rand(E1, seed=43, scale=0.1)
+    w3 = _rand(E3, C, 3, 3, seed=44, scale=(2.0 / (C * 9)) ** 0.5); b3 = _rand(E3, seed=45, scale=0.1)
+    ref1 = _nhwc(F.relu(F.conv2d(x, w1, b1)))
+    ref3 = _nhwc(F.relu(F.conv2d(x, w3, b3, padding=1)))
+    xg = _nhwc(x).cuda()
+    ran = 0
+    for cid in ops.FIRE_WINO_CFGS + (1006, 1010):
+        if not ops.fire_wino_cfg_ok(cid, C):
+            continue
+        plan = ops.FireWinoPlan(w1.cuda(), b1.cuda(), w3.cuda(), b3.cuda(), cid)
+        y = torch.full((B, H, W, E1 + E3 + 8), -7.0, device='cuda')
+        ops.fire_wino(xg, 0, plan, y, 4, 4 + E1)
+        torch.cuda.synchronize()
+        yc = y.cpu()
+        assert (yc[..., 4:4 + E1] - ref1).abs().max().item() <= _tol(ref1), f'cfg {cid} expand1x1'
+        assert (yc[..., 4 + E1:4 + E1 + E3] - ref3).abs().max().item() <= _tol(ref3), f'cfg {cid} expand3x3'
+        assert bool((yc[..., :4] == -7.0).all()) and bool((yc[..., 4 + E1 + E3:] == -7.0).all())
+        if C % 8 == 0 and cid < 1000:
+            y3 = torch.empty(B, H, W, E3, device='cuda')
+            ops.conv_wino(xg, 0, ops.WinoPlan(w3.cuda(), b3.cuda(), cid), y3, 0, relu=True)
+            assert torch.equal(y3.cpu(), yc[..., 4 + E1:4 + E1 + E3])
+        ran += 1
+    assert ran >= 2
