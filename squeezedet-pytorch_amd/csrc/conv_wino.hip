@@ -54,6 +54,9 @@ struct WinoArgs {
   int relu, accumulate;         // epilogue: y += result
   const float* ymask; const float* ymul;   // epilogue (same pitch / channel offset as y): multiply by ymul (dropout), zero where ymask <= 0
   int gxn, gyn;                 // column / row groups per image
+  unsigned gxn_m, gyn_m;        // ceil(2^32 / gxn), ceil(2^32 / gyn): the group index is split with two scalar multiply-highs
+                                // (a division of wave-uniform integers otherwise goes through ~10 vector instructions + readfirstlane,
+                                // twice per tile, and every vector instruction delays the SIMD's MFMA stream)
   int ngroups, ntiles;          // B*gyn*gxn groups; ntiles = super-groups of WV groups
   int nslices, gx;              // persistent grid: gx tile streams x nslices channel slices
   int wg_cap;
@@ -137,8 +140,10 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
     int q = t * WV + wv_s;
     gp.valid = (int)((unsigned)(q - a.ngroups) >> 31);       // q < ngroups
     q = gp.valid ? q : a.ngroups - 1;                        // idle waves of the last super-group redo the last group (not stored)
-    const int gxi = q % a.gxn; q /= a.gxn;
-    const int gyi = q % a.gyn; const int b = q / a.gyn;
+    const int q1 = a.gxn_m ? (int)__umulhi((unsigned)q, a.gxn_m) : q;        // q / gxn (exact: q * gxn < 2^32, host-checked; magic 0 = divisor 1)
+    const int gxi = q - q1 * a.gxn;
+    const int b = a.gyn_m ? (int)__umulhi((unsigned)q1, a.gyn_m) : q1;       // q1 / gyn
+    const int gyi = q1 - b * a.gyn;
     gp.y0 = gyi * 4; gp.x0 = gxi * 16;
     gp.p0 = ((long long)b * a.H + gp.y0) * a.W + gp.x0;
     gp.soff = (unsigned)(gp.p0 * a.x_pitch * 4);             // byte offset of the patch origin from the resource base
@@ -489,8 +494,10 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
     int q = t * WV + wv_s;
     gp.valid = (int)((unsigned)(q - a.ngroups) >> 31);
     q = gp.valid ? q : a.ngroups - 1;
-    const int gxi = q % a.gxn; q /= a.gxn;
-    const int gyi = q % a.gyn; const int b = q / a.gyn;
+    const int q1 = a.gxn_m ? (int)__umulhi((unsigned)q, a.gxn_m) : q;        // q / gxn (exact: q * gxn < 2^32, host-checked; magic 0 = divisor 1)
+    const int gxi = q - q1 * a.gxn;
+    const int b = a.gyn_m ? (int)__umulhi((unsigned)q1, a.gyn_m) : q1;       // q1 / gyn
+    const int gyi = q1 - b * a.gyn;
     gp.y0 = gyi * 4; gp.x0 = gxi * 16;
     gp.p0 = ((long long)b * a.H + gp.y0) * a.W + gp.x0;
     gp.soff = (unsigned)(gp.p0 * a.x_pitch * 4);
@@ -828,6 +835,8 @@ static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
   const int wgs_per_cu = nb > 4 ? 4 : nb;
   a.gxn = sqd_cdiv(a.W, 16); a.gyn = sqd_cdiv(a.H, 4);
   a.ngroups = a.B * a.gxn * a.gyn;
+  if ((long long)(a.ngroups + 8) * (a.gxn > a.gyn ? a.gxn : a.gyn) >= (1ll << 32)) return SQD_ERR_UNSUPPORTED;
+  a.gxn_m = a.gxn > 1 ? (unsigned)(((1ull << 32) + a.gxn - 1) / a.gxn) : 0u; a.gyn_m = a.gyn > 1 ? (unsigned)(((1ull << 32) + a.gyn - 1) / a.gyn) : 0u;
   a.ntiles = sqd_cdiv(a.ngroups, WV);
   // fused Fire launch: every 32-wide slice of the packed (virtual) channel axis is a workgroup stream -- first the
   // expand3x3 slices, then the expand1x1 slices (128 real channels each)
@@ -860,6 +869,8 @@ static int launch_wino(WinoArgs a, hipStream_t stream) {
   }
   a.gxn = sqd_cdiv(a.W, 16); a.gyn = sqd_cdiv(a.H, 4);
   a.ngroups = a.B * a.gxn * a.gyn;
+  if ((long long)(a.ngroups + 8) * (a.gxn > a.gyn ? a.gxn : a.gyn) >= (1ll << 32)) return SQD_ERR_UNSUPPORTED;
+  a.gxn_m = a.gxn > 1 ? (unsigned)(((1ull << 32) + a.gxn - 1) / a.gxn) : 0u; a.gyn_m = a.gyn > 1 ? (unsigned)(((1ull << 32) + a.gyn - 1) / a.gyn) : 0u;
   a.ntiles = sqd_cdiv(a.ngroups, WV);
   const int nslices = sqd_cdiv(a.N, BN);
   if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;

@@ -162,6 +162,7 @@ struct StemPoolArgs {
   const float* x; const float* w; const float* bias; float* y; uint8_t* amax;
   int B, Hin, Win, Ho, Wo, Hp, Wp, N;
   int tiles_x, tiles_y, ntiles;
+  unsigned tiles_x_m, tiles_y_m;      // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y): tile index split by scalar multiply-highs
 };
 
 __device__ __attribute__((aligned(16))) float sqd_stem_zero[4] = {0.f, 0.f, 0.f, 0.f};
@@ -252,8 +253,10 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : 1) void stem_po
   struct Tile { int ty, tx, inner; const float* xorg; long long obase; };
   auto tile_at = [&](int t) {
     Tile q;
-    q.tx = t % a.tiles_x; t /= a.tiles_x;
-    q.ty = t % a.tiles_y; const int b = t / a.tiles_y;
+    const int t1 = a.tiles_x_m ? (int)__umulhi((unsigned)t, a.tiles_x_m) : t;      // t / tiles_x (exact: t * tiles_x < 2^32, host-checked; 0 = divisor 1)
+    q.tx = t - t1 * a.tiles_x;
+    const int b = a.tiles_y_m ? (int)__umulhi((unsigned)t1, a.tiles_y_m) : t1;
+    q.ty = t1 - b * a.tiles_y;
     const int iy0 = 2 * (2 * q.ty * PH) - PAD, ix0 = 2 * (2 * q.tx * PW) - PAD;
     q.xorg = a.x + ((long long)b * 3 * a.Hin + iy0) * a.Win + ix0;      // dereferenced only where the pixel exists
     q.inner = iy0 >= 0 && iy0 + IH <= a.Hin && ix0 >= 0 && ix0 + IW <= a.Win;
@@ -425,6 +428,9 @@ static int launch_stem_pool_t(StemPoolArgs a, hipStream_t s) {
   static_assert(IH < 256 && IW < 256, "slot keys pack row/col in 8 bits");
   a.tiles_x = sqd_cdiv(a.Wp, PW); a.tiles_y = sqd_cdiv(a.Hp, PH);
   a.ntiles = a.B * a.tiles_x * a.tiles_y;
+  if ((long long)a.ntiles * (a.tiles_x > a.tiles_y ? a.tiles_x : a.tiles_y) >= (1ll << 32)) return SQD_ERR_UNSUPPORTED;
+  a.tiles_x_m = a.tiles_x > 1 ? (unsigned)(((1ull << 32) + a.tiles_x - 1) / a.tiles_x) : 0u;
+  a.tiles_y_m = a.tiles_y > 1 ? (unsigned)(((1ull << 32) + a.tiles_y - 1) / a.tiles_y) : 0u;
   auto kern = stem_pool_kernel<KS, PAD, NT, ARGMAX, WM>;
   static int wgs_per_cu = 0;
   if (wgs_per_cu == 0) {
