@@ -28,6 +28,21 @@ def _decode_pred():
     return torch.from_numpy((rs.standard_normal((2, 16848, 8)) * np.array([2, 2, 2, 2, .4, .4, .4, .4])).astype(np.float32))
 
 
+def _class_margin(pred, cfg):
+    """Gap between the best and the second-best class score of every anchor (oracle arithmetic on ``pred``)."""
+    probs, _, scores, _, _ = oracle.resolve_predictions(pred, cfg.anchors, cfg.input_size, cfg.num_classes)
+    top2 = torch.topk(probs * scores, 2, dim=2)[0]
+    return (top2[..., 0] - top2[..., 1]).numpy()
+
+
+def _assert_class_ids(got, want, margin, tol=2e-4):
+    """class_ids are an argmax: bit-exact wherever the runner-up is more than ``tol`` behind (everywhere a 1e-4 difference
+    in the inputs cannot change the winner); the few anchors inside the margin may flip."""
+    diff = got != want
+    assert not (diff & (margin > tol)).any(), f'{int((diff & (margin > tol)).sum())} class ids differ outside the tie margin'
+    assert diff.sum() <= (margin <= tol).sum()
+
+
 def test_state_dict_contract():
     from squeezedet_pytorch_amd.model import SqueezeDet, SqueezeDetWithLoss
     cfg = sqd.make_cfg()
@@ -53,7 +68,7 @@ def test_backbone_small_vs_golden_and_oracle(golden_dir, arch):
     np.testing.assert_allclose(pred.cpu().numpy(), g[f"{arch}_pred"], atol=TOL, rtol=0)
     np.testing.assert_allclose(det['scores'].cpu().numpy(), g[f"{arch}_scores"], atol=TOL, rtol=0)
     np.testing.assert_allclose(det['boxes'].cpu().numpy(), g[f"{arch}_boxes"], atol=5e-3, rtol=0)
-    assert (det['class_ids'].cpu().numpy() == g[f"{arch}_class_ids"]).mean() > 0.995
+    _assert_class_ids(det['class_ids'].cpu().numpy(), g[f"{arch}_class_ids"], _class_margin(torch.from_numpy(g[f"{arch}_pred"]), cfg))
     assert det['class_ids'].dtype == torch.int64
 
 
@@ -86,7 +101,9 @@ def test_decode_vs_golden(golden_dir):
     sel = g["sel"]
     np.testing.assert_allclose(sc.cpu().numpy()[:, sel], g["best"], atol=1e-6, rtol=0)
     np.testing.assert_allclose(bx.cpu().numpy()[:, sel], g["boxes"], atol=1e-3, rtol=0)
-    assert (ids.cpu().numpy()[:, sel] == g["class_ids"]).mean() > 0.9995
+    # identical pred on both sides: the decode kernel mirrors the oracle op for op, so the argmax may only differ where the
+    # two best classes are within rounding of each other
+    _assert_class_ids(ids.cpu().numpy()[:, sel], g["class_ids"], _class_margin(pred, cfg)[:, sel], tol=1e-6)
 
 
 def _check_detect_against_oracle(pred, cfg, cnt, cls, sc, bx, idx, exact_scores=True):
@@ -181,15 +198,39 @@ def test_detector_end_to_end_kitti():
         assert np.array_equal(r['class_ids'], d['class_ids'])
         np.testing.assert_allclose(r['scores'], d['scores'], atol=1e-6)
         np.testing.assert_allclose(r['boxes'], oracle.boxes_postprocess(d['boxes'], scales), atol=2e-3)
-        # stage B: against the oracle end to end (oracle backbone): same detections up to near-ties
+        # stage B: against the oracle end to end (oracle backbone).  fp32 summation order differs between the two backbones,
+        # so the outcome is only DETERMINED where no decision sits within the 1e-4 score / box tolerance of a boundary:
+        # top-64 cut, threshold, rank order of overlapping same-class candidates, IoU vs 0.4.  Where it is determined the
+        # kept anchors must be identical, in the same order; otherwise the two lists may differ only by fragile anchors.
         do = oracle.filter_detections(ids_o[b].numpy(), sc_o[b].numpy(), bx_o[b].numpy())
         so = sc_o[b].numpy()
-        order = np.argsort(-so, kind='stable')
-        margin_topk = so[order[63]] - so[order[64]]
-        common = set(r['anchor_idx']) & set(do['anchor_idx'])
-        if margin_topk > 2e-4 and np.min(np.abs(so[order[:64]] - 0.3)) > 2e-4:
-            assert len(common) >= len(do['anchor_idx']) - 2
         np.testing.assert_allclose(sc_h[b].numpy(), so, atol=TOL)
+        order = np.argsort(-so, kind='stable')
+        top = order[:65]
+        eps = 2e-4
+        fragile = set()
+        if so[top[63]] - so[top[64]] <= eps:
+            fragile |= {int(top[63]), int(top[64])}
+        fragile |= {int(a) for a in top[:64] if abs(so[a] - 0.3) <= eps}
+        cls_o, box_o = ids_o[b].numpy(), bx_o[b].numpy()
+        for i in range(64):
+            for j in range(i + 1, 64):
+                ai, aj = top[i], top[j]
+                if cls_o[ai] != cls_o[aj]:
+                    continue
+                bi, bj = box_o[ai], box_o[aj]
+                w = max(0.0, min(bi[2], bj[2]) - max(bi[0], bj[0])); h = max(0.0, min(bi[3], bj[3]) - max(bi[1], bj[1]))
+                inter = w * h
+                union = (bi[2] - bi[0]) * (bi[3] - bi[1]) + (bj[2] - bj[0]) * (bj[3] - bj[1]) - inter
+                iou = inter / union if union > 0 else 0.0
+                if abs(iou - 0.4) <= 2e-3 or (iou > 0.39 and abs(so[ai] - so[aj]) <= eps):
+                    fragile |= {int(ai), int(aj)}
+        got, want = [int(v) for v in r['anchor_idx']], [int(v) for v in do['anchor_idx']]
+        if not fragile:
+            assert got == want, (got, want)
+        else:
+            # everything that differs must be explained by a fragile anchor (itself, or one that suppresses / frees it)
+            assert len(set(got) ^ set(want)) <= 2 * len(fragile), (sorted(set(got) ^ set(want)), sorted(fragile))
 
 
 def test_prediction_resolver_five_outputs_vs_golden(golden_dir):
