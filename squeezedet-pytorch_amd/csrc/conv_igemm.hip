@@ -591,6 +591,197 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-stationary, barrier-free 1x1 convolution (tile configurations with dma = 3: conv_ws<NT, WAVES, D>).
+//
+// Why (round 2 measurements, DESIGN.md "1x1 family"): on the 24x78 / 48x156 layers conv_dma_kernel<1,...> is bound neither
+// by HBM nor by the matrix cores but by how a workgroup is fed: one stage (8-12 KB) in flight per workgroup per memory
+// round trip, a workgroup barrier per stage, and whole workgroups (4 waves x 16 pixels) as the unit of load balance on
+// a layer that only has 2340 16-pixel MFMA columns for 1024 SIMDs.  Here the slice's WHOLE weight matrix (C x 16 NT
+// floats, k-quad-major) is fetched into LDS once per workgroup and stays; a wave then owns 16-pixel tiles on its own:
+// its activation stages (16 pixels x 32 channels = 2 KB) arrive by LDS-DMA in a wave-private ring D stages deep, retired
+// by counted s_waitcnt vmcnt(N) -- no workgroup barrier after the weight load, every wave runs free, and the unit of
+// load balance is one wave x one 16-pixel tile.  Same arithmetic as the other kernels (k-ordered fp32 MFMA chain).
+// Weights: the packed layout of a KC = 32 plan, [C/32][8][Npad][4] = [k-quad][row][4].
+template <int NT, int WV, int D>
+__global__ __launch_bounds__(WV * 64) void conv_ws_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NTHR = WV * 64, BN = 16 * NT, KC = 32;
+  constexpr int NDMA = 2;                               // LDS-DMA instructions per stage and wave (128 slots of 16 B)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nchunks = (a.C + KC - 1) / KC, nplanes = nchunks * 8;
+  const int wslots = (nplanes * BN + NTHR - 1) / NTHR * NTHR;
+  float* const wS = smem;                               // [nplanes][BN][4]
+  float* const ringB = smem + wslots * 4;               // [WV][D][8 planes][16 px][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wgq = (int)blockIdx.x >> 3;
+  const int n0 = (wgq % a.nslices) * BN;
+  const int stream = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
+  const int ntasks = a.ntiles;                          // 16-pixel tiles
+  const int tstride = a.gx * WV;                        // wave streams in flight
+  int tile = stream * WV + wave_s;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- the slice's weights, once ----
+  {
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
+    for (int s0 = 0; s0 < wslots; s0 += NTHR) {
+      const int slot = s0 + tid;
+      const int plane = slot / BN, row = slot - plane * BN;
+      const int off = (plane < nplanes) ? (int)(((unsigned)plane * a.Npad + n0 + row) * 16u) : (int)OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_ptr_t)(wS + (s0 + wave_s * 64) * 4), 16, off, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // the only workgroup barrier
+  }
+  if (tile >= ntasks) return;
+
+  // ---- per-lane constants ----
+  int a_offB[NDMA], a_key[NDMA];                        // byte offset of the lane's slot inside a stage; key = plane << 8 | px
+#pragma unroll
+  for (int it = 0; it < NDMA; ++it) {
+    const int slot = it * 64 + lane;
+    const int v = slot >> 4, px = slot & 15;
+    a_offB[it] = (px * a.x_pitch + 4 * v) * 4;
+    a_key[it] = v << 8 | px;
+  }
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + a.x_coff), 0, 0x7ffffff0, 0x00020000);
+  float* const ringW = ringB + wave_s * (D * 128 * 4);
+  const int full_c = (a.C % KC) == 0;
+  auto issue = [&](int ptile, int pcc, int slotr) {     // request stage (ptile, pcc) into ring slot slotr
+    const unsigned soff = ((unsigned)ptile * 16u * (unsigned)a.x_pitch + (unsigned)pcc * KC) * 4u;
+    const bool full = ((long long)ptile * 16 + 16 <= a.total_px) && (full_c || (pcc + 1) * KC <= a.C);     // uniform
+#pragma unroll
+    for (int it = 0; it < NDMA; ++it) {
+      int off = a_offB[it];
+      if (!full) {
+        const int key = a_key[it];
+        const bool ok = (long long)ptile * 16 + (key & 255) < a.total_px && pcc * KC + 4 * (key >> 8) < a.C;
+        off = ok ? off : (int)OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_t)(ringW + (slotr * 128 + it * 64) * 4), 16, off, (int)soff, 0, 0);
+    }
+  };
+  f32x4 biasv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + 4 * g;
+    biasv[j] = (a.bias && n < a.N) ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int o_offB = (lr * a.y_pitch + 4 * g) * 4;
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff + n0), 0, 0x7ffffff0, 0x00020000);
+  const bool same_geom = (!a.ymul || (a.ymul_pitch == a.y_pitch)) && (!a.ymask || (a.ymask_pitch == a.y_pitch));
+  const __amdgpu_buffer_rsrc_t mulres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ymul ? a.ymul + a.ymul_coff + n0 : a.y), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t maskres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ymask ? a.ymask + a.ymask_coff + n0 : a.y), 0, 0x7ffffff0, 0x00020000);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  auto store16 = [&](f32x4 v, int voff, int soff) {     // (MUBUF store + SGPR soffset write-after-read hazard: see conv_wino.hip)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yres, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const float relu_lo = a.relu ? 0.f : -__builtin_inff();
+  const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
+  const bool plain_epi = !acc_i && !has_mul && !has_mask;
+  const float* const wL = wS + (g * BN + lr) * 4;       // + (plane group * 4 * BN + j * 16) * 4: per-lane base of the A operands
+  const float* const bL0 = ringW + (g * 16 + lr) * 4;   // + (slot * 128 + sk * 64) * 4
+
+  // ---- prefetch cursor: D - 1 stages ahead; clamps on this wave's last tile ----
+  int ptile = tile, pcc = 0;
+  auto advance = [&]() {
+    ++pcc;
+    if (pcc == nchunks) { pcc = 0; ptile = (ptile + tstride < ntasks) ? ptile + tstride : ptile; }
+  };
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) { issue(ptile, pcc, s); advance(); }
+  int rs = 0;                            // ring slot of the stage being computed
+  int cc = 0;                            // its K chunk
+  int stores_behind = 0;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // operands of one stage: activations b[sk] (16 pixels x 16 k) from ring slot r, weights a[sk][j] of chunk c
+  struct Ops { f32x4 b0, b1, a0[NT], a1[NT]; };
+  auto load_ops = [&](Ops& o, int r, int c) {
+    const float* const bL = bL0 + r * 128 * 4;
+    const float* const wC = wL + c * (8 * BN * 4);
+    o.b0 = *(const f32x4*)(bL); o.b1 = *(const f32x4*)(bL + 64 * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) o.a0[j] = *(const f32x4*)(wC + j * 64);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) o.a1[j] = *(const f32x4*)(wC + (4 * BN + j * 16) * 4);
+  };
+  // One stage: the matrix work on `cur`, with the NEXT stage's operands fetched into `nxt` in the middle of it (the next
+  // stage's activations were requested D - 1 stages ago: a counted wait retires them first) and the request for the stage
+  // D - 1 ahead issued at the top -- a wave alone on its SIMD keeps the matrix pipe fed.  Returns false after the wave's
+  // last tile.
+  auto stage = [&](const Ops& cur, Ops& nxt) -> bool {
+    issue(ptile, pcc, (rs == 0) ? D - 1 : rs - 1);           // into the slot consumed by the previous stage
+    advance();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = mfma16(cur.a0[j][t], cur.b0[t], acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    // stage k + 1 has landed: all but the 2 (D - 2) youngest requests (+ a just-finished tile's stores) are done
+    if (__builtin_amdgcn_readfirstlane(stores_behind)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (D - 2) + NT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (D - 2)) : "memory");
+    stores_behind = 0;
+    const int rsn = (rs == D - 1) ? 0 : rs + 1;
+    const int ncc = (cc + 1 == nchunks) ? 0 : cc + 1;
+    load_ops(nxt, rsn, ncc);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = mfma16(cur.a1[j][t], cur.b1[t], acc[j]);
+    bool more = true;
+    if (ncc == 0) {
+      // ---- tile finished: bias, (accumulate, dropout scale, ReLU-backward mask), ReLU, one 16-byte store per block ----
+      const int ysoff = (int)((unsigned)tile * 16u * (unsigned)a.y_pitch * 4u);
+      const bool whole = (long long)tile * 16 + 16 <= a.total_px && n0 + BN <= a.N;
+      if (whole && plain_epi) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) store16(sqd_relu4(acc[j] + biasv[j], relu_lo), o_offB + j * 64, ysoff);
+        stores_behind = 1;
+      } else {
+        const bool pvalid = (long long)tile * 16 + lr < a.total_px;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (!pvalid || n0 + j * 16 + 4 * g >= a.N) continue;
+          const int off = o_offB + j * 64;
+          f32x4 v = acc[j] + biasv[j];
+          if (acc_i) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, off, ysoff, 0));
+          if (has_mul) v *= __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mulres, (lr * a.ymul_pitch + 4 * g) * 4 + j * 64, (int)((unsigned)tile * 16u * (unsigned)a.ymul_pitch * 4u), 0));
+          if (has_mask) {
+            const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(maskres, (lr * a.ymask_pitch + 4 * g) * 4 + j * 64, (int)((unsigned)tile * 16u * (unsigned)a.ymask_pitch * 4u), 0));
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+          }
+          store16(sqd_relu4(v, relu_lo), off, ysoff);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      more = tile + tstride < ntasks;
+      tile += tstride;
+    }
+    rs = rsn; cc = ncc;
+    return more;
+  };
+  Ops opA, opB;
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (D - 2)) : "memory");      // stage 0 has landed
+  load_ops(opA, 0, 0);
+  for (;;) {
+    if (!stage(opA, opB)) break;
+    if (!stage(opB, opA)) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may still be in flight when the LDS is released
+#endif
+}
+
 static int sqd_num_cus() {
   static int cus = 0;                        // immutable per-process cache
   if (cus == 0) {
@@ -599,6 +790,51 @@ static int sqd_num_cus() {
     if (cus <= 0) cus = 256;
   }
   return cus;
+}
+
+template <int NT, int WV>
+static int launch_conv_ws(ConvArgs a, hipStream_t stream) {
+  constexpr int BN = 16 * NT, NTHR = WV * 64, KC = 32;
+  if (a.xmask) return SQD_ERR_UNSUPPORTED;
+  if (a.total_px * a.x_pitch * 4 >= (3ll << 30) || a.total_px * a.y_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;
+  if (a.ymul && a.total_px * a.ymul_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;
+  if (a.ymask && a.total_px * a.ymask_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;
+  const int nchunks = sqd_cdiv(a.C, KC), nplanes = nchunks * 8;
+  const int wslots = sqd_cdiv(nplanes * BN, NTHR) * NTHR;
+  // ring depth from what the weights leave of the LDS (one workgroup per CU when they are large): 2, 3, 4, 6 or 8 stages
+  const size_t wbytes = (size_t)wslots * 16, stage = (size_t)WV * 2048;
+  int D = 0;
+  for (int d : {8, 6, 4, 3}) if (wbytes + d * stage <= 160 * 1024 && (d <= 4 || wbytes + d * stage <= 80 * 1024)) { D = d; break; }
+  if (D == 0) return SQD_ERR_UNSUPPORTED;
+  const size_t lds = wbytes + D * stage;
+  a.ntiles = (int)((a.total_px + 15) / 16);
+  const int nslices = sqd_cdiv(a.N, BN);
+  if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;
+  auto go = [&](auto kern) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return (int)SQD_ERR_LAUNCH;
+      attr_set = true;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
+    int wgs_per_cu = nb > 4 ? 4 : nb;
+    if (a.wg_cap > 0 && a.wg_cap < wgs_per_cu) wgs_per_cu = a.wg_cap;
+    const int slots = sqd_num_cus() * wgs_per_cu;
+    int gx_max = slots / nslices; if (gx_max < 1) gx_max = 1;
+    const int wave_tiles = sqd_cdiv(a.ntiles, WV);            // tiles per wave stream if there were one stream
+    const int per_wg = sqd_cdiv(wave_tiles, gx_max);
+    const int gx = (sqd_cdiv(wave_tiles, per_wg) + 7) & ~7;
+    a.nslices = nslices; a.gx = gx;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gx * nslices)), dim3(NTHR), lds, stream, a);
+    return sqd_launch_status();
+  };
+  switch (D) {
+    case 8: return go(conv_ws_kernel<NT, WV, 8>);
+    case 6: return go(conv_ws_kernel<NT, WV, 6>);
+    case 4: return go(conv_ws_kernel<NT, WV, 4>);
+    default: return go(conv_ws_kernel<NT, WV, 3>);
+  }
 }
 
 template <int TAPS, int KC, int MT, int NT>
@@ -775,12 +1011,23 @@ static const ConvCfg kConvCfgs[] = {
     {1, 32, 2, 2, 2},  // 75
     {1, 16, 1, 4, 2},  // 76
     {1, 16, 2, 4, 2},  // 77
+    // ---- weight-stationary, barrier-free 1x1 (dma = 3: 4 waves, dma = 4: 8 waves); KC = 32 packing, 16-pixel wave tiles ----
+    {1, 32, 1, 1, 3},  // 78
+    {1, 32, 1, 2, 3},  // 79
+    {1, 32, 1, 3, 3},  // 80
+    {1, 32, 1, 4, 3},  // 81
+    {1, 32, 1, 6, 3},  // 82
+    {1, 32, 1, 2, 4},  // 83
+    {1, 32, 1, 3, 4},  // 84
+    {1, 32, 1, 4, 4},  // 85
+    {1, 32, 1, 6, 4},  // 86
 };
 static const int kNumConvCfgs = (int)(sizeof(kConvCfgs) / sizeof(kConvCfgs[0]));
 
 extern "C" int sqd_conv_num_cfgs() { return kNumConvCfgs; }
 
-// 0: register-staged (4 waves); 1: LDS-DMA, 4 waves; 2: LDS-DMA, 8 waves (no xmask support when != 0); -1: bad id
+// 0: register-staged (4 waves); 1: LDS-DMA, 4 waves; 2: LDS-DMA, 8 waves; 3 / 4: weight-stationary barrier-free 1x1, 4 / 8 waves
+// (no xmask support when != 0); -1: bad id
 extern "C" int sqd_conv_cfg_is_dma(int cfg_id) {
   if (cfg_id < 0 || cfg_id >= kNumConvCfgs) return -1;
   return kConvCfgs[cfg_id].dma;
@@ -791,7 +1038,7 @@ extern "C" int sqd_conv_cfg_info(int cfg_id, int* taps, int* kc, int* tile_px, i
   const ConvCfg& c = kConvCfgs[cfg_id];
   if (taps) *taps = c.taps;
   if (kc) *kc = c.kc;
-  if (tile_px) *tile_px = c.mt * (c.dma == 2 ? 8 : 4) * 16;
+  if (tile_px) *tile_px = (c.dma >= 3) ? 16 * (c.dma == 4 ? 8 : 4) : c.mt * (c.dma == 2 ? 8 : 4) * 16;
   if (bn) *bn = 16 * c.nt;
   return SQD_OK;
 }
@@ -826,6 +1073,11 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   a.total_px = (long long)B * H * W;
   hipStream_t s = (hipStream_t)stream;
   const ConvCfg& c = kConvCfgs[cfg_id];
+#define SQD_WS_CASE(Nn) \
+  if (c.dma >= 3 && c.nt == Nn) return (c.dma == 4) ? launch_conv_ws<Nn, 8>(a, s) : launch_conv_ws<Nn, 4>(a, s);
+  SQD_WS_CASE(1) SQD_WS_CASE(2) SQD_WS_CASE(3) SQD_WS_CASE(4) SQD_WS_CASE(6)
+#undef SQD_WS_CASE
+  if (c.dma >= 3) return SQD_ERR_UNSUPPORTED;
 #define SQD_DMA8_CASE(T, K, M, Nn) \
   if (c.dma == 2 && c.taps == T && c.kc == K && c.mt == M && c.nt == Nn) return launch_conv_dma<T, K, M, Nn, 8>(a, s);
   SQD_DMA8_CASE(9, 16, 1, 2) SQD_DMA8_CASE(9, 16, 1, 3) SQD_DMA8_CASE(9, 16, 1, 4) SQD_DMA8_CASE(9, 16, 2, 1)

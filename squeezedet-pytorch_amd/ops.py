@@ -99,9 +99,26 @@ def cfg_kernel_name(cfg_id):
     cfg_id %= 1000                            # + 1000 * k = workgroups-per-CU cap (see sqd_conv_fwd)
     taps, kc, px, bn = cfg_table()[cfg_id]
     d = _CFG_DMA[cfg_id]
+    if d >= 3:                                # weight-stationary, barrier-free 1x1: conv_ws<NT,WAVES>
+        return f'conv_ws<{bn // 16},{8 if d == 4 else 4}>'
     waves = 8 if d == 2 else 4
     mt = px // (16 * waves)
     return f'conv_dma<{taps},{kc},{mt},{bn // 16},{waves}>' if d else f'conv_igemm<{taps},{kc},{mt},{bn // 16}>'
+
+
+def conv_cfg_ok(cfg_id, C):
+    """Whether tile configuration ``cfg_id`` can run a layer with ``C`` input channels: the weight-stationary 1x1 family
+    (conv_ws) keeps the slice's whole weight matrix in LDS next to at least a 3-stage activation ring per wave."""
+    c = cfg_id % 1000
+    cfg_table()
+    d = _CFG_DMA[c]
+    if d < 3:
+        return True
+    bn = cfg_table()[c][3]
+    wv = 8 if d == 4 else 4
+    nthr = wv * 64
+    wslots = -(-(-(-C // 32) * 8 * bn) // nthr) * nthr
+    return wslots * 16 + 3 * wv * 2048 <= 160 * 1024
 
 
 _TUNING = None

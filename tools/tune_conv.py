@@ -127,6 +127,8 @@ def main():
                 continue
             if -(-N // bn) * bn > 2 * N and bn > 16:        # more than 2x channel padding: skip
                 continue
+            if not ops.conv_cfg_ok(cid, C):
+                continue
             try:
                 res.append((time_cfg(taps, C, N, B, h, w, cid), cid))
             except Exception as e:  # noqa: BLE001
