@@ -1,0 +1,51 @@
+"""Aggregate the two PMC passes of scratch/traffic.sh (FETCH_SIZE, WRITE_SIZE) into gpurun_out/traffic_<tag>.json: bytes per launch
+per kernel under the names bench.py uses, with the launch set recorded.  usage: python scratch/traffic_aggregate.py <tag>"""
+import sys
+TAG = sys.argv[1]
+import csv, glob, collections, json, re
+
+def short_name(k):
+    short = k.split("(")[0].replace("void ", "").strip()
+    m = re.match(r"conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), \d+>", short)
+    if m: return f"conv_igemm<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)}>"
+    # <TAPS, KC, MT, NT, WAVES, MINW, FUSE, WSTAT>: the name bench.py uses ignores MINW / WSTAT, FUSE = fused Fire expand
+    m = re.match(r"conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false), (true|false)>", short)
+    if m:
+        base = "fire_expand" if m.group(6) == "true" else "conv_dma"
+        return f"{base}<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>"
+    m = re.match(r"conv_wino_kernel<(\d+), (\d+)>", short)
+    if m: return f"conv_wino<{m.group(1)},{m.group(2)}>"
+    m = re.match(r"conv_ws_kernel<(\d+), (\d+), \d+>", short)
+    if m: return f"conv_ws<{m.group(1)},{m.group(2)}>"
+    m = re.match(r"conv_wino_pipe_kernel<(\d+), (\d+), (true|false)", short)
+    if m: return f"conv_wino_{'us' if m.group(3) == 'true' else 'dp'}<{m.group(1)},{m.group(2)}>"
+    m = re.match(r"(maxpool_fwd|maxpool_bwd)_kernel", short)
+    if m: return m.group(1)
+    m = re.match(r"(stem_pool|stem_conv|stem_wgrad)_kernel<(\d+),", short)
+    if m: return f"{m.group(1)}<{m.group(2)}>"
+    return {"maxpool_fwd_kernel": "maxpool_fwd", "maxpool_bwd_kernel": "maxpool_bwd", "detect_kernel": "detect", "detect_kernel(DetArgs)": "detect"}.get(short, short)
+
+res = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": collections.Counter()})
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("gpurun_out/pmc_%s_%s/**/*counter_collection.csv" % (TAG, C), recursive=True)[0]
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != C: continue
+        k = short_name(r["Kernel_Name"])
+        res[k][C] += float(r["Counter_Value"]); res[k]["n"][C] += 1
+out = {}
+# steps the profiled process launched eagerly (bench.py prints it): launches per step = launches profiled / steps
+steps = json.loads([l for l in open("gpurun_out/pmc_%s_FETCH_SIZE/out.json" % TAG) if l.startswith("{")][-1])["eager_steps_launched"]
+for k, v in res.items():
+    nf, nw = max(v["n"]["FETCH_SIZE"], 1), max(v["n"]["WRITE_SIZE"], 1)
+    fetch_kb, write_kb = v["FETCH_SIZE"] / nf, v["WRITE_SIZE"] / nw
+    out[k] = {"launches_profiled": nf, "fetch_size_kb_raw": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
+              "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
+              "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); average over all launches of this kernel"}
+    if nf % steps == 0:
+        out[k]["launches_per_step"] = nf // steps      # the launch set this average was taken over (checked by tests/test_profiles.py)
+out["_meta"] = {"workload": "python bench.py --mode infer --steps 3 --warmup 2 --no-cpu-baseline --no-graph (SqueezeDet bs=20 1248x384 inference)",
+                "eager_steps_profiled": steps,
+                "counters": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units; fabric-side L2 request counters: Infinity-Cache hits are included (MI355X_MICROARCH.md, HBM section), so these are L2<->fabric bytes, an upper bound of HBM bytes"}
+json.dump(out, open("gpurun_out/traffic_%s.json" % TAG, "w"), indent=1, sort_keys=True)
+for k, v in sorted(((k, v) for k, v in out.items() if k != "_meta"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:16]:
+    print(f'{k[:60]:60s} {v["hbm_bytes_per_launch"]/1e6:9.1f} MB/launch  (fetch raw {v["fetch_size_kb_raw"]/1e3:.1f} MB, write {v["write_size_kb"]/1e3:.1f} MB)')
