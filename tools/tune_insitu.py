@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--arch', default='squeezedet')
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--top', type=int, default=6, help='candidates per layer (fastest of the isolated measurement)')
+    ap.add_argument('--ws', action='store_true', help='also try every applicable weight-stationary 1x1 configuration (conv_ws, caps 0..2) on the 1x1 rows')
     ap.add_argument('--replays', type=int, default=40)
     ap.add_argument('--passes', type=int, default=1)
     ap.add_argument('--gain', type=float, default=0.0015, help='relative step-time gain a change must show (noise floor)')
@@ -91,6 +92,13 @@ def main():
         for k in keys:
             cands = sorted(full[k].get('all', {}).items(), key=lambda kv: kv[1])[:args.top]
             cands = [int(c) for c, _ in cands if int(c) != tab[k]]
+            if args.ws and k.startswith('1:'):
+                Ck, Nk = int(k.split(':')[1]), int(k.split(':')[2])
+                ct = ops.cfg_table()
+                for c in ct:
+                    bn = ct[c][3]
+                    if ops._CFG_DMA[c] >= 3 and ops.conv_cfg_ok(c, Ck) and not (-(-Nk // bn) * bn > 2 * Nk and bn > 16):
+                        cands += [c + 1000 * cap for cap in (0, 1, 2) if c + 1000 * cap != tab[k] and c + 1000 * cap not in cands]
             if k.startswith('W:'):
                 cands = [c for c in cands if c % 1000 < 4] + [c for c in cands if c % 1000 >= 4][:1]
             best_c, best_t = tab[k], base
