@@ -229,6 +229,21 @@ int sqd_fire_wino_fwd(const float* x, const float* u_packed, const float* bias3,
                       int C, int x_pitch, int x_coff, int N3, int y_coff3, int N1, int y_coff1, int Npad_total, int y_pitch,
                       int cfg_id, void* stream);
 
+/* Fire k's expand pair + torch.cat + Fire k+1's squeeze (src/model/squeezedet.py:18-22 applied twice; features[k] -> the
+ * squeeze of features[k+1] in squeezedet.py:43-61) in ONE launch (inference): y[..., y_coff : +Nsq] =
+ * ReLU(Wsq . cat(ReLU(conv1x1(x) + b1), ReLU(conv3x3(x) + b3)) + bsq); the concatenated expand output never reaches HBM.
+ * u_packed from sqd_pack_wino_fire.  bias_tab [Npad_total/32][8][16] floats: per 32-wide slice of the packed axis the biases of
+ * its 16-channel blocks (expand3x3 slice s: blocks 0, 1 = b3[32 s + 16 j + n]; expand1x1 slice s: 8 blocks = b1[128 s + 16 blk + n];
+ * 0 where padded).  sq_ops [blocks][4][ceil(Nsq/16)][64] floats, blocks in the same order (2 per expand3x3 slice, then 8 per
+ * expand1x1 slice): value at (block, t, q, lane = 16 g + lr) = Wsq[16 q + lr][cat channel of (block, 4 g + t)], 0 where padded.
+ * sq_bias [Nsq].  Nsq <= 32.  cfg_id 10: U resident in LDS (needs (Npad_total/32)*(C/8)*16 KB + 32 KB + operands <= 160 KB), 6: streamed;
+ * + 1000*k = workgroups-per-CU cap.  cfg_id 12 (C <= 16; the transformed input of a group stays in registers, 16-wide passes):
+ * bias_tab [passes][4][16], passes = 2*ceil(N3/32) expand3x3 passes (block 0 = b3[16 p + n]) then 2*ceil(N1/128) expand1x1 passes s1
+ * (block r = b1[128 (s1 >> 1) + (2 r + (s1 & 1)) 16 + n]); sq_ops blocks in that order (1 per expand3x3 pass, 4 per expand1x1 pass). */
+int sqd_fire_bridge_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                        float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total, int Nsq,
+                        int y_pitch, int y_coff, int cfg_id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
         saved['image'] = image
     drop_applied = False
     unpooled = None                            # inference: a pool whose output only feeds the next squeeze is folded into it
+    bridged = None                             # inference: the next Fire's squeeze output, produced by the previous Fire's launch
     for i in range(first, len(layers)):
         l = layers[i]
         if l[0] == 'pool':
@@ -66,21 +67,37 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
         else:
             _, cin, s, e1, e3 = l
             fire = feats[i]
-            if unpooled is not None:
+            if bridged is not None:
+                Bq, H, W, _ = bridged.shape
+                C = cin
+            elif unpooled is not None:
                 Bq, Hu, Wu, C = unpooled.shape
                 H, W = ops.pool_out_size(Hu, Wu)
             else:
                 Bq, H, W, C = a.shape
             assert C == cin, f'layer {i}: expected {cin} channels, got {C}'
             npix = Bq * H * W
-            sq = torch.empty(Bq, H, W, s, device=a.device, dtype=torch.float32)
-            if unpooled is not None:
-                ops.pool_squeeze(unpooled, 0, cin, base.plan(f'{i}.squeeze@pool', fire.squeeze, ops.POOL_SQUEEZE_CFG), sq, 0)
-                unpooled = None
+            if bridged is not None:
+                sq, bridged = bridged, None
             else:
-                ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
-            out = torch.empty(Bq, H, W, e1 + e3, device=a.device, dtype=torch.float32)
+                sq = torch.empty(Bq, H, W, s, device=a.device, dtype=torch.float32)
+                if unpooled is not None:
+                    ops.pool_squeeze(unpooled, 0, cin, base.plan(f'{i}.squeeze@pool', fire.squeeze, ops.POOL_SQUEEZE_CFG), sq, 0)
+                    unpooled = None
+                else:
+                    ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
             fusable = not save and not (drop_mask is not None and i == len(layers) - 1)
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            if fusable and nxt is not None and nxt[0] == 'fire' and base.fuse_fire_bridge and base.use_winograd:
+                ycfg = ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix)
+                if ycfg is not None:
+                    # inference: this Fire's expand pair AND the next Fire's squeeze in one launch; the concatenated expand
+                    # output (the next layer's only consumer is that squeeze) is never written
+                    bridged = torch.empty(Bq, H, W, nxt[2], device=sq.device, dtype=torch.float32)
+                    ops.fire_bridge(sq, 0, base.fire_bridge_plan(i, fire, feats[i + 1], ycfg), bridged, 0)
+                    a = None
+                    continue
+            out = torch.empty(Bq, H, W, e1 + e3, device=sq.device, dtype=torch.float32)
             xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fusable and base.fuse_expand_wino and base.use_winograd) else None
             fcfg = ops.choose_fused_cfg(s, e1, npix) if (fusable and xcfg is None and base.fuse_expand and e1 == e3) else None
             if xcfg is not None:

@@ -64,6 +64,9 @@ struct WinoArgs {
   // slices [nslices3, nslices) are expand1x1 slices of 128 channels (N1, y_coff1, bias1) riding in the same launch
   int nslices3, N1, y_coff1;
   const float* bias1;
+  // Fire -> Fire bridge (sqd_fire_bridge_fwd, wino_bridge.h): the next squeeze as MFMA operands, bias tables, its width
+  const float* br_w; const float* br_bias; const float* br_sqb;
+  int br_nsq;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w_t;
@@ -852,6 +855,8 @@ static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
   return sqd_launch_status();
 }
 
+#include "wino_bridge.h"
+
 template <int NT, int WV>
 static int launch_wino(WinoArgs a, hipStream_t stream) {
   constexpr int BN = 16 * NT, NTHR = WV * 64;
@@ -1071,6 +1076,45 @@ extern "C" int sqd_fire_wino_fwd(const float* x, const float* u_packed, const fl
     case 6: return launch_wino_pipe<2, 4, false, true>(a, s);
     case 8: return launch_wino_pipe<2, 8, true, true>(a, s);
     case 10: return launch_wino_pipe<2, 4, true, true>(a, s);
+  }
+  return SQD_ERR_UNSUPPORTED;
+}
+
+// Fire k's two expand convolutions + torch.cat + Fire k+1's squeeze convolution (src/model/squeezedet.py:18-22, twice) in ONE
+// launch: y[..., y_coff : y_coff + Nsq] = ReLU(Wsq . cat(ReLU(conv1x1(x) + b1), ReLU(conv3x3(x) + b3)) + bsq); the
+// concatenated expand output is never written (inference forward).  u_packed from sqd_pack_wino_fire (Npad_total wide);
+// bias_tab [Npad_total/32][8][16]: per pass (32-wide slice of the packed axis) the biases of its channel blocks (expand3x3
+// slice: blocks 0, 1; expand1x1 slice: 8 blocks of its 128 channels; 0 where padded); sq_ops [blocks][4][ceil(Nsq/16)][64]:
+// the squeeze weights as MFMA A operands, blocks in pass order, value for lane (lr, g) at (block, t, q) =
+// Wsq[16 q + lr][channel(block) + 4 g + t] (0 where padded).  cfg_id 10: U resident in LDS (small C), 6: streamed through the
+// ring; four waves per workgroup, one workgroup per CU (the wave owns 512 registers: 128 + 16..32 accumulators).
+// cfg_id 12 (C <= 16): 16-wide passes, the group's transformed input stays in registers, eight waves; its bias_tab is
+// [passes][4][16] and its sq_ops blocks follow ITS pass order: one block per expand3x3 pass (2 ceil(N3/32) passes of 16
+// channels), then four per expand1x1 pass s1 (channels 128 (s1 >> 1) + (2 r + (s1 & 1)) 16 + n, r = 0..3).
+extern "C" int sqd_fire_bridge_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                                   float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total,
+                                   int Nsq, int y_pitch, int y_coff, int cfg_id, void* stream) {
+  SQD_CHECK_ARG(x && u_packed && bias_tab && sq_ops && y && B > 0 && H > 0 && W > 0 && C > 0 && N3 > 0 && N1 > 0 && Nsq > 0);
+  SQD_CHECK_ARG(C % 8 == 0 && N3 % 4 == 0 && N1 % 16 == 0 && Nsq % 4 == 0 && Nsq <= 32);
+  SQD_CHECK_ARG(x_pitch % 4 == 0 && x_coff % 4 == 0 && y_pitch % 4 == 0 && y_coff % 4 == 0);
+  SQD_CHECK_ARG(x_coff >= 0 && x_coff + C <= x_pitch && y_coff >= 0 && y_coff + Nsq <= y_pitch);
+  SQD_CHECK_ARG(Npad_total == sqd_cdiv(N3, 32) * 32 + sqd_cdiv(N1, 128) * 32);
+  SQD_CHECK_ARG((long long)W * 6 * (x_pitch > y_pitch ? x_pitch : y_pitch) * 4 < (1ll << 30));
+  SQD_CHECK_ARG((long long)B * H * W * x_pitch * 4 < (1ll << 32) - (1ll << 30));
+  SQD_CHECK_ARG((long long)(C >> 3) * 16 * Npad_total * 8 * 4 < (1ll << 32));
+  const int cap = cfg_id / 1000; cfg_id %= 1000;
+  WinoArgs a{};
+  a.x = x; a.u = u_packed; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.N = N3; a.Npad = Npad_total; a.y_pitch = y_pitch; a.y_coff = y_coff; a.relu = 1; a.wg_cap = cap;
+  a.N1 = N1; a.nslices3 = sqd_cdiv(N3, 32);
+  a.br_w = sq_ops; a.br_bias = bias_tab; a.br_sqb = sq_bias; a.br_nsq = Nsq;
+  hipStream_t s = (hipStream_t)stream;
+  const bool one = Nsq <= 16;
+  switch (cfg_id) {
+    case 6: return one ? launch_wino_bridge<4, false, 1>(a, s) : launch_wino_bridge<4, false, 2>(a, s);
+    case 10: return one ? launch_wino_bridge<4, true, 1>(a, s) : launch_wino_bridge<4, true, 2>(a, s);
+    case 12: return one ? launch_wino_bridge16<1>(a, s) : launch_wino_bridge16<2>(a, s);
   }
   return SQD_ERR_UNSUPPORTED;
 }

@@ -1,0 +1,739 @@
+// Fire -> Fire bridge (included by conv_wino.hip): the two expand convolutions of Fire k AND the squeeze convolution of
+// Fire k+1 in one launch, so that the concatenated expand output -- the widest tensor of the early network, 153 MB
+// written and read again at 1248x384 bs=20 -- never exists (reference: src/model/squeezedet.py:18-22, Fire.forward twice:
+// cat(relu(e1(s)), relu(e3(s))) -> relu(squeeze'(.)); inference only, the training forward keeps every activation).
+//
+// Built on the deep-prefetch Winograd machinery above (wave-private patch ring filled by LDS-DMA, counted vmcnt waits,
+// 16 tiles x 32 channels x 16 positions per wave in 32 accumulators).  One wave takes a 4x16-pixel group through P
+// "passes": the expand3x3 slices (32 channels each), then the expand1x1 slices in Winograd form (128 channels x the four
+// inner positions, see wino_pipe_body).  Behind the last chunk of a pass the accumulators are inverse-transformed, get
+// their ReLU and -- instead of being stored -- are multiplied into the next squeeze: the inverse transform leaves lane
+// (tile, g) holding channels 4g..4g+3 of a 16-channel block for the tile's four pixels, which IS the B operand
+// (k = g, column = tile) of v_mfma_f32_16x16x4_f32 for input channel 4g + t, t = 0..3; the A operand is the matching
+// column of the squeeze weights, pre-arranged by the host (sq_ops[block][t][q][lane]).  Four more accumulators per 16
+// squeeze channels collect the result over all passes; bias + ReLU + one 16-byte store per pixel finish the group.
+// The patch of a chunk is re-requested for every pass (L2 hits); U is resident (USTAT) or streamed through the ring.
+template <int WV, bool USTAT, int NSQ>
+__device__ __forceinline__ void wino_bridge_body(const WinoArgs& a) {
+  constexpr int NT = 2;
+  constexpr int NTHR = WV * 64;
+  constexpr int BN = 16 * NT;
+  constexpr int RP = 113;
+  constexpr int RAW_IT = 4;
+  constexpr int USLOTS = 32 * BN;
+  constexpr int U_IT = USLOTS / NTHR;
+  constexpr int NDMA = RAW_IT + (USTAT ? 0 : U_IT);
+  constexpr int NSTB = 4 * NSQ;                // store instructions of a whole group
+  constexpr int NSTEP = 8;
+  constexpr int RAW_STEPS = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int P = a.nslices, P3 = a.nslices3;
+  const int nchunks = a.C >> 3;
+  float* const rawB = smem;                                         // [2][WV][256][4]
+  float* const UB = rawB + 2 * WV * 256 * 4;                        // [3 | P * C/8][USLOTS][4]
+  float* const sqAL = UB + (USTAT ? P * nchunks : 3) * USLOTS * 4;  // [blocks][4 t][NSQ][64 lanes]
+  const int nblk = 2 * P3 + 8 * (P - P3);
+  float* const biasL = sqAL + nblk * 4 * NSQ * 64;                  // [P][8 blocks][16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int tstride = a.gx;
+  const int ntiles = a.ntiles;
+  int tile = (int)blockIdx.x;
+  if (tile >= ntiles) return;
+  const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+
+  constexpr unsigned OOB = 0x80000000u;
+  int r_offB[RAW_IT], r_key[RAW_IT];
+#pragma unroll
+  for (int it = 0; it < RAW_IT; ++it) {
+    const int slot = it * 64 + lane;
+    const int kq = slot / RP, pix = slot - kq * RP;
+    const bool real = kq < 2 && pix < 108;
+    const int r = pix / 18, c = pix - r * 18;
+    r_key[it] = real ? (r << 8 | c) : -1;
+    r_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * kq) * 4 : 0;
+  }
+  int u_offB[U_IT];
+#pragma unroll
+  for (int it = 0; it < U_IT; ++it) {
+    const int slot = it * NTHR + tid;
+    const int pp = slot / (4 * BN), rem = slot - pp * (4 * BN);
+    u_offB[it] = (pp * a.Npad * 16 + rem * 4) * 4;
+  }
+  const unsigned u_chunkB = 16u * a.Npad * 8u * 4u;
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + a.x_coff - (long long)(a.W + 1) * a.x_pitch), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, 0x7ffffff0, 0x00020000);
+
+  struct GPos { int y0, x0, inner, valid; long long p0; unsigned soff; };
+  auto group_pos = [&](int t) {
+    GPos gp;
+    int q = t * WV + wv_s;
+    gp.valid = (int)((unsigned)(q - a.ngroups) >> 31);
+    q = gp.valid ? q : a.ngroups - 1;
+    const int q1 = a.gxn_m ? (int)__umulhi((unsigned)q, a.gxn_m) : q;
+    const int gxi = q - q1 * a.gxn;
+    const int b = a.gyn_m ? (int)__umulhi((unsigned)q1, a.gyn_m) : q1;
+    const int gyi = q1 - b * a.gyn;
+    gp.y0 = gyi * 4; gp.x0 = gxi * 16;
+    gp.p0 = ((long long)b * a.H + gp.y0) * a.W + gp.x0;
+    gp.soff = (unsigned)(gp.p0 * a.x_pitch * 4);
+    gp.inner = (int)(((unsigned)(-gp.y0) & (unsigned)(gp.y0 + 4 - a.H) & (unsigned)(-gp.x0) & (unsigned)(gp.x0 + 16 - a.W)) >> 31);
+    return gp;
+  };
+  int r_offG[RAW_IT];
+  auto group_offsets = [&](int y0, int x0, int inner) {
+    if (inner) {
+#pragma unroll
+      for (int it = 0; it < RAW_IT; ++it) r_offG[it] = r_offB[it];
+      return;
+    }
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+      const int key = r_key[it];
+      const bool ok = key >= 0 && (unsigned)(y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(x0 + (key & 255) - 1) < (unsigned)a.W;
+      r_offG[it] = ok ? r_offB[it] : (int)OOB;
+    }
+  };
+  float* const rawW = rawB + wv_s * 256 * 4;
+  auto dma_raw_one = [&](int it, unsigned soff, int rb) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_w_t)(rawW + (rb * WV * 256 + it * 64) * 4), 16, r_offG[it], (int)soff, 0, 0);
+  };
+  // U of (pass, chunk) into ring / resident slot `slot`; a pass is a 32-wide slice of the packed virtual channel axis
+  auto dma_u_one = [&](int it, int pass, int cc, int slot) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ures, (lds_ptr_w_t)(UB + (slot * USLOTS + it * NTHR + wv_s * 64) * 4), 16, u_offB[it],
+                                             (int)(cc * u_chunkB + (unsigned)pass * (BN * 64u)), 0, 0);
+  };
+
+  f32x4 acc[16][NT];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc_sq[4][NSQ], sqb[NSQ];
+#pragma unroll
+  for (int q = 0; q < NSQ; ++q) {
+    const int n = q * 16 + 4 * g;
+    sqb[q] = (a.br_sqb && n < a.br_nsq) ? *(const f32x4*)(a.br_sqb + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int px = 0; px < 4; ++px) acc_sq[px][q] = sqb[q];
+  }
+  const float oneB = (g == 0) ? 1.f : 0.f;
+  const int ty = lr >> 3, tx = lr & 7;
+  int o_offB[4];
+#pragma unroll
+  for (int px = 0; px < 4; ++px) o_offB[px] = (((2 * ty + (px >> 1)) * a.W + 2 * tx + (px & 1)) * a.y_pitch + 4 * g) * 4;
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff), 0, 0x7ffffff0, 0x00020000);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  auto store16 = [&](f32x4 v, __amdgpu_buffer_rsrc_t res, int voff, int soff) {      // (hazard: see wino_pipe_body)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), res, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int tt = lr, cp = g;
+  const int rawL_off = (((cp >> 1) * RP + (2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 4 + 2 * (cp & 1));
+  const float* const uR0 = UB + g * 64 + lr * 4;
+
+  // ---- prefetch cursor: two stages ahead of the compute cursor; a stage = (pass, chunk) of a tile ----
+  GPos cur = group_pos(tile);
+  int ptile = tile, ppass = 0, pcc = 0;
+  unsigned psoff = cur.soff;
+  group_offsets(cur.y0, cur.x0, cur.inner);
+  auto advance = [&]() {
+    ++pcc;
+    if (pcc == nchunks) {
+      pcc = 0;
+      ++ppass;
+      if (ppass == P) {
+        ppass = 0;
+        ptile = (ptile + tstride < ntiles) ? ptile + tstride : ptile;
+        const GPos pf = group_pos(ptile);
+        psoff = pf.soff;
+        group_offsets(pf.y0, pf.x0, pf.inner);
+      }
+    }
+  };
+  // squeeze operands + bias table into LDS (plain loads), the resident U by DMA; one barrier publishes all of it
+  for (int i = tid; i < nblk * 4 * NSQ * 64; i += NTHR) sqAL[i] = a.br_w[i];
+  for (int i = tid; i < P * 8 * 16; i += NTHR) biasL[i] = a.br_bias[i];
+  if (USTAT) {
+    for (int ps = 0; ps < P; ++ps)
+      for (int c = 0; c < nchunks; ++c)
+#pragma unroll
+        for (int it = 0; it < U_IT; ++it) dma_u_one(it, ps, c, ps * nchunks + c);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (!USTAT) {
+#pragma unroll
+      for (int it = 0; it < U_IT; ++it) dma_u_one(it, ppass, pcc, s);
+    }
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) dma_raw_one(it, psoff + (unsigned)pcc * 32u, s);
+    advance();
+  }
+  int ub = 0, rb = 0;
+  int stores_behind = 0;
+
+  for (;;) {
+    const bool more = tile + tstride < ntiles;
+    for (int pass = 0; pass < P; ++pass) {
+      const bool is_e1 = pass >= P3;
+      const int e1_c0 = (pass - P3) * 128;
+      const bool e1_half = is_e1 && (a.N1 - e1_c0 <= 64);      // only channel blocks 0..3 exist: the odd MFMA steps are all padding
+      for (int cc = 0; cc < nchunks; ++cc) {
+        {
+          const int sb = __builtin_amdgcn_readfirstlane(stores_behind);
+          if (sb == NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + NSTB) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        }
+        if (!USTAT) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stores_behind = 0;
+        const bool last = cc + 1 == nchunks;
+        const int ub2 = (ub >= 1) ? ub - 1 : 2;
+        if (!USTAT) {
+#pragma unroll
+          for (int it = 0; it < U_IT; ++it) dma_u_one(it, ppass, pcc, ub2);
+        }
+        const unsigned nsoff = psoff + (unsigned)pcc * 32u;
+        const float* const uR = uR0 + (USTAT ? pass * nchunks + cc : ub) * USLOTS * 4;
+        const float* const rawL = rawW + rb * WV * 256 * 4 + rawL_off;
+        const float* const bL = biasL + pass * 128 + lr;
+
+        // KIND 0: expand3x3 slice; 1: expand1x1 slice; 2: expand1x1 slice whose upper four channel blocks are padding
+        auto stage = [&](auto kind_c, auto first_c) {
+          constexpr int KIND = decltype(kind_c)::value;
+          constexpr bool FIRST = decltype(first_c)::value;
+          constexpr bool E1 = KIND != 0;
+          f32x2 vv[16];
+          float bA[E1 ? 8 : 2];
+          if constexpr (FIRST) {
+#pragma unroll
+            for (int k = 0; k < (E1 ? (KIND == 2 ? 4 : 8) : 2); ++k) bA[k] = bL[k * 16];
+          }
+          if constexpr (E1) {
+            const f32x2 d11 = *(const f32x2*)(rawL + (1 * 18 + 1) * 4), d12 = *(const f32x2*)(rawL + (1 * 18 + 2) * 4);
+            const f32x2 d21 = *(const f32x2*)(rawL + (2 * 18 + 1) * 4), d22 = *(const f32x2*)(rawL + (2 * 18 + 2) * 4);
+            const f32x2 t11 = d11 + d21, t12 = d12 + d22, t21 = d21 - d11, t22 = d22 - d12;
+            vv[5] = t11 + t12; vv[6] = t12 - t11; vv[9] = t21 + t22; vv[10] = t22 - t21;
+          } else {
+            f32x2 t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * 4), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * 4);
+              const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * 4), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * 4);
+              t[0][j] = d0 - d2; t[1][j] = d1 + d2; t[2][j] = d2 - d1; t[3][j] = d1 - d3;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              vv[i * 4 + 0] = t[i][0] - t[i][2]; vv[i * 4 + 1] = t[i][1] + t[i][2];
+              vv[i * 4 + 2] = t[i][2] - t[i][1]; vv[i * 4 + 3] = t[i][1] - t[i][3];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+
+          auto load_ops = [&](int step, f32x4 (&afr)[NT]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) afr[j] = *(const f32x4*)(uR + (step * NT + j) * 256);
+          };
+          auto mfma_pos = [&](int step, const f32x4 (&afr)[NT], int h) {
+            const int p = 2 * step + h;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                const int pv = E1 ? ((p >> 2) == 0 ? 5 : (p >> 2) == 1 ? 6 : (p >> 2) == 2 ? 9 : 10) : p;
+                f32x4 c0v;
+                if (FIRST && t == 0) {
+                  c0v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                  if (E1 ? (p < 4) : (p == 5)) c0v = mfma16(bA[E1 ? (p & 3) * 2 + j : j], oneB, c0v);   // bias: rank-1 product into m11
+                } else {
+                  c0v = acc[p][j];
+                }
+                acc[p][j] = mfma16(afr[j][2 * h + t], vv[pv][t], c0v);
+              }
+          };
+          constexpr int SSTEP = (KIND == 2) ? 2 : 1;       // KIND 2: virtual positions 4q+2, 4q+3 (odd steps) are padding
+          f32x4 af0[NT], af1[NT];
+          load_ops(0, af0);
+#pragma unroll
+          for (int si = 0; si < NSTEP / SSTEP; ++si) {
+            const int step = si * SSTEP;
+#pragma unroll
+            for (int q = 0; q < RAW_IT; ++q)
+              if (q * RAW_STEPS / RAW_IT == si) dma_raw_one(q, nsoff, rb);
+            if (si & 1) {
+              mfma_pos(step, af1, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (si + 1 < NSTEP / SSTEP) load_ops(step + SSTEP, af0);
+              __builtin_amdgcn_sched_barrier(0);
+              mfma_pos(step, af1, 1);
+            } else {
+              mfma_pos(step, af0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (si + 1 < NSTEP / SSTEP) load_ops(step + SSTEP, af1);
+              __builtin_amdgcn_sched_barrier(0);
+              mfma_pos(step, af0, 1);
+            }
+          }
+        };
+        if (!is_e1) { if (cc == 0) stage(std::integral_constant<int, 0>{}, std::true_type{}); else stage(std::integral_constant<int, 0>{}, std::false_type{}); }
+        else if (!e1_half) { if (cc == 0) stage(std::integral_constant<int, 1>{}, std::true_type{}); else stage(std::integral_constant<int, 1>{}, std::false_type{}); }
+        else { if (cc == 0) stage(std::integral_constant<int, 2>{}, std::true_type{}); else stage(std::integral_constant<int, 2>{}, std::false_type{}); }
+        advance();
+
+        if (last) {
+          // ---- this pass's channels: inverse transform, ReLU, then straight into the next squeeze ----
+          auto squeeze_in = [&](int bi, const f32x4 (&ov)[4]) {
+            const float* const sA = sqAL + bi * (4 * NSQ * 64) + lane;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              float wa[NSQ];
+#pragma unroll
+              for (int q = 0; q < NSQ; ++q) wa[q] = sA[(t * NSQ + q) * 64];
+#pragma unroll
+              for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int q = 0; q < NSQ; ++q) acc_sq[px][q] = mfma16(wa[q], ov[px][t], acc_sq[px][q]);
+            }
+          };
+          if (is_e1) {
+            const int bi0 = 2 * P3 + 8 * (pass - P3);
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+              if (e1_c0 + blk * 16 >= a.N1) continue;
+              const f32x4 m0 = acc[0 + (blk >> 1)][blk & 1], m1 = acc[4 + (blk >> 1)][blk & 1];
+              const f32x4 m2 = acc[8 + (blk >> 1)][blk & 1], m3 = acc[12 + (blk >> 1)][blk & 1];
+              const f32x4 s01 = m0 + m1, d01 = m0 - m1, s23 = m2 + m3, d23 = m2 - m3;
+              const f32x4 ov[4] = {wino_relu4(s01 + s23, 0.f), wino_relu4(d01 + d23, 0.f), wino_relu4(s01 - s23, 0.f), wino_relu4(d01 - d23, 0.f)};
+              squeeze_in(bi0 + blk, ov);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              auto inv = [&](auto half, auto put) {
+                f32x2 sx[4][2];
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                  const f32x2 m0 = half(acc[xi * 4 + 0][j]), m1 = half(acc[xi * 4 + 1][j]);
+                  const f32x2 m2 = half(acc[xi * 4 + 2][j]), m3 = half(acc[xi * 4 + 3][j]);
+                  sx[xi][0] = m0 + m1 + m2;
+                  sx[xi][1] = m1 - (m2 + m3);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                  put(0 * 2 + b, sx[0][b] + sx[1][b] + sx[2][b]);
+                  put(1 * 2 + b, sx[1][b] - (sx[2][b] + sx[3][b]));
+                }
+              };
+              f32x4 ov[4];
+              inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
+              inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
+#pragma unroll
+              for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
+              squeeze_in(2 * pass + j, ov);
+            }
+          }
+          if (pass == P - 1) {
+            // ---- the group's squeeze output: ReLU + store; the accumulators restart from the bias ----
+            if (cur.valid) {
+              const int ysoff = (int)(unsigned)(cur.p0 * a.y_pitch * 4);
+              const bool whole = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W && NSQ * 16 <= a.br_nsq;
+#pragma unroll
+              for (int px = 0; px < 4; ++px) {
+                const bool valid = whole || (cur.y0 + 2 * ty + (px >> 1) < a.H && cur.x0 + 2 * tx + (px & 1) < a.W);
+#pragma unroll
+                for (int q = 0; q < NSQ; ++q) {
+                  if (!valid || q * 16 + 4 * g >= a.br_nsq) continue;
+                  store16(wino_relu4(acc_sq[px][q], 0.f), yres, o_offB[px] + q * 64, ysoff);
+                }
+              }
+              stores_behind = whole ? NSTB : 0;
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+              for (int q = 0; q < NSQ; ++q) acc_sq[px][q] = sqb[q];
+          }
+        }
+        ub = (ub == 2) ? 0 : ub + 1;
+        rb ^= 1;
+      }
+    }
+    if (!more) break;
+    tile += tstride;
+    cur = group_pos(tile);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int WV, bool USTAT, int NSQ>
+__global__ __launch_bounds__(WV * 64, 1) void fire_bridge_kernel(WinoArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  wino_bridge_body<WV, USTAT, NSQ>(a);
+#endif
+}
+
+template <int WV, bool USTAT, int NSQ>
+static int launch_wino_bridge(WinoArgs a, hipStream_t stream) {
+  constexpr int NTHR = WV * 64, USLOTS = 32 * 32;
+  const int P = a.Npad / 32, nchunks = a.C >> 3;
+  const int nblk = 2 * a.nslices3 + 8 * (P - a.nslices3);
+  const size_t lds = (size_t)(2 * WV * 256 * 4 + (USTAT ? P * nchunks : 3) * USLOTS * 4 + nblk * 4 * NSQ * 64 + P * 128) * sizeof(float);
+  if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
+  auto kern = fire_bridge_kernel<WV, USTAT, NSQ>;
+  if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
+  const int wgs_per_cu = nb > 4 ? 4 : nb;
+  a.gxn = sqd_cdiv(a.W, 16); a.gyn = sqd_cdiv(a.H, 4);
+  a.ngroups = a.B * a.gxn * a.gyn;
+  if ((long long)(a.ngroups + 8) * (a.gxn > a.gyn ? a.gxn : a.gyn) >= (1ll << 32)) return SQD_ERR_UNSUPPORTED;
+  a.gxn_m = a.gxn > 1 ? (unsigned)(((1ull << 32) + a.gxn - 1) / a.gxn) : 0u; a.gyn_m = a.gyn > 1 ? (unsigned)(((1ull << 32) + a.gyn - 1) / a.gyn) : 0u;
+  a.ntiles = sqd_cdiv(a.ngroups, WV);
+  const int slots = wino_num_cus() * ((a.wg_cap > 0 && a.wg_cap < wgs_per_cu) ? a.wg_cap : wgs_per_cu);
+  const int per_wg = sqd_cdiv(a.ntiles, slots);
+  const int gx = sqd_cdiv(a.ntiles, per_wg);
+  a.nslices = P; a.gx = gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NTHR), lds, stream, a);
+  return sqd_launch_status();
+}
+
+// ---- small-C form (C <= 16: the first Fire of SqueezeDet, squeeze width 16) ----
+// With at most two 8-channel chunks the transformed input of a group fits in registers (2 x 16 register pairs), so the patch
+// is fetched and transformed ONCE per group and every pass only streams its U from LDS.  Passes are 16 channels wide (16
+// accumulators): eight waves per workgroup, two per SIMD, so one wave's transforms and epilogues run under the other's matrix
+// work; no workgroup barrier after the operands are in LDS.  An expand1x1 pass holds 4 positions x 64 channels (virtual
+// channel slice `s1` of the packed axis: channels 128 (s1 >> 1) + (2 r + (s1 & 1)) 16 + n, r = 0..3); when r = 2, 3 are all
+// padding (N1 <= 64) only the even position pairs are kept in LDS and multiplied.
+template <int NSQ>
+__device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
+  constexpr int WV = 8, NTHR = WV * 64, RP = 113, RAW_IT = 4, NSTB = 4 * NSQ;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int P3 = a.nslices3, P = a.nslices;            // 16-wide passes: expand3x3, then expand1x1
+  const int nchunks = a.C >> 3;                        // 1 or 2
+  const bool e1_half = a.N1 <= 64;
+  const int e1_stage = e1_half ? 1024 : 2048;          // floats per (pass, chunk) of U in LDS
+  float* const rawB = smem;                            // [2 chunks][WV][256][4]
+  float* const UB = rawB + 2 * WV * 256 * 4;           // expand3x3: [P3][nchunks][2048]; expand1x1: [P - P3][nchunks][e1_stage]
+  float* const U1B = UB + P3 * nchunks * 2048;
+  float* const sqAL = U1B + (P - P3) * nchunks * e1_stage;      // [P3 + 4 (P - P3) blocks][4 t][NSQ][64 lanes]
+  const int nblk = P3 + 4 * (P - P3);
+  float* const biasL = sqAL + nblk * 4 * NSQ * 64;     // [P][4][16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int tstride = a.gx;
+  const int ntiles = a.ntiles;
+  int tile = (int)blockIdx.x;
+  if (tile >= ntiles) return;
+  const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+
+  constexpr unsigned OOB = 0x80000000u;
+  int r_offB[RAW_IT], r_key[RAW_IT];
+#pragma unroll
+  for (int it = 0; it < RAW_IT; ++it) {
+    const int slot = it * 64 + lane;
+    const int kq = slot / RP, pix = slot - kq * RP;
+    const bool real = kq < 2 && pix < 108;
+    const int r = pix / 18, c = pix - r * 18;
+    r_key[it] = real ? (r << 8 | c) : -1;
+    r_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * kq) * 4 : 0;
+  }
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + a.x_coff - (long long)(a.W + 1) * a.x_pitch), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, 0x7ffffff0, 0x00020000);
+
+  struct GPos { int y0, x0, inner, valid; long long p0; unsigned soff; };
+  auto group_pos = [&](int t) {
+    GPos gp;
+    int q = t * WV + wv_s;
+    gp.valid = (int)((unsigned)(q - a.ngroups) >> 31);
+    q = gp.valid ? q : a.ngroups - 1;
+    const int q1 = a.gxn_m ? (int)__umulhi((unsigned)q, a.gxn_m) : q;
+    const int gxi = q - q1 * a.gxn;
+    const int b = a.gyn_m ? (int)__umulhi((unsigned)q1, a.gyn_m) : q1;
+    const int gyi = q1 - b * a.gyn;
+    gp.y0 = gyi * 4; gp.x0 = gxi * 16;
+    gp.p0 = ((long long)b * a.H + gp.y0) * a.W + gp.x0;
+    gp.soff = (unsigned)(gp.p0 * a.x_pitch * 4);
+    gp.inner = (int)(((unsigned)(-gp.y0) & (unsigned)(gp.y0 + 4 - a.H) & (unsigned)(-gp.x0) & (unsigned)(gp.x0 + 16 - a.W)) >> 31);
+    return gp;
+  };
+  float* const rawW = rawB + wv_s * 256 * 4;
+  auto dma_group = [&](const GPos& gp) {               // both chunks of a group's patch into this wave's two buffers
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+      const int key = r_key[it];
+      const bool ok = gp.inner ? true : (key >= 0 && (unsigned)(gp.y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(gp.x0 + (key & 255) - 1) < (unsigned)a.W);
+      const int off = ok ? r_offB[it] : (int)OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_w_t)(rawW + (it * 64) * 4), 16, off, (int)gp.soff, 0, 0);
+      if (nchunks > 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_w_t)(rawW + (WV * 256 + it * 64) * 4), 16, off, (int)(gp.soff + 32u), 0, 0);
+    }
+  };
+
+  // ---- operands into LDS, once: U of every pass (wave w brings position pair w of each stage), squeeze operands, biases ----
+  {
+    const int u_lane = (g * 16 + lr) * 16;             // byte offset of this lane's 16-byte slot inside a (position pair, block)
+    const unsigned u_chunkB = 16u * a.Npad * 8u * 4u;
+    for (int ps = 0; ps < P; ++ps)
+      for (int c = 0; c < nchunks; ++c) {
+        const bool is1 = ps >= P3;
+        if (is1 && e1_half && (wv_s & 1)) continue;
+        float* const dst = is1 ? U1B + ((ps - P3) * nchunks + c) * e1_stage + (e1_half ? (wv_s >> 1) : wv_s) * 256
+                               : UB + (ps * nchunks + c) * 2048 + wv_s * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ures, (lds_ptr_w_t)dst, 16, u_lane + wv_s * a.Npad * 64,
+                                                 (int)(c * u_chunkB + (unsigned)ps * 1024u), 0, 0);
+      }
+    for (int i = tid; i < nblk * 4 * NSQ * 64; i += NTHR) sqAL[i] = a.br_w[i];
+    for (int i = tid; i < P * 64; i += NTHR) biasL[i] = a.br_bias[i];
+  }
+  GPos cur = group_pos(tile);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  dma_group(cur);
+
+  f32x4 acc[16];
+  f32x4 acc_sq[4][NSQ], sqb[NSQ];
+#pragma unroll
+  for (int q = 0; q < NSQ; ++q) {
+    const int n = q * 16 + 4 * g;
+    sqb[q] = (a.br_sqb && n < a.br_nsq) ? *(const f32x4*)(a.br_sqb + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int px = 0; px < 4; ++px) acc_sq[px][q] = sqb[q];
+  }
+  const float oneB = (g == 0) ? 1.f : 0.f;
+  const int ty = lr >> 3, tx = lr & 7;
+  int o_offB[4];
+#pragma unroll
+  for (int px = 0; px < 4; ++px) o_offB[px] = (((2 * ty + (px >> 1)) * a.W + 2 * tx + (px & 1)) * a.y_pitch + 4 * g) * 4;
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff), 0, 0x7ffffff0, 0x00020000);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  auto store16 = [&](f32x4 v, __amdgpu_buffer_rsrc_t res, int voff, int soff) {      // (hazard: see wino_pipe_body)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), res, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int rawL_off = (((g >> 1) * RP + (2 * (lr >> 3)) * 18 + 2 * (lr & 7)) * 4 + 2 * (g & 1));
+  const int u_ln = g * 64 + lr * 4;
+  int stores_behind = 0;
+
+  for (;;) {
+    const bool more = tile + tstride < ntiles;
+    // the group's patch has landed (only a finished group's stores are younger)
+    if (__builtin_amdgcn_readfirstlane(stores_behind) == NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    stores_behind = 0;
+    // ---- input transform of the whole group (both chunks), kept in registers for every pass ----
+    f32x2 vv[2][16];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c >= nchunks) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) vv[c][p] = (f32x2){0.f, 0.f};
+        continue;
+      }
+      const float* const rawL = rawW + c * WV * 256 * 4 + rawL_off;
+      f32x2 t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * 4), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * 4);
+        const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * 4), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * 4);
+        t[0][j] = d0 - d2; t[1][j] = d1 + d2; t[2][j] = d2 - d1; t[3][j] = d1 - d3;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vv[c][i * 4 + 0] = t[i][0] - t[i][2]; vv[c][i * 4 + 1] = t[i][1] + t[i][2];
+        vv[c][i * 4 + 2] = t[i][2] - t[i][1]; vv[c][i * 4 + 3] = t[i][1] - t[i][3];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the next group's patch may now overwrite the buffers (the last group re-reads itself; retired by the final wait)
+    const int ntile = more ? tile + tstride : tile;
+    const GPos nxt = group_pos(ntile);
+    dma_group(nxt);
+
+    auto squeeze_in = [&](int bi, const f32x4 (&ov)[4]) {
+      const float* const sA = sqAL + bi * (4 * NSQ * 64) + lane;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float wa[NSQ];
+#pragma unroll
+        for (int q = 0; q < NSQ; ++q) wa[q] = sA[(t * NSQ + q) * 64];
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+          for (int q = 0; q < NSQ; ++q) acc_sq[px][q] = mfma16(wa[q], ov[px][t], acc_sq[px][q]);
+      }
+    };
+
+    {
+      // KIND 0: expand3x3 pass; 1: expand1x1 pass, all four channel blocks; 2: expand1x1 pass, blocks 0, 1 only
+      auto run_pass = [&](auto kind_c, int pass) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const float* const bL = biasL + pass * 64 + lr;
+        constexpr bool E1 = KIND != 0;
+        constexpr int SSTEP = (KIND == 2) ? 2 : 1, NS = 8 / SSTEP;
+        float bA[E1 ? 4 : 1];
+#pragma unroll
+        for (int k = 0; k < (E1 ? (KIND == 2 ? 2 : 4) : 1); ++k) bA[k] = bL[k * 16];
+        for (int cc = 0; cc < nchunks; ++cc) {
+          const float* const uR = (E1 ? U1B + ((pass - P3) * nchunks + cc) * e1_stage : UB + (pass * nchunks + cc) * 2048) + u_ln;
+          auto chunk = [&](auto first_c, auto cc_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            constexpr int CC = decltype(cc_c)::value;
+            f32x4 af0 = *(const f32x4*)uR, af1;
+#pragma unroll
+            for (int si = 0; si < NS; ++si) {
+              const int step = si * SSTEP;
+              __builtin_amdgcn_sched_barrier(0);
+              if (si + 1 < NS) { if (si & 1) af0 = *(const f32x4*)(uR + (si + 1) * 256); else af1 = *(const f32x4*)(uR + (si + 1) * 256); }
+              __builtin_amdgcn_sched_barrier(0);
+              const f32x4 af = (si & 1) ? af1 : af0;
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const int p = 2 * step + h;
+                  const int pv = E1 ? ((p >> 2) == 0 ? 5 : (p >> 2) == 1 ? 6 : (p >> 2) == 2 ? 9 : 10) : p;
+                  f32x4 c0v;
+                  if (FIRST && t == 0) {
+                    c0v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (E1 ? (p < 4) : (p == 5)) c0v = mfma16(bA[E1 ? (p & 3) : 0], oneB, c0v);      // bias: rank-1 product into m11
+                  } else {
+                    c0v = acc[p];
+                  }
+                  acc[p] = mfma16(af[2 * h + t], vv[CC][pv][t], c0v);
+                }
+            }
+          };
+          if (cc == 0) chunk(std::true_type{}, std::integral_constant<int, 0>{});
+          else chunk(std::false_type{}, std::integral_constant<int, 1>{});
+        }
+        // ---- this pass's channels: inverse transform, ReLU, into the next squeeze ----
+        if constexpr (E1) {
+          const int bi0 = P3 + 4 * (pass - P3);
+#pragma unroll
+          for (int r = 0; r < (KIND == 2 ? 2 : 4); ++r) {
+            f32x4 ov[4];
+            auto inv1 = [&](auto half, auto put) {          // (register pairs: packed adds)
+              const f32x2 m0 = half(acc[0 + r]), m1 = half(acc[4 + r]), m2 = half(acc[8 + r]), m3 = half(acc[12 + r]);
+              const f32x2 s01 = m0 + m1, d01 = m0 - m1, s23 = m2 + m3, d23 = m2 - m3;
+              put(0, s01 + s23); put(1, d01 + d23); put(2, s01 - s23); put(3, d01 - d23);
+            };
+            inv1([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
+            inv1([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
+#pragma unroll
+            for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
+            squeeze_in(bi0 + r, ov);
+          }
+        } else {
+          auto inv = [&](auto half, auto put) {
+            f32x2 sx[4][2];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+              const f32x2 m0 = half(acc[xi * 4 + 0]), m1 = half(acc[xi * 4 + 1]);
+              const f32x2 m2 = half(acc[xi * 4 + 2]), m3 = half(acc[xi * 4 + 3]);
+              sx[xi][0] = m0 + m1 + m2;
+              sx[xi][1] = m1 - (m2 + m3);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              put(0 * 2 + b, sx[0][b] + sx[1][b] + sx[2][b]);
+              put(1 * 2 + b, sx[1][b] - (sx[2][b] + sx[3][b]));
+            }
+          };
+          f32x4 ov[4];
+          inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
+          inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
+#pragma unroll
+          for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
+          squeeze_in(pass, ov);
+        }
+      };
+      for (int pass = 0; pass < P3; ++pass) run_pass(std::integral_constant<int, 0>{}, pass);
+      if (e1_half) { for (int pass = P3; pass < P; ++pass) run_pass(std::integral_constant<int, 2>{}, pass); }
+      else { for (int pass = P3; pass < P; ++pass) run_pass(std::integral_constant<int, 1>{}, pass); }
+    }
+    // ---- the group's squeeze output: ReLU + store; the accumulators restart from the bias ----
+    if (cur.valid) {
+      const int ysoff = (int)(unsigned)(cur.p0 * a.y_pitch * 4);
+      const bool whole = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W && NSQ * 16 <= a.br_nsq;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const bool valid = whole || (cur.y0 + 2 * ty + (px >> 1) < a.H && cur.x0 + 2 * tx + (px & 1) < a.W);
+#pragma unroll
+        for (int q = 0; q < NSQ; ++q) {
+          if (!valid || q * 16 + 4 * g >= a.br_nsq) continue;
+          store16(wino_relu4(acc_sq[px][q], 0.f), yres, o_offB[px] + q * 64, ysoff);
+        }
+      }
+      stores_behind = whole ? NSTB : 0;
+    }
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+      for (int q = 0; q < NSQ; ++q) acc_sq[px][q] = sqb[q];
+    if (!more) break;
+    tile = ntile;
+    cur = nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NSQ>
+__global__ __launch_bounds__(512, 1) void fire_bridge16_kernel(WinoArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  wino_bridge16_body<NSQ>(a);
+#endif
+}
+
+// bias table / squeeze operand blocks of this form: 16-wide passes (see sqd_fire_bridge_fwd)
+template <int NSQ>
+static int launch_wino_bridge16(WinoArgs a, hipStream_t stream) {
+  constexpr int WV = 8, NTHR = WV * 64;
+  const int nchunks = a.C >> 3;
+  if (nchunks < 1 || nchunks > 2) return SQD_ERR_UNSUPPORTED;
+  const int P3 = sqd_cdiv(a.N, 16), P1 = 2 * sqd_cdiv(a.N1, 128);
+  if (a.Npad != sqd_cdiv(a.N, 32) * 32 + sqd_cdiv(a.N1, 128) * 32) return SQD_ERR_BAD_ARG;
+  // the expand1x1 passes are the 16-wide slices of the packed axis behind ceil32(N3)
+  const int first1 = sqd_cdiv(a.N, 32) * 2;
+  const int e1_stage = a.N1 <= 64 ? 1024 : 2048;
+  const int nblk = first1 + 4 * P1;
+  const size_t lds = (size_t)(2 * WV * 256 * 4 + first1 * nchunks * 2048 + P1 * nchunks * e1_stage + nblk * 4 * NSQ * 64 + (first1 + P1) * 64) * sizeof(float);
+  (void)P3;
+  if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
+  auto kern = fire_bridge16_kernel<NSQ>;
+  if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  a.gxn = sqd_cdiv(a.W, 16); a.gyn = sqd_cdiv(a.H, 4);
+  a.ngroups = a.B * a.gxn * a.gyn;
+  if ((long long)(a.ngroups + 8) * (a.gxn > a.gyn ? a.gxn : a.gyn) >= (1ll << 32)) return SQD_ERR_UNSUPPORTED;
+  a.gxn_m = a.gxn > 1 ? (unsigned)(((1ull << 32) + a.gxn - 1) / a.gxn) : 0u; a.gyn_m = a.gyn > 1 ? (unsigned)(((1ull << 32) + a.gyn - 1) / a.gyn) : 0u;
+  a.ntiles = sqd_cdiv(a.ngroups, WV);
+  const int slots = wino_num_cus();
+  const int per_wg = sqd_cdiv(a.ntiles, slots);
+  const int gx = sqd_cdiv(a.ntiles, per_wg);
+  a.nslices3 = first1; a.nslices = first1 + P1; a.gx = gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NTHR), lds, stream, a);
+  return sqd_launch_status();
+}

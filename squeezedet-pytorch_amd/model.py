@@ -145,6 +145,7 @@ class SqueezeDetBase(nn.Module):
         self.use_winograd = True                  # 3x3 forward convs: Winograd F(2x2,3x3) kernel where tuning.json says it is faster
         self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
         self.fuse_expand_wino = True              # ... in Winograd form (ops.fire_wino) where the table has an X: row
+        self.fuse_fire_bridge = True              # ... together with the NEXT Fire's squeeze (ops.fire_bridge) where it has a Y: row
         # inference forward: pool 2 / 3 folded into the following squeeze (ops.pool_squeeze).  Off by default: measured equal
         # to the two separate kernels (0.174 vs 0.18 ms) -- both are bound by the 9x L2 read amplification of the window gather
         self.fuse_pool_squeeze = False
@@ -194,6 +195,20 @@ class SqueezeDetBase(nn.Module):
         if hit is not None and hit[0] == ver:
             return hit[1]
         p = ops.FireWinoPlan(fire.expand1x1.weight, fire.expand1x1.bias, fire.expand3x3.weight, fire.expand3x3.bias, cfg_id)
+        self._fused_plans[key] = (ver, p)
+        return p
+
+    def fire_bridge_plan(self, idx, fire, nxt, cfg_id):
+        """Operands of the one-launch form of ``fire``'s expand pair + ``nxt``'s squeeze (ops.fire_bridge, inference forward);
+        rebuilt when any of the three modules' parameters change."""
+        key = ('firebridge', idx, cfg_id)
+        mods = (fire.expand1x1, fire.expand3x3, nxt.squeeze)
+        ver = tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()))
+        hit = self._fused_plans.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        p = ops.FireBridgePlan(fire.expand1x1.weight, fire.expand1x1.bias, fire.expand3x3.weight, fire.expand3x3.bias,
+                               nxt.squeeze.weight, nxt.squeeze.bias, cfg_id)
         self._fused_plans[key] = (ver, p)
         return p
 

@@ -556,6 +556,105 @@ def fire_wino(x, x_coff, plan, y, y_coff1, y_coff3):
     return y
 
 
+FIRE_BRIDGE_CFGS = (6, 10, 12)
+
+
+def fire_bridge_lds_bytes(cfg_id, C, N3, N1, Nsq):
+    P3, P1 = -(-N3 // 32), -(-N1 // 128)
+    if cfg_id % 1000 == 12:         # 16-wide passes, eight waves, U resident (expand1x1 stages halved when N1 <= 64)
+        return 4 * (2 * 8 * 256 * 4 + 2 * P3 * (C // 8) * 2048 + 2 * P1 * (C // 8) * (1024 if N1 <= 64 else 2048)
+                    + (2 * P3 + 8 * P1) * 4 * -(-Nsq // 16) * 64 + (2 * P3 + 2 * P1) * 64)
+    P = P3 + P1
+    ustages = P * (C // 8) if cfg_id % 1000 == 10 else 3
+    return 4 * (2 * 4 * 256 * 4 + ustages * 1024 * 4 + (2 * P3 + 8 * P1) * 4 * -(-Nsq // 16) * 64 + P * 128)
+
+
+def fire_bridge_cfg_ok(cfg_id, C, N3, N1, Nsq):
+    """Whether ``fire_bridge`` can run this Fire pair: 8 | C, 16 | N1, 4 | N3, Nsq <= 32, and the LDS plan fits one CU."""
+    return (cfg_id % 1000 in FIRE_BRIDGE_CFGS and C % 8 == 0 and N1 % 16 == 0 and N3 % 4 == 0 and Nsq % 4 == 0 and Nsq <= 32
+            and (cfg_id % 1000 != 12 or C <= 16) and fire_bridge_lds_bytes(cfg_id, C, N3, N1, Nsq) <= 160 * 1024)
+
+
+def choose_fire_bridge_cfg(C, N1, N3, Nsq, npix):
+    """Tuned bridge configuration of a Fire pair (tuning.json row 'Y:C:N1:N3:Nsq:npix'), or None."""
+    hit = _tuning().get(f'Y:{C}:{N1}:{N3}:{Nsq}:{npix}')
+    return hit if (hit is not None and hit >= 0 and fire_bridge_cfg_ok(hit, C, N3, N1, Nsq)) else None
+
+
+class FireBridgePlan:
+    """Operands of ``fire_bridge``: the Fire's expand pair transformed as in FireWinoPlan, the per-pass bias table, and the next
+    Fire's squeeze weights laid out as MFMA A operands (include/sqd_hip.h, sqd_fire_bridge_fwd)."""
+    __slots__ = ('cfg_id', 'C', 'N3', 'N1', 'Npad', 'Nsq', 'w', 'bias_tab', 'sq_ops', 'sq_bias')
+
+    def __init__(self, w1, b1, w3, b3, wsq, bsq, cfg_id):
+        N3, C = w3.shape[0], w3.shape[1]
+        N1, Nsq = w1.shape[0], wsq.shape[0]
+        if tuple(w3.shape) != (N3, C, 3, 3) or tuple(w1.shape) != (N1, C, 1, 1) or tuple(wsq.shape) != (Nsq, N1 + N3, 1, 1):
+            raise ValueError(f'fire_bridge: need expand3x3 [N3,C,3,3], expand1x1 [N1,C,1,1] and the next squeeze [Nsq,N1+N3,1,1], got '
+                             f'{tuple(w3.shape)}, {tuple(w1.shape)}, {tuple(wsq.shape)}')
+        if not fire_bridge_cfg_ok(cfg_id, C, N3, N1, Nsq):
+            raise ValueError(f'fire_bridge: configuration {cfg_id} cannot run C={C} E={N1}+{N3} -> {Nsq}')
+        dev = w3.device
+        self.cfg_id, self.C, self.N3, self.N1, self.Nsq = cfg_id, C, N3, N1, Nsq
+        P3, P1 = -(-N3 // 32), -(-N1 // 128)
+        self.Npad = 32 * (P3 + P1)
+        self.w = torch.empty(C // 8, 16, self.Npad, 8, device=dev, dtype=torch.float32)
+        nat.check(nat.lib().sqd_pack_wino_fire(nat.ptr(w3.detach().contiguous()), nat.ptr(w1.detach().contiguous()), nat.ptr(self.w),
+                                               N3, N1, C, self.Npad, nat.stream_handle(dev)), 'sqd_pack_wino_fire')
+        # cat channel of every 16-channel block, in pass order: expand3x3 slices (cat offset N1), then expand1x1 slices
+        narrow = cfg_id % 1000 == 12                 # 16-wide passes: 1 block per expand3x3 pass, 4 per expand1x1 pass
+        if narrow:
+            base = [N1 + 16 * p for p in range(2 * P3)] + [128 * (s1 >> 1) + (2 * r + (s1 & 1)) * 16 for s1 in range(2 * P1) for r in range(4)]
+        else:
+            base = [N1 + 32 * s + 16 * j for s in range(P3) for j in range(2)] + [128 * s + 16 * blk for s in range(P1) for blk in range(8)]
+        limit = [N1 + N3] * (2 * P3) + [N1] * (8 * P1)
+        nblk, nq = len(base), -(-Nsq // 16)
+        ch = torch.tensor(base, device=dev).view(nblk, 1) + torch.arange(16, device=dev).view(1, 16)          # [blk][c16]
+        ok = ch < torch.tensor(limit, device=dev).view(nblk, 1)
+        chs = torch.where(ok, ch, torch.zeros_like(ch))
+        wz = torch.zeros(16 * nq, N1 + N3, device=dev, dtype=torch.float32)
+        wz[:Nsq] = wsq.detach().reshape(Nsq, N1 + N3)
+        g = wz[:, chs.reshape(-1)].view(nq, 16, nblk, 4, 4) * ok.view(1, 1, nblk, 4, 4)                        # [q][lr][blk][g][t]
+        self.sq_ops = g.permute(2, 4, 0, 3, 1).contiguous()                                                   # [blk][t][q][g][lr]
+        bcat = torch.cat([torch.zeros(N1, device=dev) if b1 is None else b1.detach().float(),
+                          torch.zeros(N3, device=dev) if b3 is None else b3.detach().float()])
+        bvals = bcat[chs.reshape(-1)].view(nblk, 16) * ok
+        if narrow:
+            bt = torch.zeros(2 * P3 + 2 * P1, 4, 16, device=dev, dtype=torch.float32)
+            bt[:2 * P3, 0] = bvals[:2 * P3]
+            bt[2 * P3:] = bvals[2 * P3:].view(2 * P1, 4, 16)
+        else:
+            bt = torch.zeros(P3 + P1, 8, 16, device=dev, dtype=torch.float32)
+            bt[:P3, :2] = bvals[:2 * P3].view(P3, 2, 16)
+            bt[P3:] = bvals[2 * P3:].view(P1, 8, 16)
+        self.bias_tab = bt.contiguous()
+        self.sq_bias = (torch.zeros(Nsq, device=dev) if bsq is None else bsq.detach().float()).contiguous()
+
+
+def fire_bridge(x, x_coff, plan, y, y_coff):
+    """y[..., y_coff:+Nsq] = relu(squeeze'(cat(relu(expand1x1(x)), relu(expand3x3(x))))) in ONE launch (inference)."""
+    _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
+    B, H, W, xp = x.shape
+    if tuple(y.shape[:3]) != (B, H, W):
+        raise ValueError('fire_bridge: x and y disagree on B,H,W')
+    yp = y.shape[3]
+    if x_coff < 0 or x_coff + plan.C > xp or y_coff < 0 or y_coff + plan.Nsq > yp:
+        raise ValueError('fire_bridge: channel window out of range')
+    br = None
+    if _timer is not None:
+        npix = B * H * W
+        br = _Bracket('fire_bridge', f'fire C{plan.C} E{plan.N1}+{plan.N3} -> S{plan.Nsq} {H}x{W}',
+                      2.0 * npix * (plan.C * (4 * plan.N3 + plan.N1) + (plan.N1 + plan.N3) * plan.Nsq),
+                      4.0 * (npix * (plan.C + plan.Nsq) + plan.C * (16 * plan.N3 + plan.N1) + (plan.N1 + plan.N3) * plan.Nsq))
+    rc = nat.lib().sqd_fire_bridge_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias_tab), nat.ptr(plan.sq_ops), nat.ptr(plan.sq_bias),
+                                       nat.ptr(y), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1, plan.Npad, plan.Nsq, yp, y_coff,
+                                       plan.cfg_id, nat.stream_handle(x.device))
+    nat.check(rc, 'sqd_fire_bridge_fwd')
+    if br is not None:
+        br.done()
+    return y
+
+
 POOL_SQUEEZE_CFG = 28        # 1x1 tiling with KC = 32, 16-channel slices: its packed weights are [C/4][ceil16(N)][4]
 
 

@@ -15,7 +15,7 @@ from .synthetic import convdet_in_channels, layer_table
 
 
 def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
-                          use_winograd=True, fuse_expand=True):
+                          use_winograd=True, fuse_expand=True, fuse_fire_bridge=True):
     """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order."""
     layers = layer_table(arch)
     H, W = ops.stem_out_size(input_size[0], input_size[1], layers[0][3])
@@ -36,14 +36,25 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
             return (ops.wino_kernel_name(wc), f'9tap C{Cin} N{N} {H}x{W}')
         return (ops.cfg_kernel_name(ops.choose_cfg(9, Cin, N, npix)), f'9tap C{Cin} N{N} {H}x{W}')
 
-    for l in layers[first:]:
+    bridged = False
+    for i in range(first, len(layers)):
+        l = layers[i]
         if l[0] == 'pool':
             plan.append(('maxpool_fwd', f'pool C{C} {H}x{W}'))
             H, W = ops.pool_out_size(H, W)
             continue
         _, cin, s, e1, e3 = l
         npix = batch * H * W
-        plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, cin, s, npix)), f'1tap C{cin} N{s} {H}x{W}'))
+        if not bridged:
+            plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, cin, s, npix)), f'1tap C{cin} N{s} {H}x{W}'))
+        bridged = False
+        C = e1 + e3
+        nxt = layers[i + 1] if i + 1 < len(layers) else None
+        if nxt is not None and nxt[0] == 'fire' and fuse_fire_bridge and use_winograd:
+            if ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix) is not None:
+                plan.append(('fire_bridge', f'fire C{s} E{e1}+{e3} -> S{nxt[2]} {H}x{W}'))
+                bridged = True
+                continue
         xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fuse_expand and use_winograd) else None
         fcfg = ops.choose_fused_cfg(s, e1, npix) if (xcfg is None and fuse_expand and e1 == e3) else None
         if xcfg is not None:
@@ -53,7 +64,6 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
         else:
             plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, s, e1, npix)), f'1tap C{s} N{e1} {H}x{W}'))
             plan.append(conv3x3(s, e3))
-        C = e1 + e3
     plan.append(conv3x3(convdet_in_channels(arch), anchors_per_grid * (num_classes + 5)))
     plan.append(('detect', f'detect A{H * W * anchors_per_grid}'))
     return plan

@@ -28,7 +28,7 @@ class LaunchLog:
 
     def __init__(self, monkeypatch):
         self.calls = []
-        real_conv, real_wino, real_fused = ops.conv, ops.conv_wino, ops.fire_expand
+        real_conv, real_wino, real_fused, real_bridge = ops.conv, ops.conv_wino, ops.fire_expand, ops.fire_bridge
 
         def conv(x, x_coff, plan, y, y_coff, **kw):
             self.calls.append(('direct', plan.taps, plan.C, plan.N, x.shape[0] * x.shape[1] * x.shape[2], plan.cfg_id))
@@ -41,18 +41,27 @@ class LaunchLog:
         def fire_expand(x, x_coff, fplan, y, y_coff):
             self.calls.append(('fused', 9, fplan.C, fplan.E, x.shape[0] * x.shape[1] * x.shape[2], fplan.cfg_id))
             return real_fused(x, x_coff, fplan, y, y_coff)
+        def fire_bridge(x, x_coff, plan, y, y_coff):
+            self.calls.append(('bridge', 9, plan.C, (plan.N1, plan.N3, plan.Nsq), x.shape[0] * x.shape[1] * x.shape[2], plan.cfg_id))
+            return real_bridge(x, x_coff, plan, y, y_coff)
+        monkeypatch.setattr(ops, 'fire_bridge', fire_bridge)
         monkeypatch.setattr(ops, 'conv', conv)
         monkeypatch.setattr(ops, 'conv_wino', conv_wino)
         monkeypatch.setattr(ops, 'fire_expand', fire_expand)
 
-    def assert_exact_table_hits(self, expect_3x3, allow_fused=False):
+    def assert_exact_table_hits(self, expect_3x3, allow_fused=False, expect_bridges=0):
         """Every launch ran the configuration the shipped table holds for EXACTLY this shape (no nearest-shape or
         heuristic fallback), and every 3x3 layer ran the Winograd kernel (``allow_fused``: or the one-launch fused
-        expand where the table's ``F:`` row says it wins)."""
+        expand where the table's ``F:`` row says it wins; ``expect_bridges``: Fire -> Fire bridge launches, each standing
+        for an expand1x1, an expand3x3 and the next squeeze, where the table has a ``Y:`` row)."""
         tab = ops._tuning()
         n3 = 0
+        assert sum(1 for c in self.calls if c[0] == 'bridge') == expect_bridges
         for kind, taps, C, N, npix, cfg in self.calls:
-            if kind == 'fused':
+            if kind == 'bridge':
+                n3 += 1
+                key = f'Y:{C}:{N[0]}:{N[1]}:{N[2]}:{npix}'
+            elif kind == 'fused':
                 n3 += 1
                 assert allow_fused, f'fused expand C{C} E{N} npix {npix}: expected separate expand1x1 + Winograd launches'
                 key = f'F:{C}:{N}:{npix}'
@@ -107,8 +116,8 @@ def test_squeezedet_bs20_inference_vs_oracle(monkeypatch):
     log = LaunchLog(monkeypatch)
     with torch.no_grad():
         pred = det.model.base(xg)
-    log.assert_exact_table_hits(expect_3x3=11)             # 10 expand3x3 + ConvDet
-    assert sum(1 for c in log.calls if c[1] == 1) == 20    # 10 squeeze + 10 expand1x1
+    log.assert_exact_table_hits(expect_3x3=11, expect_bridges=1)             # 10 expand3x3 (fire3's inside the fire3 -> fire4 bridge) + ConvDet
+    assert sum(1 for c in log.calls if c[1] == 1) == 18    # 10 squeeze + 10 expand1x1, less fire3's expand1x1 and fire4's squeeze (bridge)
     with torch.no_grad():
         ref = oracle.backbone_forward(x, sd)
     assert tuple(pred.shape) == (20, 16848, 8)

@@ -350,3 +350,41 @@ def test_golden_forward_through_one_launch_winograd_fire(golden_dir, monkeypatch
         pred1 = m.base(x1.cuda())
     np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
     assert used['n'] >= 30
+
+
+def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
+    """The reference-generated goldens with every Fire -> Fire pair the bridge launch can take (expand pair + the next Fire's
+    squeeze in one kernel, squeeze width <= 32: fire3 -> fire4 and fire6 -> fire7 of SqueezeDet, none of SqueezeDet+; the
+    shipped table takes fire3 -> fire4 at the headline shape) forced onto it: same 1e-4 bound, and the switch
+    ``fuse_fire_bridge = False`` gives the plain path back."""
+    from squeezedet_pytorch_amd import ops
+    used = {'n': 0}
+
+    def always(C, E1, E3, Nsq, npix):
+        for cid in (12, 10, 6):
+            if ops.fire_bridge_cfg_ok(cid, C, E3, E1, Nsq):
+                used['n'] += 1
+                return cid
+        return None
+    monkeypatch.setattr(ops, 'choose_fire_bridge_cfg', always)
+    monkeypatch.setattr(ops, 'choose_wino_cfg', lambda C, N, npix: (2 if C % 8 == 0 else None))
+    g = np.load(os.path.join(golden_dir, "backbone_small.npz"))
+    for arch in ("squeezedet", "squeezedetplus"):
+        cfg, m, sd = _model(arch, (64, 96))
+        x = synthetic.make_images(2, (64, 96), seed=3)
+        with torch.no_grad():
+            pred = m.base(x.cuda())
+            n_bridged = used['n']
+            m.base.fuse_fire_bridge = False
+            plain = m.base(x.cuda())
+        assert used['n'] == n_bridged
+        np.testing.assert_allclose(pred.cpu().numpy(), g[f"{arch}_pred"], atol=TOL, rtol=0)
+        np.testing.assert_allclose(pred.cpu().numpy(), plain.cpu().numpy(), atol=2e-5, rtol=0)
+    gk = np.load(os.path.join(golden_dir, "kitti_full.npz"))
+    cfg, m, sd = _model('squeezedet', (384, 1248))
+    x1 = synthetic.make_images(1, (384, 1248), seed=0)
+    with torch.no_grad():
+        pred1 = m.base(x1.cuda())
+    np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(pred1[0].cpu().numpy()[gk["top_idx"]], gk["pred_top"], atol=TOL, rtol=0)
+    assert used['n'] == 4                                   # two pairs x two SqueezeDet forwards

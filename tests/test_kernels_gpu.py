@@ -337,6 +337,40 @@ def test_conv_wgrad_winograd(C, N, B, H, W):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("C,E1,E3,S,B,H,W", [
+    (16, 64, 64, 16, 2, 12, 20), (16, 64, 64, 16, 6, 96, 312), (8, 32, 40, 12, 1, 5, 17), (16, 96, 48, 16, 2, 11, 23),
+    (16, 144, 32, 24, 3, 13, 50), (16, 48, 96, 32, 2, 7, 40), (32, 128, 128, 32, 2, 24, 78), (48, 192, 192, 32, 1, 9, 20),
+])
+def test_fire_bridge_one_launch(C, E1, E3, S, B, H, W):
+    """Fire k's expand pair + concat + Fire k+1's squeeze in ONE launch (sqd_fire_bridge_fwd) == the three fp32 convolutions of
+    the reference (src/model/squeezedet.py:18-22 applied twice), every configuration that can run the shape (C <= 16 register-resident
+    form, U-resident, streamed), odd sizes, partial slices (E1 not a multiple of 128, E3 not of 32, S not of 16), bytes outside
+    the output window untouched."""
+    ops = _ops()
+    x = F.relu(_rand(B, C, H, W, seed=51))
+    w1 = _rand(E1, C, 1, 1, seed=52, scale=(2.0 / C) ** 0.5); b1 = _rand(E1, seed=53, scale=0.1)
+    w3 = _rand(E3, C, 3, 3, seed=54, scale=(2.0 / (C * 9)) ** 0.5); b3 = _rand(E3, seed=55, scale=0.1)
+    ws = _rand(S, E1 + E3, 1, 1, seed=56, scale=(2.0 / (E1 + E3)) ** 0.5); bs = _rand(S, seed=57, scale=0.1)
+    mid = torch.cat([F.relu(F.conv2d(x, w1, b1)), F.relu(F.conv2d(x, w3, b3, padding=1))], 1)
+    ref = _nhwc(F.relu(F.conv2d(mid, ws, bs)))
+    xg = _nhwc(x).cuda()
+    ran = 0
+    for cid in ops.FIRE_BRIDGE_CFGS:
+        if not ops.fire_bridge_cfg_ok(cid, C, E3, E1, S):
+            with pytest.raises(ValueError):
+                ops.FireBridgePlan(w1.cuda(), b1.cuda(), w3.cuda(), b3.cuda(), ws.cuda(), bs.cuda(), cid)
+            continue
+        plan = ops.FireBridgePlan(w1.cuda(), b1.cuda(), w3.cuda(), b3.cuda(), ws.cuda(), bs.cuda(), cid)
+        y = torch.full((B, H, W, S + 8), -7.0, device='cuda')
+        ops.fire_bridge(xg, 0, plan, y, 4)
+        torch.cuda.synchronize()
+        yc = y.cpu()
+        assert (yc[..., 4:4 + S] - ref).abs().max().item() <= _tol(ref), f'cfg {cid}'
+        assert bool((yc[..., :4] == -7.0).all()) and bool((yc[..., 4 + S:] == -7.0).all())
+        ran += 1
+    assert ran >= 1
+
+
 @pytest.mark.parametrize("C,E1,E3,B,H,W", [
     (16, 64, 64, 2, 12, 20), (32, 128, 128, 1, 9, 33), (48, 192, 192, 1, 24, 78), (64, 256, 256, 2, 6, 18), (96, 384, 384, 1, 5, 17),
     (16, 64, 64, 6, 96, 312), (96, 384, 384, 20, 24, 78), (8, 16, 20, 3, 4, 16), (24, 48, 40, 2, 7, 35),
