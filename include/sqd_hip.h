@@ -223,7 +223,8 @@ int sqd_loss_bwd(const float* pred, const float* gt, const float* anchors, const
  * each) that reuse the squeeze tile's staging instead of a second launch re-reading it.
  * sqd_pack_wino_fire: w3 OIHW [N3][C][3][3] + w1 OIHW [N1][C][1][1] -> u_packed of (C/8)*16*Npad_total*8 floats,
  * Npad_total = ceil32(N3) + 32*ceil(N1/128).  cfg_id of sqd_fire_wino_fwd: 4 / 6 (streamed U, 8 / 4 waves), 8 / 10
- * (U-stationary: whole U in LDS, needs (C/8)*16 KB + patch ring <= 160 KB), + 1000*k = workgroups-per-CU cap. */
+ * (U-stationary: whole U in LDS, needs (C/8)*16 KB + patch ring <= 160 KB), 12 (C <= 16: one workgroup stream runs ALL channel
+ * passes of a pixel group from a transformed input held in registers; whole U in LDS), + 1000*k = workgroups-per-CU cap. */
 int sqd_pack_wino_fire(const float* w3_oihw, const float* w1_oihw, float* u_packed, int N3, int N1, int C, int Npad_total, void* stream);
 int sqd_fire_wino_fwd(const float* x, const float* u_packed, const float* bias3, const float* bias1, float* y, int B, int H, int W,
                       int C, int x_pitch, int x_coff, int N3, int y_coff3, int N1, int y_coff1, int Npad_total, int y_pitch,

@@ -12,7 +12,7 @@ def timeit(fn):
     for _ in range(ITERS): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / ITERS * 1e3
-for (C, E, H, W) in [(16, 64, 96, 312), (32, 128, 48, 156), (48, 192, 24, 78), (64, 256, 24, 78), (96, 384, 24, 78)]:
+for (C, E, H, W) in [(16, 64, 96, 312)]:
     torch.manual_seed(0)
     x = torch.randn(B, H, W, C, device='cuda').relu_()
     w1 = torch.randn(E, C, 1, 1, device='cuda') * 0.1; b1 = torch.randn(E, device='cuda') * 0.1
@@ -22,8 +22,8 @@ for (C, E, H, W) in [(16, 64, 96, 312), (32, 128, 48, 156), (48, 192, 24, 78), (
     p1 = ops.ConvPlan(w1, b1, ops.choose_cfg(1, C, E, npix)); p3 = ops.WinoPlan(w3, b3, ops.choose_wino_cfg(C, E, npix))
     t1 = timeit(lambda: ops.conv(x, 0, p1, y, 0, relu=True)); t3 = timeit(lambda: ops.conv_wino(x, 0, p3, y, E, relu=True))
     line = f'C{C} E{E} {H}x{W}: separate {t1:.1f} + {t3:.1f} = {t1 + t3:.1f} us |'
-    for cid in (6, 1006, 10, 1010, 8, 4):
-        if not ops.fire_wino_cfg_ok(cid, C): continue
+    for cid in (12, 6, 1006, 10, 1010, 8, 4):
+        if not ops.fire_wino_cfg_ok(cid, C, E, E): continue
         fp = ops.FireWinoPlan(w1, b1, w3, b3, cid)
         line += f' x{cid} {timeit(lambda: ops.fire_wino(x, 0, fp, y, 0, E)):.1f}'
     print(line, flush=True)

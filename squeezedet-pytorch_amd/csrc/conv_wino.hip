@@ -1052,7 +1052,8 @@ extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const fl
 // Fire.forward's two expand convolutions + torch.cat (src/model/squeezedet.py:18-22) in ONE Winograd launch: y[..., y_coff3 :
 // y_coff3 + N3] = ReLU(conv3x3(x) + b3), y[..., y_coff1 : y_coff1 + N1] = ReLU(conv1x1(x) + b1).  u_packed from
 // sqd_pack_wino_fire; cfg_id: a 32-channel-slice id of the deep-prefetch family (4, 6: streamed U; 8, 10: U-stationary, C <= 64
-// at 4 waves / C <= 32 at 8), + 1000 k = workgroups-per-CU cap.  Inference forward (plain epilogue: bias + ReLU).
+// at 4 waves / C <= 32 at 8; 12: C <= 16, the group's transformed input stays in registers, U resident, eight waves),
+// + 1000 k = workgroups-per-CU cap.  Plain epilogue: bias + ReLU.
 extern "C" int sqd_fire_wino_fwd(const float* x, const float* u_packed, const float* bias3, const float* bias1, float* y, int B, int H,
                                  int W, int C, int x_pitch, int x_coff, int N3, int y_coff3, int N1, int y_coff1, int Npad_total,
                                  int y_pitch, int cfg_id, void* stream) {
@@ -1076,6 +1077,7 @@ extern "C" int sqd_fire_wino_fwd(const float* x, const float* u_packed, const fl
     case 6: return launch_wino_pipe<2, 4, false, true>(a, s);
     case 8: return launch_wino_pipe<2, 8, true, true>(a, s);
     case 10: return launch_wino_pipe<2, 4, true, true>(a, s);
+    case 12: return launch_wino_bridge16<1, false>(a, s);      // C <= 16: transformed input in registers, 16-wide passes (wino_bridge.h)
   }
   return SQD_ERR_UNSUPPORTED;
 }

@@ -169,7 +169,7 @@ __device__ __attribute__((aligned(16))) float sqd_stem_zero[4] = {0.f, 0.f, 0.f,
 typedef __attribute__((address_space(3))) void* stem_lds_ptr_t;
 
 template <int KS, int PAD, int NT, bool ARGMAX, int WM>
-__global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : 1) void stem_pool_kernel(StemPoolArgs a) {
+__global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : ((WM == 8 && KS == 3) ? 4 : 1)) void stem_pool_kernel(StemPoolArgs a) {
   constexpr int NTHR = WM * 64;                       // 4 or 8 waves; with 8, two waves per SIMD work on one tile
   constexpr int PH = 3, PW = 8;                       // pooled tile
   constexpr int CH = 2 * PH + 1, CW = 2 * PW + 1;     // conv patch 7 x 17
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : 1) void stem_po
     in_key[it] = real ? (r << 8 | c) : -1;
   }
   // pooling items: (pooled pixel, channel quad)
-  int pl_lds[P_IT], pl_out[P_IT], pl_key[P_IT];
+  int pl_lds[P_IT], pl_out[P_IT], pl_key[P_IT], pl_ch[P_IT];
 #pragma unroll
   for (int it = 0; it < P_IT; ++it) {
     const int idx = (tid & (NPOOL - 1)) + it * NPOOL;
@@ -248,6 +248,7 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : 1) void stem_po
     pl_lds[it] = ((2 * pr) * CW + 2 * pc) * CP + 4 * cq;
     pl_out[it] = (pr * a.Wp + pc) * a.N + 4 * cq;
     pl_key[it] = real ? (pr << 8 | pc) : -1;
+    pl_ch[it] = 4 * cq;
   }
 
   struct Tile { int ty, tx, inner; const float* xorg; long long obase; };
@@ -349,12 +350,23 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : 1) void stem_po
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = j * 16 + 4 * g;
-        f32x4 v = acc[i][j] + *(const f32x4*)(biasL + n);
-        // ReLU as ONE v_max per element (fmaxf costs a canonicalising max in front; every VALU op delays the MFMAs)
-        asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
-                     : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-        if (!conv_inner) {                                            // uniform: only border tiles mask per lane
-          if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 v;
+        if constexpr (ARGMAX) {
+          v = acc[i][j] + *(const f32x4*)(biasL + n);
+          // ReLU as ONE v_max per element (fmaxf costs a canonicalising max in front; every VALU op delays the MFMAs)
+          asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
+                       : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+          if (!conv_inner) {                                            // uniform: only border tiles mask per lane
+            if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        } else {
+          // inference: bias and ReLU move BEHIND the pool -- max_i fl(x_i + b) == fl(max_i x_i + b) (rounding is monotone) and
+          // relu(max) == max(relu), bit for bit -- so they run on the 24 pooled pixels of a tile instead of its 119 conv
+          // pixels (every VALU instruction delays the matrix pipe); positions outside the conv map are -inf here
+          v = acc[i][j];
+          if (!conv_inner) {
+            if (!inside) v = (f32x4){-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+          }
         }
         *(f32x4*)(convT + p * CP + n) = v;
       }
@@ -384,6 +396,9 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : 1) void stem_po
         m.y = fmaxf(fmaxf(fmaxf(fmaxf(w[0].y, w[1].y), w[2].y), fmaxf(fmaxf(w[3].y, w[4].y), w[5].y)), fmaxf(fmaxf(w[6].y, w[7].y), w[8].y));
         m.z = fmaxf(fmaxf(fmaxf(fmaxf(w[0].z, w[1].z), w[2].z), fmaxf(fmaxf(w[3].z, w[4].z), w[5].z)), fmaxf(fmaxf(w[6].z, w[7].z), w[8].z));
         m.w = fmaxf(fmaxf(fmaxf(fmaxf(w[0].w, w[1].w), w[2].w), fmaxf(fmaxf(w[3].w, w[4].w), w[5].w)), fmaxf(fmaxf(w[6].w, w[7].w), w[8].w));
+        m += *(const f32x4*)(biasL + pl_ch[it]);
+        asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
+                     : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
         *(f32x4*)(a.y + o) = m;
       } else {
         // max by v_max3, then the FIRST window position holding it (scan t = 8..0, the smallest match written last).

@@ -417,7 +417,9 @@ static int launch_wino_bridge(WinoArgs a, hipStream_t stream) {
 // work; no workgroup barrier after the operands are in LDS.  An expand1x1 pass holds 4 positions x 64 channels (virtual
 // channel slice `s1` of the packed axis: channels 128 (s1 >> 1) + (2 r + (s1 & 1)) 16 + n, r = 0..3); when r = 2, 3 are all
 // padding (N1 <= 64) only the even position pairs are kept in LDS and multiplied.
-template <int NSQ>
+// SQZ = false: the same machinery as the plain fused expand (sqd_fire_wino_fwd cfg 12): every pass's channels get bias + ReLU and
+// are stored to their window of the concatenated output instead of entering a squeeze.
+template <int NSQ, bool SQZ>
 __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
   constexpr int WV = 8, NTHR = WV * 64, RP = 113, RAW_IT = 4, NSTB = 4 * NSQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -429,7 +431,7 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
   float* const UB = rawB + 2 * WV * 256 * 4;           // expand3x3: [P3][nchunks][2048]; expand1x1: [P - P3][nchunks][e1_stage]
   float* const U1B = UB + P3 * nchunks * 2048;
   float* const sqAL = U1B + (P - P3) * nchunks * e1_stage;      // [P3 + 4 (P - P3) blocks][4 t][NSQ][64 lanes]
-  const int nblk = P3 + 4 * (P - P3);
+  const int nblk = SQZ ? P3 + 4 * (P - P3) : 0;
   float* const biasL = sqAL + nblk * 4 * NSQ * 64;     // [P][4][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -497,8 +499,21 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ures, (lds_ptr_w_t)dst, 16, u_lane + wv_s * a.Npad * 64,
                                                  (int)(c * u_chunkB + (unsigned)ps * 1024u), 0, 0);
       }
-    for (int i = tid; i < nblk * 4 * NSQ * 64; i += NTHR) sqAL[i] = a.br_w[i];
-    for (int i = tid; i < P * 64; i += NTHR) biasL[i] = a.br_bias[i];
+    if constexpr (SQZ) {
+      for (int i = tid; i < nblk * 4 * NSQ * 64; i += NTHR) sqAL[i] = a.br_w[i];
+      for (int i = tid; i < P * 64; i += NTHR) biasL[i] = a.br_bias[i];
+    } else {
+      for (int i = tid; i < P * 64; i += NTHR) {         // the bias table from the two bias vectors
+        const int ps = i >> 6, r = (i >> 4) & 3, n = i & 15;
+        float v = 0.f;
+        if (ps < P3) { if (r == 0 && a.bias && ps * 16 + n < a.N) v = a.bias[ps * 16 + n]; }
+        else {
+          const int s1 = ps - P3, ch = 128 * (s1 >> 1) + (2 * r + (s1 & 1)) * 16 + n;
+          if (a.bias1 && ch < a.N1) v = a.bias1[ch];
+        }
+        biasL[i] = v;
+      }
+    }
   }
   GPos cur = group_pos(tile);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -510,7 +525,7 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
 #pragma unroll
   for (int q = 0; q < NSQ; ++q) {
     const int n = q * 16 + 4 * g;
-    sqb[q] = (a.br_sqb && n < a.br_nsq) ? *(const f32x4*)(a.br_sqb + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    sqb[q] = (SQZ && a.br_sqb && n < a.br_nsq) ? *(const f32x4*)(a.br_sqb + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int px = 0; px < 4; ++px) acc_sq[px][q] = sqb[q];
   }
@@ -520,6 +535,9 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
 #pragma unroll
   for (int px = 0; px < 4; ++px) o_offB[px] = (((2 * ty + (px >> 1)) * a.W + 2 * tx + (px & 1)) * a.y_pitch + 4 * g) * 4;
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff1), 0, 0x7ffffff0, 0x00020000);
+  // plain fused expand: store instructions of a whole group with every channel block present
+  const int nst_full = ((a.N & 15) == 0 && (a.N1 & 31) == 0) ? 4 * ((a.N >> 4) + (a.N1 >> 4)) : -1;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   auto store16 = [&](f32x4 v, __amdgpu_buffer_rsrc_t res, int voff, int soff) {      // (hazard: see wino_pipe_body)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), res, voff, soff, 0);
@@ -534,8 +552,13 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
   for (;;) {
     const bool more = tile + tstride < ntiles;
     // the group's patch has landed (only a finished group's stores are younger)
-    if (__builtin_amdgcn_readfirstlane(stores_behind) == NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTB) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+      const int sb = __builtin_amdgcn_readfirstlane(stores_behind);
+      if (SQZ && sb == NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTB) : "memory");
+      else if (!SQZ && sb == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (!SQZ && sb >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("" ::: "memory");
     stores_behind = 0;
     // ---- input transform of the whole group (both chunks), kept in registers for every pass ----
@@ -568,6 +591,17 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
     const GPos nxt = group_pos(ntile);
     dma_group(nxt);
 
+    const int ysoff_g = (int)(unsigned)(cur.p0 * a.y_pitch * 4);
+    const bool wholexy = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W;
+    // SQZ = false: channels [c0 + 4 g, +4) of window `res` for the tile's four pixels
+    auto store_out = [&](__amdgpu_buffer_rsrc_t res, int c0, int nlim, const f32x4 (&ov)[4]) {
+      if (!cur.valid || c0 + 4 * g >= nlim) return;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        if (!wholexy && !(cur.y0 + 2 * ty + (px >> 1) < a.H && cur.x0 + 2 * tx + (px & 1) < a.W)) continue;
+        store16(ov[px], res, o_offB[px] + c0 * 4, ysoff_g);
+      }
+    };
     auto squeeze_in = [&](int bi, const f32x4 (&ov)[4]) {
       const float* const sA = sqAL + bi * (4 * NSQ * 64) + lane;
 #pragma unroll
@@ -640,7 +674,8 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
             inv1([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
 #pragma unroll
             for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
-            squeeze_in(bi0 + r, ov);
+            if constexpr (SQZ) squeeze_in(bi0 + r, ov);
+            else { const int s1 = pass - P3; store_out(yres1, 128 * (s1 >> 1) + (2 * r + (s1 & 1)) * 16, a.N1, ov); }
           }
         } else {
           auto inv = [&](auto half, auto put) {
@@ -663,15 +698,17 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
           inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
 #pragma unroll
           for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
-          squeeze_in(pass, ov);
+          if constexpr (SQZ) squeeze_in(pass, ov);
+          else store_out(yres, pass * 16, a.N, ov);
         }
       };
       for (int pass = 0; pass < P3; ++pass) run_pass(std::integral_constant<int, 0>{}, pass);
       if (e1_half) { for (int pass = P3; pass < P; ++pass) run_pass(std::integral_constant<int, 2>{}, pass); }
       else { for (int pass = P3; pass < P; ++pass) run_pass(std::integral_constant<int, 1>{}, pass); }
     }
+    if constexpr (!SQZ) stores_behind = (cur.valid && wholexy && nst_full > 0) ? nst_full : 0;
     // ---- the group's squeeze output: ReLU + store; the accumulators restart from the bias ----
-    if (cur.valid) {
+    if (SQZ && cur.valid) {
       const int ysoff = (int)(unsigned)(cur.p0 * a.y_pitch * 4);
       const bool whole = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W && NSQ * 16 <= a.br_nsq;
 #pragma unroll
@@ -696,15 +733,15 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSQ>
+template <int NSQ, bool SQZ>
 __global__ __launch_bounds__(512, 1) void fire_bridge16_kernel(WinoArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  wino_bridge16_body<NSQ>(a);
+  wino_bridge16_body<NSQ, SQZ>(a);
 #endif
 }
 
 // bias table / squeeze operand blocks of this form: 16-wide passes (see sqd_fire_bridge_fwd)
-template <int NSQ>
+template <int NSQ, bool SQZ = true>
 static int launch_wino_bridge16(WinoArgs a, hipStream_t stream) {
   constexpr int WV = 8, NTHR = WV * 64;
   const int nchunks = a.C >> 3;
@@ -714,11 +751,11 @@ static int launch_wino_bridge16(WinoArgs a, hipStream_t stream) {
   // the expand1x1 passes are the 16-wide slices of the packed axis behind ceil32(N3)
   const int first1 = sqd_cdiv(a.N, 32) * 2;
   const int e1_stage = a.N1 <= 64 ? 1024 : 2048;
-  const int nblk = first1 + 4 * P1;
+  const int nblk = SQZ ? first1 + 4 * P1 : 0;
   const size_t lds = (size_t)(2 * WV * 256 * 4 + first1 * nchunks * 2048 + P1 * nchunks * e1_stage + nblk * 4 * NSQ * 64 + (first1 + P1) * 64) * sizeof(float);
   (void)P3;
   if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
-  auto kern = fire_bridge16_kernel<NSQ>;
+  auto kern = fire_bridge16_kernel<NSQ, SQZ>;
   if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {

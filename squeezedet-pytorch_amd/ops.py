@@ -495,10 +495,18 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=No
     return y
 
 
-FIRE_WINO_CFGS = (4, 6, 8, 10)      # 32-channel-slice ids of the deep-prefetch / U-stationary Winograd family
+FIRE_WINO_CFGS = (4, 6, 8, 10, 12)  # 32-channel-slice ids of the deep-prefetch / U-stationary Winograd family; 12: the small-C form
 
 
-def fire_wino_cfg_ok(cfg_id, C):
+def fire_wino_cfg_ok(cfg_id, C, E1=None, E3=None):
+    """Whether ``fire_wino`` can run configuration ``cfg_id`` on a Fire with squeeze width C (and, for the small-C form 12 whose
+    LDS plan holds every channel pass's U, expand widths E1 / E3)."""
+    if cfg_id % 1000 == 12:
+        if C % 8 or C > 16 or E1 is None or E3 is None:
+            return False
+        P3, P1 = -(-E3 // 32), -(-E1 // 128)
+        lds = 4 * (2 * 8 * 256 * 4 + 2 * P3 * (C // 8) * 2048 + 2 * P1 * (C // 8) * (1024 if E1 <= 64 else 2048) + (2 * P3 + 2 * P1) * 64)
+        return lds <= 160 * 1024
     return cfg_id % 1000 in FIRE_WINO_CFGS and wino_cfg_ok(cfg_id, C)
 
 
@@ -508,7 +516,11 @@ def choose_fire_wino_cfg(C, E1, E3, npix):
     if C % 8 or E1 % 16 or E3 % 4:
         return None
     hit = _tuning().get(f'X:{C}:{E3}:{npix}')
-    return hit if (hit is not None and hit >= 0 and fire_wino_cfg_ok(hit, C)) else None
+    return hit if (hit is not None and hit >= 0 and fire_wino_cfg_ok(hit, C, E1, E3)) else None
+
+
+def fire_wino_kernel_name(cfg_id):
+    return 'fire_wino16' if cfg_id % 1000 == 12 else wino_kernel_name(cfg_id).replace('conv_wino', 'fire_wino')
 
 
 class FireWinoPlan:
@@ -521,8 +533,8 @@ class FireWinoPlan:
         N1 = w1.shape[0]
         if tuple(w3.shape) != (N3, C, 3, 3) or tuple(w1.shape) != (N1, C, 1, 1) or C % 8 or N1 % 16 or N3 % 4:
             raise ValueError(f'fire_wino: need expand3x3 [N3,C,3,3] and expand1x1 [N1,C,1,1], C % 8 == 0, got {tuple(w3.shape)}, {tuple(w1.shape)}')
-        if not fire_wino_cfg_ok(cfg_id, C):
-            raise ValueError(f'fire_wino: configuration {cfg_id} cannot run C={C}')
+        if not fire_wino_cfg_ok(cfg_id, C, N1, N3):
+            raise ValueError(f'fire_wino: configuration {cfg_id} cannot run C={C} E={N1}+{N3}')
         self.cfg_id, self.C, self.N3, self.N1 = cfg_id, C, N3, N1
         self.Npad = -(-N3 // 32) * 32 + -(-N1 // 128) * 32
         self.w = torch.empty(C // 8, 16, self.Npad, 8, device=w3.device, dtype=torch.float32)
@@ -546,7 +558,7 @@ def fire_wino(x, x_coff, plan, y, y_coff1, y_coff3):
     br = None
     if _timer is not None:
         npix = B * H * W
-        br = _Bracket(wino_kernel_name(plan.cfg_id).replace('conv_wino', 'fire_wino'), f'fire C{plan.C} E{plan.N1}+{plan.N3} {H}x{W}',
+        br = _Bracket(fire_wino_kernel_name(plan.cfg_id), f'fire C{plan.C} E{plan.N1}+{plan.N3} {H}x{W}',
                       2.0 * npix * plan.C * (4 * plan.N3 + plan.N1), 4.0 * (npix * (plan.C + plan.N1 + plan.N3) + plan.C * (16 * plan.N3 + plan.N1)))
     rc = nat.lib().sqd_fire_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.b3), nat.ptr(plan.b1), nat.ptr(y), B, H, W, plan.C, xp, x_coff,
                                      plan.N3, y_coff3, plan.N1, y_coff1, plan.Npad, yp, plan.cfg_id, nat.stream_handle(x.device))

@@ -58,7 +58,7 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
         xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fuse_expand and use_winograd) else None
         fcfg = ops.choose_fused_cfg(s, e1, npix) if (xcfg is None and fuse_expand and e1 == e3) else None
         if xcfg is not None:
-            plan.append((ops.wino_kernel_name(xcfg).replace('conv_wino', 'fire_wino'), f'fire C{s} E{e1}+{e3} {H}x{W}'))
+            plan.append((ops.fire_wino_kernel_name(xcfg), f'fire C{s} E{e1}+{e3} {H}x{W}'))
         elif fcfg is not None:
             plan.append((ops.cfg_kernel_name(fcfg).replace('conv_dma', 'fire_expand'), f'expand C{s} E{e1} {H}x{W}'))
         else:
