@@ -245,6 +245,16 @@ int sqd_fire_bridge_fwd(const float* x, const float* u_packed, const float* bias
                         float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total, int Nsq,
                         int y_pitch, int y_coff, int cfg_id, void* stream);
 
+/* Fire k's expand pair + torch.cat + MaxPool2d(3, 2, ceil_mode=True) + Fire k+1's squeeze (src/model/squeezedet.py:18-22 and the
+ * features[...] sequence at 47-52: Fire, MaxPool2d, Fire) in ONE launch (inference): y [B][Hp][Wp] window [y_coff, +Nsq) =
+ * ReLU(Wsq . maxpool(cat(ReLU(conv1x1(x) + b1), ReLU(conv3x3(x) + b3))) + bsq).  Neither the expand output nor the pooled tensor
+ * is written.  C <= 16, N1 <= 64, N3 <= 64, Nsq <= 32.  u_packed / bias_tab as for sqd_fire_bridge_fwd cfg 12; sq_ops
+ * [blocks][4][ceil(Nsq/16)][64] with one block per expand3x3 pass and TWO per expand1x1 pass s1 (channels 128 (s1 >> 1) +
+ * (2 r + (s1 & 1)) 16 + n, r = 0, 1).  Hp x Wp = the pool's output size.  nseg >= 1: vertical segments per column strip. */
+int sqd_fire_pool_bridge_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                             float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total, int Nsq,
+                             int Hp, int Wp, int y_pitch, int y_coff, int nseg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

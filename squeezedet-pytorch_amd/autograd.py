@@ -54,6 +54,8 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
     for i in range(first, len(layers)):
         l = layers[i]
         if l[0] == 'pool':
+            if bridged is not None:                # the previous Fire's launch already pooled and squeezed
+                continue
             Bq, H, W, C = a.shape
             nxt = layers[i + 1] if i + 1 < len(layers) else None
             if (not save and base.fuse_pool_squeeze and nxt is not None and nxt[0] == 'fire' and ops.pool_squeeze_ok(C, nxt[2])):
@@ -88,6 +90,16 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                     ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
             fusable = not save and not (drop_mask is not None and i == len(layers) - 1)
             nxt = layers[i + 1] if i + 1 < len(layers) else None
+            nxt2 = layers[i + 2] if i + 2 < len(layers) else None
+            if (fusable and nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire' and base.fuse_fire_bridge
+                    and base.use_winograd):
+                zseg = ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix)
+                if zseg is not None:
+                    # inference: expand pair + concat + the max pool + the squeeze of the Fire behind it in one launch
+                    bridged = torch.empty(Bq, *ops.pool_out_size(H, W), nxt2[2], device=sq.device, dtype=torch.float32)
+                    ops.fire_pool_bridge(sq, 0, base.fire_bridge_plan(i, fire, feats[i + 2], 12, pooled=True), bridged, 0, nseg=zseg)
+                    a = None
+                    continue
             if fusable and nxt is not None and nxt[0] == 'fire' and base.fuse_fire_bridge and base.use_winograd:
                 ycfg = ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix)
                 if ycfg is not None:

@@ -67,6 +67,9 @@ struct WinoArgs {
   // Fire -> Fire bridge (sqd_fire_bridge_fwd, wino_bridge.h): the next squeeze as MFMA operands, bias tables, its width
   const float* br_w; const float* br_bias; const float* br_sqb;
   int br_nsq;
+  // ... through a 3x3 / stride-2 max pool (sqd_fire_pool_bridge_fwd, wino_poolbridge.h): pooled size, strips of 7 pooled
+  // columns, segments of pb_gseg group rows (4 pixel rows each) out of pb_ng
+  int pb_hp, pb_wp, pb_ns, pb_nseg, pb_gseg, pb_ng;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w_t;
@@ -856,6 +859,7 @@ static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
 }
 
 #include "wino_bridge.h"
+#include "wino_poolbridge.h"
 
 template <int NT, int WV>
 static int launch_wino(WinoArgs a, hipStream_t stream) {
@@ -1119,4 +1123,36 @@ extern "C" int sqd_fire_bridge_fwd(const float* x, const float* u_packed, const 
     case 12: return one ? launch_wino_bridge16<1>(a, s) : launch_wino_bridge16<2>(a, s);
   }
   return SQD_ERR_UNSUPPORTED;
+}
+
+// Fire k's expand pair + torch.cat + MaxPool2d(3, 2, ceil_mode=True) + Fire k+1's squeeze (src/model/squeezedet.py:18-22, 47-52) in
+// ONE launch: y [B][Hp][Wp][y_pitch] window [y_coff, +Nsq) = ReLU(Wsq . maxpool(cat(ReLU(conv1x1(x) + b1), ReLU(conv3x3(x) + b3))) + bsq).
+// Operands as for sqd_fire_bridge_fwd cfg 12 (16-wide passes) except that an expand1x1 pass contributes two channel blocks
+// (N1 <= 64, N3 <= 64, C <= 16, Nsq <= 32).  Hp x Wp must be the pool's output size for H x W.  nseg: segments a column
+// strip is cut into (parallelism vs. one recomputed group row per segment).
+extern "C" int sqd_fire_pool_bridge_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                                        float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total,
+                                        int Nsq, int Hp, int Wp, int y_pitch, int y_coff, int nseg, void* stream) {
+  SQD_CHECK_ARG(x && u_packed && bias_tab && sq_ops && y && B > 0 && H >= 3 && W >= 3 && C > 0 && N3 > 0 && N1 > 0 && Nsq > 0);
+  SQD_CHECK_ARG(C % 8 == 0 && N3 % 4 == 0 && N1 % 16 == 0 && Nsq % 4 == 0 && Nsq <= 32);
+  SQD_CHECK_ARG(x_pitch % 4 == 0 && x_coff % 4 == 0 && y_pitch % 4 == 0 && y_coff % 4 == 0);
+  SQD_CHECK_ARG(x_coff >= 0 && x_coff + C <= x_pitch && y_coff >= 0 && y_coff + Nsq <= y_pitch);
+  SQD_CHECK_ARG(Npad_total == sqd_cdiv(N3, 32) * 32 + sqd_cdiv(N1, 128) * 32);
+  int hp = (H - 2) / 2 + 1, wp = (W - 2) / 2 + 1;            // ceil((n - 3) / 2) + 1, last window must start inside the map
+  if ((hp - 1) * 2 >= H) --hp;
+  if ((wp - 1) * 2 >= W) --wp;
+  SQD_CHECK_ARG(Hp == hp && Wp == wp);
+  SQD_CHECK_ARG((long long)W * 6 * x_pitch * 4 < (1ll << 30) && (long long)(Wp + 8) * 2 * y_pitch * 4 < (1ll << 30));
+  SQD_CHECK_ARG((long long)B * (H + 8) * W * x_pitch * 4 < (1ll << 32) - (1ll << 30));
+  SQD_CHECK_ARG((long long)B * (Hp + 2) * Wp * y_pitch * 4 < (1ll << 32) - (1ll << 30));
+  SQD_CHECK_ARG((long long)(C >> 3) * 16 * Npad_total * 8 * 4 < (1ll << 32));
+  WinoArgs a{};
+  a.x = x; a.u = u_packed; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.N = N3; a.Npad = Npad_total; a.y_pitch = y_pitch; a.y_coff = y_coff; a.relu = 1;
+  a.N1 = N1;
+  a.br_w = sq_ops; a.br_bias = bias_tab; a.br_sqb = sq_bias; a.br_nsq = Nsq;
+  a.pb_hp = Hp; a.pb_wp = Wp;
+  hipStream_t s = (hipStream_t)stream;
+  return Nsq <= 16 ? launch_wino_poolbridge16<1>(a, nseg, s) : launch_wino_poolbridge16<2>(a, nseg, s);
 }

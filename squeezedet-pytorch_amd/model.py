@@ -198,17 +198,17 @@ class SqueezeDetBase(nn.Module):
         self._fused_plans[key] = (ver, p)
         return p
 
-    def fire_bridge_plan(self, idx, fire, nxt, cfg_id):
+    def fire_bridge_plan(self, idx, fire, nxt, cfg_id, pooled=False):
         """Operands of the one-launch form of ``fire``'s expand pair + ``nxt``'s squeeze (ops.fire_bridge, inference forward);
         rebuilt when any of the three modules' parameters change."""
-        key = ('firebridge', idx, cfg_id)
+        key = ('firebridge', idx, cfg_id, pooled)
         mods = (fire.expand1x1, fire.expand3x3, nxt.squeeze)
         ver = tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()))
         hit = self._fused_plans.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         p = ops.FireBridgePlan(fire.expand1x1.weight, fire.expand1x1.bias, fire.expand3x3.weight, fire.expand3x3.bias,
-                               nxt.squeeze.weight, nxt.squeeze.bias, cfg_id)
+                               nxt.squeeze.weight, nxt.squeeze.bias, cfg_id, pooled=pooled)
         self._fused_plans[key] = (ver, p)
         return p
 

@@ -596,16 +596,21 @@ def choose_fire_bridge_cfg(C, N1, N3, Nsq, npix):
 class FireBridgePlan:
     """Operands of ``fire_bridge``: the Fire's expand pair transformed as in FireWinoPlan, the per-pass bias table, and the next
     Fire's squeeze weights laid out as MFMA A operands (include/sqd_hip.h, sqd_fire_bridge_fwd)."""
-    __slots__ = ('cfg_id', 'C', 'N3', 'N1', 'Npad', 'Nsq', 'w', 'bias_tab', 'sq_ops', 'sq_bias')
+    __slots__ = ('cfg_id', 'C', 'N3', 'N1', 'Npad', 'Nsq', 'w', 'bias_tab', 'sq_ops', 'sq_bias', 'pooled')
 
-    def __init__(self, w1, b1, w3, b3, wsq, bsq, cfg_id):
+    def __init__(self, w1, b1, w3, b3, wsq, bsq, cfg_id, pooled=False):
         N3, C = w3.shape[0], w3.shape[1]
         N1, Nsq = w1.shape[0], wsq.shape[0]
         if tuple(w3.shape) != (N3, C, 3, 3) or tuple(w1.shape) != (N1, C, 1, 1) or tuple(wsq.shape) != (Nsq, N1 + N3, 1, 1):
             raise ValueError(f'fire_bridge: need expand3x3 [N3,C,3,3], expand1x1 [N1,C,1,1] and the next squeeze [Nsq,N1+N3,1,1], got '
                              f'{tuple(w3.shape)}, {tuple(w1.shape)}, {tuple(wsq.shape)}')
-        if not fire_bridge_cfg_ok(cfg_id, C, N3, N1, Nsq):
+        if pooled:
+            if not fire_pool_bridge_ok(C, N3, N1, Nsq):
+                raise ValueError(f'fire_pool_bridge: cannot run C={C} E={N1}+{N3} -> {Nsq}')
+            cfg_id = 12                              # (the operand layout of the 16-wide-pass form)
+        elif not fire_bridge_cfg_ok(cfg_id, C, N3, N1, Nsq):
             raise ValueError(f'fire_bridge: configuration {cfg_id} cannot run C={C} E={N1}+{N3} -> {Nsq}')
+        self.pooled = pooled
         dev = w3.device
         self.cfg_id, self.C, self.N3, self.N1, self.Nsq = cfg_id, C, N3, N1, Nsq
         P3, P1 = -(-N3 // 32), -(-N1 // 128)
@@ -616,10 +621,11 @@ class FireBridgePlan:
         # cat channel of every 16-channel block, in pass order: expand3x3 slices (cat offset N1), then expand1x1 slices
         narrow = cfg_id % 1000 == 12                 # 16-wide passes: 1 block per expand3x3 pass, 4 per expand1x1 pass
         if narrow:
-            base = [N1 + 16 * p for p in range(2 * P3)] + [128 * (s1 >> 1) + (2 * r + (s1 & 1)) * 16 for s1 in range(2 * P1) for r in range(4)]
+            rb = 2 if pooled else 4               # (the pooled form keeps only the blocks that exist when N1 <= 64)
+            base = [N1 + 16 * p for p in range(2 * P3)] + [128 * (s1 >> 1) + (2 * r + (s1 & 1)) * 16 for s1 in range(2 * P1) for r in range(rb)]
         else:
             base = [N1 + 32 * s + 16 * j for s in range(P3) for j in range(2)] + [128 * s + 16 * blk for s in range(P1) for blk in range(8)]
-        limit = [N1 + N3] * (2 * P3) + [N1] * (8 * P1)
+        limit = [N1 + N3] * (2 * P3) + [N1] * (len(base) - 2 * P3)
         nblk, nq = len(base), -(-Nsq // 16)
         ch = torch.tensor(base, device=dev).view(nblk, 1) + torch.arange(16, device=dev).view(1, 16)          # [blk][c16]
         ok = ch < torch.tensor(limit, device=dev).view(nblk, 1)
@@ -634,7 +640,8 @@ class FireBridgePlan:
         if narrow:
             bt = torch.zeros(2 * P3 + 2 * P1, 4, 16, device=dev, dtype=torch.float32)
             bt[:2 * P3, 0] = bvals[:2 * P3]
-            bt[2 * P3:] = bvals[2 * P3:].view(2 * P1, 4, 16)
+            rb = 2 if pooled else 4
+            bt[2 * P3:, :rb] = bvals[2 * P3:].view(2 * P1, rb, 16)
         else:
             bt = torch.zeros(P3 + P1, 8, 16, device=dev, dtype=torch.float32)
             bt[:P3, :2] = bvals[:2 * P3].view(P3, 2, 16)
@@ -647,8 +654,8 @@ def fire_bridge(x, x_coff, plan, y, y_coff):
     """y[..., y_coff:+Nsq] = relu(squeeze'(cat(relu(expand1x1(x)), relu(expand3x3(x))))) in ONE launch (inference)."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
     B, H, W, xp = x.shape
-    if tuple(y.shape[:3]) != (B, H, W):
-        raise ValueError('fire_bridge: x and y disagree on B,H,W')
+    if tuple(y.shape[:3]) != (B, H, W) or plan.pooled:
+        raise ValueError('fire_bridge: x and y disagree on B,H,W (or the plan is a pooled one)')
     yp = y.shape[3]
     if x_coff < 0 or x_coff + plan.C > xp or y_coff < 0 or y_coff + plan.Nsq > yp:
         raise ValueError('fire_bridge: channel window out of range')
@@ -662,6 +669,48 @@ def fire_bridge(x, x_coff, plan, y, y_coff):
                                        nat.ptr(y), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1, plan.Npad, plan.Nsq, yp, y_coff,
                                        plan.cfg_id, nat.stream_handle(x.device))
     nat.check(rc, 'sqd_fire_bridge_fwd')
+    if br is not None:
+        br.done()
+    return y
+
+
+def fire_pool_bridge_ok(C, N3, N1, Nsq):
+    """Whether ``fire_pool_bridge`` can run a Fire (squeeze width C, expands N1 + N3) -> pool -> squeeze (Nsq) chain."""
+    if C % 8 or C > 16 or N1 % 16 or N3 % 4 or N1 > 64 or N3 > 64 or Nsq % 4 or Nsq > 32:
+        return False
+    P3, P1 = -(-N3 // 32), -(-N1 // 128)
+    lds = 4 * (2 * 8 * 224 * 4 + 2 * P3 * (C // 8) * 2048 + 2 * P1 * (C // 8) * 1024 + (2 * P3 + 4 * P1) * 4 * -(-Nsq // 16) * 64
+               + (2 * P3 + 2 * P1) * 64 + -(-Nsq // 16) * 16)
+    return lds <= 160 * 1024
+
+
+def choose_fire_pool_bridge(C, N1, N3, Nsq, npix):
+    """Segments per column strip for the Fire -> pool -> Fire bridge (tuning.json row 'Z:C:N1:N3:Nsq:npix', cfg = segments) or None."""
+    hit = _tuning().get(f'Z:{C}:{N1}:{N3}:{Nsq}:{npix}')
+    return hit if (hit is not None and hit >= 1 and fire_pool_bridge_ok(C, N3, N1, Nsq)) else None
+
+
+def fire_pool_bridge(x, x_coff, plan, y, y_coff, nseg=4):
+    """y[..., y_coff:+Nsq] = relu(squeeze'(maxpool3x3s2_ceil(cat(relu(expand1x1(x)), relu(expand3x3(x)))))) in ONE launch
+    (inference); y is [B, Hp, Wp, .] with (Hp, Wp) = pool_out_size(H, W).  ``plan``: FireBridgePlan(..., pooled=True)."""
+    _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
+    B, H, W, xp = x.shape
+    Hp, Wp = pool_out_size(H, W)
+    if tuple(y.shape[:3]) != (B, Hp, Wp) or not plan.pooled:
+        raise ValueError('fire_pool_bridge: y must be [B, Hp, Wp, .] of the pooled map and the plan a pooled one')
+    yp = y.shape[3]
+    if x_coff < 0 or x_coff + plan.C > xp or y_coff < 0 or y_coff + plan.Nsq > yp:
+        raise ValueError('fire_pool_bridge: channel window out of range')
+    br = None
+    if _timer is not None:
+        npix = B * H * W
+        br = _Bracket('fire_pool_bridge', f'fire C{plan.C} E{plan.N1}+{plan.N3} -> pool -> S{plan.Nsq} {H}x{W}',
+                      2.0 * (npix * plan.C * (4 * plan.N3 + plan.N1) + B * Hp * Wp * (plan.N1 + plan.N3) * plan.Nsq),
+                      4.0 * (npix * plan.C + B * Hp * Wp * plan.Nsq + plan.C * (16 * plan.N3 + plan.N1) + (plan.N1 + plan.N3) * plan.Nsq))
+    rc = nat.lib().sqd_fire_pool_bridge_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias_tab), nat.ptr(plan.sq_ops), nat.ptr(plan.sq_bias),
+                                            nat.ptr(y), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1, plan.Npad, plan.Nsq, Hp, Wp, yp, y_coff,
+                                            int(nseg), nat.stream_handle(x.device))
+    nat.check(rc, 'sqd_fire_pool_bridge_fwd')
     if br is not None:
         br.done()
     return y

@@ -40,7 +40,8 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
     for i in range(first, len(layers)):
         l = layers[i]
         if l[0] == 'pool':
-            plan.append(('maxpool_fwd', f'pool C{C} {H}x{W}'))
+            if not bridged:
+                plan.append(('maxpool_fwd', f'pool C{C} {H}x{W}'))
             H, W = ops.pool_out_size(H, W)
             continue
         _, cin, s, e1, e3 = l
@@ -50,6 +51,12 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
         bridged = False
         C = e1 + e3
         nxt = layers[i + 1] if i + 1 < len(layers) else None
+        nxt2 = layers[i + 2] if i + 2 < len(layers) else None
+        if nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire' and fuse_fire_bridge and use_winograd:
+            if ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix) is not None:
+                plan.append(('fire_pool_bridge', f'fire C{s} E{e1}+{e3} -> pool -> S{nxt2[2]} {H}x{W}'))
+                bridged = True
+                continue
         if nxt is not None and nxt[0] == 'fire' and fuse_fire_bridge and use_winograd:
             if ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix) is not None:
                 plan.append(('fire_bridge', f'fire C{s} E{e1}+{e3} -> S{nxt[2]} {H}x{W}'))

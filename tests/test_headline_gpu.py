@@ -44,7 +44,13 @@ class LaunchLog:
         def fire_bridge(x, x_coff, plan, y, y_coff):
             self.calls.append(('bridge', 9, plan.C, (plan.N1, plan.N3, plan.Nsq), x.shape[0] * x.shape[1] * x.shape[2], plan.cfg_id))
             return real_bridge(x, x_coff, plan, y, y_coff)
+        real_pool_bridge = ops.fire_pool_bridge
+
+        def fire_pool_bridge(x, x_coff, plan, y, y_coff, nseg=4):
+            self.calls.append(('poolbridge', 9, plan.C, (plan.N1, plan.N3, plan.Nsq), x.shape[0] * x.shape[1] * x.shape[2], nseg))
+            return real_pool_bridge(x, x_coff, plan, y, y_coff, nseg=nseg)
         monkeypatch.setattr(ops, 'fire_bridge', fire_bridge)
+        monkeypatch.setattr(ops, 'fire_pool_bridge', fire_pool_bridge)
         monkeypatch.setattr(ops, 'conv', conv)
         monkeypatch.setattr(ops, 'conv_wino', conv_wino)
         monkeypatch.setattr(ops, 'fire_expand', fire_expand)
@@ -56,11 +62,11 @@ class LaunchLog:
         for an expand1x1, an expand3x3 and the next squeeze, where the table has a ``Y:`` row)."""
         tab = ops._tuning()
         n3 = 0
-        assert sum(1 for c in self.calls if c[0] == 'bridge') == expect_bridges
+        assert sum(1 for c in self.calls if c[0] in ('bridge', 'poolbridge')) == expect_bridges
         for kind, taps, C, N, npix, cfg in self.calls:
-            if kind == 'bridge':
+            if kind in ('bridge', 'poolbridge'):
                 n3 += 1
-                key = f'Y:{C}:{N[0]}:{N[1]}:{N[2]}:{npix}'
+                key = f"{'Y' if kind == 'bridge' else 'Z'}:{C}:{N[0]}:{N[1]}:{N[2]}:{npix}"
             elif kind == 'fused':
                 n3 += 1
                 assert allow_fused, f'fused expand C{C} E{N} npix {npix}: expected separate expand1x1 + Winograd launches'
@@ -116,8 +122,9 @@ def test_squeezedet_bs20_inference_vs_oracle(monkeypatch):
     log = LaunchLog(monkeypatch)
     with torch.no_grad():
         pred = det.model.base(xg)
-    log.assert_exact_table_hits(expect_3x3=11, expect_bridges=1)             # 10 expand3x3 (fire3's inside the fire3 -> fire4 bridge) + ConvDet
-    assert sum(1 for c in log.calls if c[1] == 1) == 18    # 10 squeeze + 10 expand1x1, less fire3's expand1x1 and fire4's squeeze (bridge)
+    # 10 expand3x3 (fire3's inside the fire3 -> fire4 bridge, fire4's inside the fire4 -> pool -> fire6 bridge) + ConvDet
+    log.assert_exact_table_hits(expect_3x3=11, expect_bridges=2)
+    assert sum(1 for c in log.calls if c[1] == 1) == 16    # 10 squeeze + 10 expand1x1, less the two expand1x1 and two squeezes inside the bridges
     with torch.no_grad():
         ref = oracle.backbone_forward(x, sd)
     assert tuple(pred.shape) == (20, 16848, 8)

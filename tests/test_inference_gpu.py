@@ -353,10 +353,10 @@ def test_golden_forward_through_one_launch_winograd_fire(golden_dir, monkeypatch
 
 
 def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
-    """The reference-generated goldens with every Fire -> Fire pair the bridge launch can take (expand pair + the next Fire's
-    squeeze in one kernel, squeeze width <= 32: fire3 -> fire4 and fire6 -> fire7 of SqueezeDet, none of SqueezeDet+; the
-    shipped table takes fire3 -> fire4 at the headline shape) forced onto it: same 1e-4 bound, and the switch
-    ``fuse_fire_bridge = False`` gives the plain path back."""
+    """The reference-generated goldens with every Fire -> Fire pair the bridge launches can take (expand pair + the next Fire's
+    squeeze in one kernel, squeeze width <= 32: fire3 -> fire4 and fire6 -> fire7 of SqueezeDet; and through the max pool,
+    fire4 -> pool -> fire6; none of SqueezeDet+; the shipped table takes fire3 -> fire4 and fire4 -> pool -> fire6 at the
+    headline shape) forced onto them: same 1e-4 bound, and the switch ``fuse_fire_bridge = False`` gives the plain path back."""
     from squeezedet_pytorch_amd import ops
     used = {'n': 0}
 
@@ -367,6 +367,13 @@ def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
                 return cid
         return None
     monkeypatch.setattr(ops, 'choose_fire_bridge_cfg', always)
+
+    def always_pooled(C, E1, E3, Nsq, npix):
+        if not ops.fire_pool_bridge_ok(C, E3, E1, Nsq):
+            return None
+        used['n'] += 1
+        return 3
+    monkeypatch.setattr(ops, 'choose_fire_pool_bridge', always_pooled)
     monkeypatch.setattr(ops, 'choose_wino_cfg', lambda C, N, npix: (2 if C % 8 == 0 else None))
     g = np.load(os.path.join(golden_dir, "backbone_small.npz"))
     for arch in ("squeezedet", "squeezedetplus"):
@@ -387,4 +394,4 @@ def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
         pred1 = m.base(x1.cuda())
     np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
     np.testing.assert_allclose(pred1[0].cpu().numpy()[gk["top_idx"]], gk["pred_top"], atol=TOL, rtol=0)
-    assert used['n'] == 4                                   # two pairs x two SqueezeDet forwards
+    assert used['n'] == 6                                   # three bridges x two SqueezeDet forwards

@@ -338,7 +338,7 @@ def test_conv_wgrad_winograd(C, N, B, H, W):
 
 
 @pytest.mark.parametrize("C,E1,E3,S,B,H,W", [
-    (16, 64, 64, 16, 2, 12, 20), (16, 64, 64, 16, 6, 96, 312), (8, 32, 40, 12, 1, 5, 17), (16, 96, 48, 16, 2, 11, 23),
+    (16, 64, 64, 16, 2, 12, 20), (16, 64, 64, 16, 6, 96, 312), (8, 32, 40, 12, 1, 5, 17), (16, 96, 48, 16, 2, 11, 23), (8, 32, 32, 32, 2, 10, 21),
     (16, 144, 32, 24, 3, 13, 50), (16, 48, 96, 32, 2, 7, 40), (32, 128, 128, 32, 2, 24, 78), (48, 192, 192, 32, 1, 9, 20),
 ])
 def test_fire_bridge_one_launch(C, E1, E3, S, B, H, W):
@@ -369,6 +369,38 @@ def test_fire_bridge_one_launch(C, E1, E3, S, B, H, W):
         assert bool((yc[..., :4] == -7.0).all()) and bool((yc[..., 4 + S:] == -7.0).all())
         ran += 1
     assert ran >= 1
+
+
+@pytest.mark.parametrize("C,E1,E3,S,B,H,W,nseg", [
+    (16, 64, 64, 32, 1, 8, 32, 1), (16, 64, 64, 32, 1, 8, 32, 2), (16, 64, 64, 32, 2, 9, 37, 1), (8, 32, 40, 12, 1, 5, 17, 1),
+    (16, 48, 64, 16, 2, 12, 30, 3), (16, 64, 32, 24, 3, 13, 50, 2), (8, 16, 16, 32, 1, 24, 14, 6), (16, 64, 64, 32, 3, 96, 312, 4),
+    (8, 16, 8, 4, 1, 3, 3, 1), (16, 64, 64, 32, 1, 31, 45, 5), (16, 64, 64, 32, 2, 7, 100, 9),
+])
+def test_fire_pool_bridge_one_launch(C, E1, E3, S, B, H, W, nseg):
+    """Fire k's expand pair + concat + MaxPool2d(3, 2, ceil_mode=True) + Fire k+1's squeeze in ONE launch (sqd_fire_pool_bridge_fwd)
+    == the reference's four modules in fp32 (src/model/squeezedet.py:18-22, 47-52): odd and even map sizes (windows clipped at the
+    right / bottom edge), maps smaller than a group, one to many segments per strip (the carried pooled row crosses segment
+    and image ends), partial channel blocks, bytes outside the output window untouched."""
+    ops = _ops()
+    x = F.relu(_rand(B, C, H, W, seed=61))
+    w1 = _rand(E1, C, 1, 1, seed=62, scale=(2.0 / C) ** 0.5); b1 = _rand(E1, seed=63, scale=0.1)
+    w3 = _rand(E3, C, 3, 3, seed=64, scale=(2.0 / (C * 9)) ** 0.5); b3 = _rand(E3, seed=65, scale=0.1)
+    ws = _rand(S, E1 + E3, 1, 1, seed=66, scale=(2.0 / (E1 + E3)) ** 0.5); bs = _rand(S, seed=67, scale=0.1)
+    mid = torch.cat([F.relu(F.conv2d(x, w1, b1)), F.relu(F.conv2d(x, w3, b3, padding=1))], 1)
+    ref = _nhwc(F.relu(F.conv2d(F.max_pool2d(mid, 3, 2, ceil_mode=True), ws, bs)))
+    assert ops.fire_pool_bridge_ok(C, E3, E1, S)
+    plan = ops.FireBridgePlan(w1.cuda(), b1.cuda(), w3.cuda(), b3.cuda(), ws.cuda(), bs.cuda(), 12, pooled=True)
+    Hp, Wp = ops.pool_out_size(H, W)
+    assert tuple(ref.shape[:3]) == (B, Hp, Wp)
+    y = torch.full((B, Hp, Wp, S + 8), -7.0, device='cuda')
+    ops.fire_pool_bridge(_nhwc(x).cuda(), 0, plan, y, 4, nseg=nseg)
+    torch.cuda.synchronize()
+    yc = y.cpu()
+    assert (yc[..., 4:4 + S] - ref).abs().max().item() <= _tol(ref)
+    assert bool((yc[..., :4] == -7.0).all()) and bool((yc[..., 4 + S:] == -7.0).all())
+    with pytest.raises(ValueError):
+        ops.fire_bridge(_nhwc(x).cuda(), 0, plan, torch.empty(B, H, W, S, device='cuda'), 0)      # a pooled plan is not a plain bridge plan
+    assert not ops.fire_pool_bridge_ok(32, E3, E1, S) and not ops.fire_pool_bridge_ok(C, E3, 128, S)
 
 
 @pytest.mark.parametrize("C,E1,E3,B,H,W", [
