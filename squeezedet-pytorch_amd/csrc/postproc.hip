@@ -134,9 +134,10 @@ extern "C" int sqd_resolve_fwd(const float* pred, const float* anchors, float* p
 }
 
 // ---- fused detection ----
-// One launch, one workgroup per image.  Phase 1 (1024 threads) scores the anchors into LDS keys -- the fp32 score bits if
-// score > score_thresh, else 0; phase 2 (the first 256 threads) compacts the non-zero keys (stable, ascending anchor
-// index), selects the top K, ranks them, runs class-wise NMS and writes the compact result.  (Tried and dropped in
+// One launch, one workgroup per image of 1024 threads.  Phase 1 scores the anchors into LDS keys -- the fp32 score bits if
+// score > score_thresh, else 0; phase 2 compacts the non-zero keys (stable, ascending anchor index) and selects the top K
+// (radix select; the 256 histogram bins belong to the first 256 threads, the candidate sweeps run on all 1024), ranks them,
+// runs class-wise NMS on one wave and writes the compact result.  (Tried and dropped in
 // round 2: spreading phase 1 over the whole chip and handing the keys to the last-arriving workgroup of each image
 // through global memory -- the device-scope release / acquire pair across the XCDs' L2s cost 12-100 us, more than the
 // 20 idle-chip microseconds it saved; profiles/r02_detect_variants.log.)
@@ -156,7 +157,7 @@ struct DetArgs {
   float wmax, hmax, nms_thresh, score_thresh;
 };
 
-#define DET_SCORE_THREADS 1024      // phase 1 (scoring) runs 16 waves wide; phase 2 continues on the first DET_THREADS threads
+#define DET_SCORE_THREADS 1024      // threads per image (16 waves)
 
 __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
   unsigned short* cidx = (unsigned short*)(smem_raw + (size_t)((a.A + 3) & ~3) * 4);   // [A] candidate anchor indices
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_need, s_cnt, s_nlive;
-  __shared__ unsigned wave_tot[DET_THREADS / 64];
+  __shared__ unsigned wave_tot[DET_SCORE_THREADS / 64];
   __shared__ unsigned cand_key[DET_K];
   __shared__ int cand_idx[DET_K];
   __shared__ int sorted_pos[DET_K];
@@ -214,7 +215,6 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
     }
   }
   __syncthreads();
-  if (tid >= DET_THREADS) return;            // phase 2 runs on 4 waves (its barriers only count the waves still alive)
 
   if (tid < DET_K) { cand_key[tid] = 0u; cand_idx[tid] = 0x7fffffff - DET_K + tid; }   // distinct sentinels: ranks stay a permutation
   if (tid == 0) { s_prefix = 0u; s_need = (unsigned)K; s_cnt = 0u; }
@@ -231,13 +231,13 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     unsigned woff = 0u, tot = 0u;
-    for (int w = 0; w < DET_THREADS / 64; ++w) { if (w < wave) woff += wave_tot[w]; tot += wave_tot[w]; }
+    for (int w = 0; w < DET_SCORE_THREADS / 64; ++w) { if (w < wave) woff += wave_tot[w]; tot += wave_tot[w]; }
     total = tot;
     return incl - c + woff;
   };
 
   // 1. stable compaction of the above-threshold anchors: contiguous index range per thread
-  const int chunk = (A + DET_THREADS - 1) / DET_THREADS;
+  const int chunk = (A + DET_SCORE_THREADS - 1) / DET_SCORE_THREADS;
   const int lo = tid * chunk, hi = min(A, lo + chunk);
   __syncthreads();
   unsigned c = 0u;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
 
   int ncand;
   if ((int)M <= K) {
-    for (int i = tid; i < (int)M; i += DET_THREADS) { cand_key[i] = keysL[cidx[i]]; cand_idx[i] = cidx[i]; }
+    for (int i = tid; i < (int)M; i += DET_SCORE_THREADS) { cand_key[i] = keysL[cidx[i]]; cand_idx[i] = cidx[i]; }
     ncand = (int)M;
     __syncthreads();
   } else {
@@ -258,12 +258,12 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
     unsigned mask = 0u;
     for (int pass = 0; pass < 4; ++pass) {
       const int shift = 24 - 8 * pass;
-      hist[tid] = 0u;                                          // DET_THREADS == 256 bins
+      if (tid < DET_THREADS) hist[tid] = 0u;                   // DET_THREADS == 256 bins
       __syncthreads();
       const unsigned prefix = s_prefix;
       // scores cluster in 2-3 exponent bins: in the leading pass aggregate equal bins inside a wave (one
       // atomic per distinct bin) instead of serialising up to 64 same-address LDS atomics
-      for (int i0 = 0; i0 < (int)M; i0 += DET_THREADS) {
+      for (int i0 = 0; i0 < (int)M; i0 += DET_SCORE_THREADS) {
         const int i = i0 + tid;
         const unsigned k = (i < (int)M) ? keysL[cidx[i]] : 0u;
         const bool act = (i < (int)M) && ((k & mask) == prefix);
@@ -286,10 +286,10 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
         // bucket holding the need-th largest key: thread t owns bin 255-t; an exclusive block scan gives the
         // number of keys in higher bins (256 threads in parallel instead of a serial 256-step walk)
         const unsigned need = s_need;
-        const unsigned h = hist[255 - tid];
+        const unsigned h = (tid < DET_THREADS) ? hist[255 - tid] : 0u;
         unsigned tot;
         const unsigned above = block_excl_scan(h, tot);
-        if (above < need && above + h >= need) {          // exactly one thread
+        if (tid < DET_THREADS && above < need && above + h >= need) {          // exactly one thread
           s_need = need - above;                          // how many keys to take from this bucket (and below-level ties)
           s_prefix = prefix | ((unsigned)(255 - tid) << shift);
         }
@@ -301,12 +301,12 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
     const unsigned need = s_need;         // number of keys == tkey to take (>= 1)
     const unsigned n_gt = (unsigned)K - need;
     // 3a. keys strictly above the threshold key (unordered; ranked later)
-    for (int i = tid; i < (int)M; i += DET_THREADS) {
+    for (int i = tid; i < (int)M; i += DET_SCORE_THREADS) {
       const unsigned k = keysL[cidx[i]];
       if (k > tkey) { const unsigned pos = atomicAdd(&s_cnt, 1u); cand_key[pos] = k; cand_idx[pos] = cidx[i]; }
     }
     // 3b. ties at the threshold key in ascending anchor order (the compacted list is index-ordered)
-    const int chunk2 = ((int)M + DET_THREADS - 1) / DET_THREADS;
+    const int chunk2 = ((int)M + DET_SCORE_THREADS - 1) / DET_SCORE_THREADS;
     const int lo2 = tid * chunk2, hi2 = min((int)M, lo2 + chunk2);
     unsigned c2 = 0u;
     for (int i = lo2; i < hi2; ++i) c2 += (keysL[cidx[i]] == tkey) ? 1u : 0u;
