@@ -19,6 +19,7 @@ def short_name(k):
     if m: return f"conv_ws<{m.group(1)},{m.group(2)}>"
     m = re.match(r"conv_wino_pipe_kernel<(\d+), (\d+), (true|false)", short)
     if m: return f"conv_wino_{'us' if m.group(3) == 'true' else 'dp'}<{m.group(1)},{m.group(2)}>"
+    if short.startswith("fire_poolbridge16_kernel"): return "fire_pool_bridge"
     m = re.match(r"fire_bridge(16)?_kernel<[^>]*?(true|false)?>", short)
     if m: return "fire_wino16" if (m.group(1) and m.group(2) == "false") else "fire_bridge"
     m = re.match(r"(maxpool_fwd|maxpool_bwd)_kernel", short)

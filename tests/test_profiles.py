@@ -20,7 +20,7 @@ def test_traffic_profile_matches_shipped_launch_set():
         assert prof[kernel].get('launches_per_step') == n, (kernel, prof[kernel].get('launches_per_step'), n)
     # and nothing conv-like in the profile that the plan no longer launches
     for kernel in prof:
-        if kernel.startswith(('conv_', 'fire_expand', 'stem_', 'maxpool', 'detect')):
+        if kernel.startswith(('conv_', 'fire_', 'stem_', 'maxpool', 'detect')):
             assert kernel in want, f'{kernel}: in the profile but not launched by the shipped plan'
 
 
@@ -28,6 +28,11 @@ def test_launch_plan_totals():
     from squeezedet_pytorch_amd import plan
     p = plan.inference_launch_plan('squeezedet', 20, (384, 1248))
     names = [n for n, _ in p]
-    assert names[0] == 'stem_pool<3>' and names[-1] == 'detect' and names.count('maxpool_fwd') == 2
-    assert sum(1 for n in names if n.startswith('conv_wino')) == 11            # 10 expand3x3 + ConvDet, all Winograd at bs=20
-    assert len(p) == 1 + 2 + 30 + 1 + 1
+    assert names[0] == 'stem_pool<3>' and names[-1] == 'detect'
+    # fire3's and fire4's expand pairs run inside the two bridge launches (with fire4's / fire6's squeeze, and the first pool)
+    assert names.count('fire_bridge') == 1 and names.count('fire_pool_bridge') == 1 and names.count('maxpool_fwd') == 1
+    assert sum(1 for n in names if n.startswith('conv_wino')) == 9             # 8 expand3x3 + ConvDet, all Winograd at bs=20
+    assert len(p) == 1 + 1 + 2 + 24 + 1 + 1             # stem+pool, pool, bridges, 8 squeeze + 8 expand1x1 + 8 expand3x3, ConvDet, detect
+    # without the bridges: the plain launch set
+    q = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_fire_bridge=False)
+    assert len(q) == 1 + 2 + 30 + 1 + 1 and sum(1 for n, _ in q if n.startswith('conv_wino')) == 11
