@@ -27,6 +27,14 @@ def test_every_tuned_entry_names_a_compiled_configuration(table):
             assert cid % 1000 in ops.wino_cfgs() and cid // 1000 <= 8 and int(C) % 8 == 0, key
             assert v["us"] > 0 and "direct_us" in v
             continue
+        if key.startswith(("Y:", "Z:")):                                          # Fire bridges: Y = configuration id, Z = segments per strip
+            _, C, E1, E3, Nsq, npix = key.split(":")
+            if key.startswith("Y:"):
+                assert ops.fire_bridge_cfg_ok(cid, int(C), int(E3), int(E1), int(Nsq)), key
+            else:
+                assert cid >= 1 and ops.fire_pool_bridge_ok(int(C), int(E3), int(E1), int(Nsq)), key
+            assert v["us"] > 0 and v["separate_us"] > v["us"], key                 # only kept where the one launch wins
+            continue
         assert 0 <= cid % 1000 < len(tab) and cid // 1000 <= 8, key
         taps = tab[cid % 1000][0]
         if key.startswith("F:"):
