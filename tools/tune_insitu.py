@@ -30,6 +30,10 @@ def main():
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--top', type=int, default=6, help='candidates per layer (fastest of the isolated measurement)')
     ap.add_argument('--ws', action='store_true', help='also try every applicable weight-stationary 1x1 configuration (conv_ws, caps 0..2) on the 1x1 rows')
+    ap.add_argument('--mode', default='infer', choices=('infer', 'train'),
+                    help="train: time the TRAINING step (fwd + loss + bwd + clip + SGD, hipGraph) and walk the rows only it consults "
+                         "(data-gradient orientations, measured in isolation WITHOUT their ReLU-mask / accumulate epilogues, and the forward "
+                         "rows the inference step no longer uses)")
     ap.add_argument('--replays', type=int, default=40)
     ap.add_argument('--passes', type=int, default=1)
     ap.add_argument('--gain', type=float, default=0.0015, help='relative step-time gain a change must show (noise floor)')
@@ -45,21 +49,63 @@ def main():
     x = synthetic.make_images(B, cfg.input_size, seed=0).cuda()
     bufs = ops._det_buffers(B, cfg.keep_top_k, x.device, cfg.num_anchors)
     tab = ops._tuning()                          # live {key: cfg} table the choosers read; edited in place
+    train_keys = []
+    if args.mode == 'train':
+        from squeezedet_pytorch_amd.model import SqueezeDetWithLoss
+        tmodel = SqueezeDetWithLoss(cfg)
+        tmodel.load_state_dict(synthetic.make_state_dict(args.arch, seed=1234))
+        tmodel = tmodel.cuda().train()
+        params = [p for p in tmodel.parameters() if p.requires_grad]
+        opt = torch.optim.SGD(params, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+        batch = {'image': x, 'gt': synthetic.make_gt(B, cfg.anchors, cfg.input_size, cfg.num_classes, seed=1).cuda()}
+
+        def train_step():
+            loss, _ = tmodel(batch)
+            loss = loss.mean()
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm)
+            opt.step()
+
+        # the rows the step consults: record the choosers' exact hits during one eager step
+        real_choose, real_wino = ops.choose_cfg, ops.choose_wino_cfg
+
+        def rec_choose(taps, C, N, npix, *a, **kw):
+            k = f'{taps}:{C}:{N}:{npix}'
+            if k in full and k not in train_keys:
+                train_keys.append(k)
+            return real_choose(taps, C, N, npix, *a, **kw)
+
+        def rec_wino(C, N, npix, *a, **kw):
+            k = f'W:{C}:{N}:{npix}'
+            if k in full and k not in train_keys:
+                train_keys.append(k)
+            return real_wino(C, N, npix, *a, **kw)
+        ops.choose_cfg, ops.choose_wino_cfg = rec_choose, rec_wino
+        train_step()
+        torch.cuda.synchronize()
+        ops.choose_cfg, ops.choose_wino_cfg = real_choose, real_wino
+
+    def run_step():
+        if args.mode == 'train':
+            train_step()
+        else:
+            det.detect_device(x, out=bufs)
 
     def step_ms():
         """Median hipGraph replay time of the whole step with the current table."""
-        model.base.invalidate_plans()
+        (tmodel.base if args.mode == 'train' else model.base).invalidate_plans()
         for _ in range(2):
-            det.detect_device(x, out=bufs)
+            run_step()
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            det.detect_device(x, out=bufs)
+            run_step()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
-                det.detect_device(x, out=bufs)
+                run_step()
         torch.cuda.current_stream().wait_stream(side)
         for _ in range(5):
             g.replay()
@@ -72,6 +118,7 @@ def main():
                 g.replay()
             e1.record(); torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) / args.replays)
+        del g
         return sorted(times)[1]
 
     # the table keys this workload actually consults, in launch order
@@ -85,6 +132,8 @@ def main():
         k = f'W:{C}:{N}:{B * h * w}' if taps == 9 else f'{taps}:{C}:{N}:{B * h * w}'
         if k in full and k not in keys:
             keys.append(k)
+    if args.mode == 'train':
+        keys = [k for k in train_keys if k not in keys]          # leave the inference step's rows alone
     base = step_ms()
     print(f'start: {base:.4f} ms/step ({B / base * 1e3:.0f} img/s), {len(keys)} table rows in play', flush=True)
     changed = {}
@@ -113,6 +162,7 @@ def main():
                 if t < best_t * (1.0 - args.gain):
                     best_c, best_t = c, t
             tab[k] = best_c
+            print(f'  .. {k}: {len(cands)} candidates, best {best_c} ({best_t:.4f} ms vs {base:.4f})', flush=True)
             if best_c != keep:
                 t2 = step_ms()                              # confirm against a fresh measurement of the incumbent
                 tab[k] = keep
