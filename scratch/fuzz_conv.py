@@ -100,4 +100,41 @@ while time.time() - t0 < budget:
         if not (e3 <= 1e-4 * sc and e4 <= 1e-4 * max(1.0, bg.grad.abs().max().item())):
             print('WGRAD MISMATCH', dict(taps=taps, B=B, H=H, W=W, C=C, N=N, e3=e3, e4=e4, sc=sc)); sys.exit(1)
         n_ok += 1
-print(f'fuzz ok: {n_ok} cases in {time.time() - t0:.0f} s, worst err/tol {worst:.2f}')
+# Fire bridges (one launch for expand pair + next squeeze, optionally through the max pool): random small-C Fire shapes
+tb = time.time()
+nb = 0
+while time.time() - tb < max(2.0, 0.15 * budget):
+    B = int(rs.randint(1, 4)); H = int(rs.choice([3, 4, 5, 8, 9, 13, 16, 23, 31])); W = int(rs.choice([3, 7, 14, 15, 16, 17, 29, 33, 47, 61]))
+    C = int(rs.choice([8, 16])); E1 = int(rs.choice([16, 32, 48, 64])); E3 = int(rs.choice([8, 16, 24, 40, 64])); S = int(rs.choice([4, 12, 16, 24, 32]))
+    x = torch.relu(torch.randn(B, C, H, W))
+    w1 = torch.randn(E1, C, 1, 1) / C ** 0.5; b1 = torch.randn(E1) * 0.1
+    w3 = torch.randn(E3, C, 3, 3) / (9 * C) ** 0.5; b3 = torch.randn(E3) * 0.1
+    ws = torch.randn(S, E1 + E3, 1, 1) / (E1 + E3) ** 0.5; bs = torch.randn(S) * 0.1
+    mid = torch.cat([torch.relu(F.conv2d(x, w1, b1)), torch.relu(F.conv2d(x, w3, b3, padding=1))], 1)
+    pooled = bool(rs.randint(0, 2))
+    args = [t.cuda() for t in (w1, b1, w3, b3, ws, bs)]
+    if pooled:
+        if not ops.fire_pool_bridge_ok(C, E3, E1, S):
+            continue
+        ref = nhwc(torch.relu(F.conv2d(F.max_pool2d(mid, 3, 2, ceil_mode=True), ws, bs)))
+        nseg = int(rs.randint(1, 8))
+        y = torch.full((B, ref.shape[1], ref.shape[2], S + 8), -3.0).cuda()
+        ops.fire_pool_bridge(nhwc(x).cuda(), 0, ops.FireBridgePlan(*args, 12, pooled=True), y, 4, nseg=nseg)
+        what = dict(kind='pool bridge', nseg=nseg)
+    else:
+        cands = [c for c in ops.FIRE_BRIDGE_CFGS if ops.fire_bridge_cfg_ok(c, C, E3, E1, S)]
+        if not cands:
+            continue
+        cid = int(rs.choice(cands))
+        ref = nhwc(torch.relu(F.conv2d(mid, ws, bs)))
+        y = torch.full((B, H, W, S + 8), -3.0).cuda()
+        ops.fire_bridge(nhwc(x).cuda(), 0, ops.FireBridgePlan(*args, cid), y, 4)
+        what = dict(kind='bridge', cfg=cid)
+    out = y.cpu()
+    e7 = (out[..., 4:4 + S] - ref).abs().max().item()
+    tol7 = 2e-5 * max(1.0, ref.abs().max().item()) + 1e-5
+    if not (e7 <= tol7 and bool((out[..., :4] == -3.0).all()) and bool((out[..., 4 + S:] == -3.0).all())):
+        print('BRIDGE MISMATCH', dict(B=B, H=H, W=W, C=C, E1=E1, E3=E3, S=S, err=e7, tol=tol7, **what)); sys.exit(1)
+    worst = max(worst, e7 / tol7); nb += 1
+n_ok += nb
+print(f'fuzz ok: {n_ok} cases ({nb} bridge launches) in {time.time() - t0:.0f} s, worst err/tol {worst:.2f}')
