@@ -15,7 +15,8 @@
 //     later in its own registers: the partial maxima of that row are carried (4 registers per 16-channel block) and finished
 //     by the next group's first tile row.  A strip is cut into segments for parallelism; each segment runs one extra group
 //     at its lower end for that row only;
-//   * ReLU outputs are non-negative, so 0 is the neutral element everywhere (DPP shifts with zero fill, tiles outside the map);
+//   * the expand ReLU runs behind the pool (it commutes with max), which also makes 0 the neutral element everywhere (DPP
+//     shifts with zero fill, pixels outside the map);
 //   * the pooled values leave the max in exactly the lane layout the squeeze product wants (lane = pooled pixel, 4 channels).
 template <int NSQ>
 __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
@@ -203,19 +204,42 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
       }
       const f32x4 m_top = max4(ov[0], ov[1]), m_left = max4(ov[0], ov[2]);
       const f32x4 m_all = max4(m_top, max4(ov[2], ov[3]));
+      // neighbour lanes through DPP operands of the max itself (row_shl:1 = lane + 1 = the tile to the right, row_shl:8 / row_shr:8
+      // = the tile below / above; lanes without that neighbour read 0).  Written as ISA: the compiler leaves the shifts as
+      // separate v_mov_dpp (16 per channel block) and every VALU instruction delays the matrix pipe.  (s_nop 1: a DPP operand
+      // may not be read in the two wait states behind the VALU write of that register.)
       f32x4 A, Bt, pooled;
+      const f32x4 ov0 = ov[0];
+      asm volatile("s_nop 1\n\t"
+                   "v_max_f32_dpp %0, %8, %12 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      // own tile + the right neighbour's left column
+                   "v_max_f32_dpp %1, %9, %13 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %2, %10, %14 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %3, %11, %15 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %4, %16, %20 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"     // own top row + the right neighbour's corner
+                   "v_max_f32_dpp %5, %17, %21 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %6, %18, %22 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %7, %19, %23 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                   : "=&v"(A.x), "=&v"(A.y), "=&v"(A.z), "=&v"(A.w), "=&v"(Bt.x), "=&v"(Bt.y), "=&v"(Bt.z), "=&v"(Bt.w)
+                   : "v"(m_left.x), "v"(m_left.y), "v"(m_left.z), "v"(m_left.w), "v"(m_all.x), "v"(m_all.y), "v"(m_all.z), "v"(m_all.w),
+                     "v"(ov0.x), "v"(ov0.y), "v"(ov0.z), "v"(ov0.w), "v"(m_top.x), "v"(m_top.y), "v"(m_top.z), "v"(m_top.w));
+      // first tile row: its own window + the row below (lane + 8); second tile row: the CARRIED window + the new first row (lane - 8)
+      f32x4 base;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        A[e] = __builtin_fmaxf(m_all[e], shl(m_left[e], std::integral_constant<int, 1>{}));       // own tile + the right neighbour's left column
-        Bt[e] = __builtin_fmaxf(m_top[e], shl(ov[0][e], std::integral_constant<int, 1>{}));        // own top row + the right neighbour's corner
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // first tile row: its own window + the row below (lane + 8); second tile row: the CARRIED window + the new first row (lane - 8)
-        const float below = shl(Bt[e], std::integral_constant<int, 8>{}), above = shr(Bt[e], std::integral_constant<int, 8>{});
-        const float base = ty ? carry[KS][e] : A[e];
-        pooled[e] = __builtin_fmaxf(base, __builtin_fmaxf(below, above));
-      }
+      for (int e = 0; e < 4; ++e) base[e] = ty ? carry[KS][e] : A[e];
+      asm volatile("s_nop 1\n\t"
+                   "v_max_f32_dpp %0, %4, %8 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %1, %5, %9 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %2, %6, %10 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %3, %7, %11 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %0, %4, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %1, %5, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %2, %6, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                   "v_max_f32_dpp %3, %7, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                   : "=&v"(pooled.x), "=&v"(pooled.y), "=&v"(pooled.z), "=&v"(pooled.w)
+                   : "v"(Bt.x), "v"(Bt.y), "v"(Bt.z), "v"(Bt.w), "v"(base.x), "v"(base.y), "v"(base.z), "v"(base.w));
+      // the expand ReLU is applied HERE, behind the pool (relu o max == max o relu; zero fills and masked pixels are neutral
+      // under it): 4 instead of 16 maxima per channel block
+      pooled = wino_relu4(pooled, 0.f);
       carry[KS] = A;
       const float* const sA = sqAL + bi * (4 * NSQ * 64) + lane;
 #pragma unroll
@@ -279,8 +303,6 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
             };
             inv1([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
             inv1([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
-#pragma unroll
-            for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
             if (rr == 0) pool_in(bi0 + rr, std::integral_constant<int, KS0>{}, ov);
             else if (rr == 1) pool_in(bi0 + rr, std::integral_constant<int, KS0 + 1>{}, ov);
             else if (rr == 2) pool_in(bi0 + rr, std::integral_constant<int, (KS0 + 2) & 7>{}, ov);
@@ -305,8 +327,6 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
           f32x4 ov[4];
           inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
           inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
-#pragma unroll
-          for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
           pool_in(pass, std::integral_constant<int, KS0>{}, ov);
         }
       };
