@@ -349,7 +349,8 @@ def main():
     hip_pred = hip_det = train_probe = None
 
     # ---------------- inference ----------------
-    if args.mode in ('both', 'infer'):
+    def bench_infer():
+        nonlocal hip_pred, hip_det
         model = SqueezeDet(cfg)
         model.load_state_dict(sd)
         det = Detector(model, cfg)
@@ -387,10 +388,17 @@ def main():
             with torch.no_grad():
                 hip_pred = model.base(x).cpu()
             hip_det = tuple(t.cpu().numpy() for t in out_bufs[:5])
-        del model, det
+        # release the captured step (graph exec, its memory pool, the side stream's queue) before the training half: with
+        # several ranks on ONE GPU (gloo rehearsal) a live graph exec next to the eager training step oversubscribed the
+        # hardware queues (20 -> 95..1500 ms per step); one rank per GPU never showed it, but nothing after this needs the graph
+        del model, det, run, infer_step
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
 
     # ---------------- training ----------------
-    if args.mode in ('both', 'train'):
+    def bench_train():
+        nonlocal train_probe
         from squeezedet_pytorch_amd.trainer import make_train_step
         step, describe, probe = make_train_step(cfg, sd, x, rank, joined, dist, force_exchange=args.force_dist)
         if rank == 0 and joined == 1 and not args.no_cpu_baseline and args.mode == 'both':
@@ -413,6 +421,17 @@ def main():
             'workload': describe, 'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
             'layers': {f'{k} | {tag}': round(t[1] * 1e3, 1) for k, v in summ.items() for tag, t in v['tags'].items()},
         }
+
+    # One rank per GPU with a process group: the training half (eager, with the gradient exchange) runs FIRST, in a process
+    # that has not captured or replayed a graph yet -- a two-ranks-on-one-GPU gloo rehearsal showed eager steps behind a graph
+    # replay phase at 95..1500 ms instead of 20 ms (hardware-queue oversubscription of the shared GPU); on one rank per GPU the
+    # order made no difference, so the safe order is used whenever ranks communicate.
+    order = ('train', 'infer') if dist is not None else ('infer', 'train')
+    for half in order:
+        if half == 'infer' and args.mode in ('both', 'infer'):
+            bench_infer()
+        if half == 'train' and args.mode in ('both', 'train'):
+            bench_train()
 
     if rank == 0:
         cpu = parity = None
