@@ -419,12 +419,14 @@ static int launch_wino_bridge(WinoArgs a, hipStream_t stream) {
 // padding (N1 <= 64) only the even position pairs are kept in LDS and multiplied.
 // SQZ = false: the same machinery as the plain fused expand (sqd_fire_wino_fwd cfg 12): every pass's channels get bias + ReLU and
 // are stored to their window of the concatenated output instead of entering a squeeze.
-template <int NSQ, bool SQZ>
+// NCH = C / 8 (1 or 2) is a template parameter and the (at most 4 + 2) channel passes are enumerated statically: with run-time
+// trip counts the compiler rotated the 64 transform registers and the accumulators through ~200 copies per group.
+template <int NSQ, bool SQZ, int NCH>
 __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
   constexpr int WV = 8, NTHR = WV * 64, RP = 113, RAW_IT = 4, NSTB = 4 * NSQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int P3 = a.nslices3, P = a.nslices;            // 16-wide passes: expand3x3, then expand1x1
-  const int nchunks = a.C >> 3;                        // 1 or 2
+  constexpr int nchunks = NCH;                         // C / 8
   const bool e1_half = a.N1 <= 64;
   const int e1_stage = e1_half ? 1024 : 2048;          // floats per (pass, chunk) of U in LDS
   float* const rawB = smem;                            // [2 chunks][WV][256][4]
@@ -562,14 +564,9 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
     asm volatile("" ::: "memory");
     stores_behind = 0;
     // ---- input transform of the whole group (both chunks), kept in registers for every pass ----
-    f32x2 vv[2][16];
+    f32x2 vv[NCH][16];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (c >= nchunks) {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) vv[c][p] = (f32x2){0.f, 0.f};
-        continue;
-      }
+    for (int c = 0; c < NCH; ++c) {
       const float* const rawL = rawW + c * WV * 256 * 4 + rawL_off;
       f32x2 t[4][4];
 #pragma unroll
@@ -626,9 +623,10 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
         float bA[E1 ? 4 : 1];
 #pragma unroll
         for (int k = 0; k < (E1 ? (KIND == 2 ? 2 : 4) : 1); ++k) bA[k] = bL[k * 16];
-        for (int cc = 0; cc < nchunks; ++cc) {
-          const float* const uR = (E1 ? U1B + ((pass - P3) * nchunks + cc) * e1_stage : UB + (pass * nchunks + cc) * 2048) + u_ln;
+        {
           auto chunk = [&](auto first_c, auto cc_c) {
+            constexpr int cc = decltype(cc_c)::value;
+            const float* const uR = (E1 ? U1B + ((pass - P3) * nchunks + cc) * e1_stage : UB + (pass * nchunks + cc) * 2048) + u_ln;
             constexpr bool FIRST = decltype(first_c)::value;
             constexpr int CC = decltype(cc_c)::value;
             f32x4 af0 = *(const f32x4*)uR, af1;
@@ -656,8 +654,8 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
                 }
             }
           };
-          if (cc == 0) chunk(std::true_type{}, std::integral_constant<int, 0>{});
-          else chunk(std::false_type{}, std::integral_constant<int, 1>{});
+          chunk(std::true_type{}, std::integral_constant<int, 0>{});
+          if constexpr (NCH > 1) chunk(std::false_type{}, std::integral_constant<int, 1>{});
         }
         // ---- this pass's channels: inverse transform, ReLU, into the next squeeze ----
         if constexpr (E1) {
@@ -702,9 +700,18 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
           else store_out(yres, pass * 16, a.N, ov);
         }
       };
-      for (int pass = 0; pass < P3; ++pass) run_pass(std::integral_constant<int, 0>{}, pass);
-      if (e1_half) { for (int pass = P3; pass < P; ++pass) run_pass(std::integral_constant<int, 2>{}, pass); }
-      else { for (int pass = P3; pass < P; ++pass) run_pass(std::integral_constant<int, 1>{}, pass); }
+      // (host-checked: at most 4 expand3x3 and 2 expand1x1 passes)
+      if (P3 > 0) run_pass(std::integral_constant<int, 0>{}, 0);
+      if (P3 > 1) run_pass(std::integral_constant<int, 0>{}, 1);
+      if (P3 > 2) run_pass(std::integral_constant<int, 0>{}, 2);
+      if (P3 > 3) run_pass(std::integral_constant<int, 0>{}, 3);
+      if (e1_half) {
+        if (P > P3) run_pass(std::integral_constant<int, 2>{}, P3);
+        if (P > P3 + 1) run_pass(std::integral_constant<int, 2>{}, P3 + 1);
+      } else {
+        if (P > P3) run_pass(std::integral_constant<int, 1>{}, P3);
+        if (P > P3 + 1) run_pass(std::integral_constant<int, 1>{}, P3 + 1);
+      }
     }
     if constexpr (!SQZ) stores_behind = (cur.valid && wholexy && nst_full > 0) ? nst_full : 0;
     // ---- the group's squeeze output: ReLU + store; the accumulators restart from the bias ----
@@ -733,29 +740,30 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSQ, bool SQZ>
+template <int NSQ, bool SQZ, int NCH>
 __global__ __launch_bounds__(512, 1) void fire_bridge16_kernel(WinoArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  wino_bridge16_body<NSQ, SQZ>(a);
+  wino_bridge16_body<NSQ, SQZ, NCH>(a);
 #endif
 }
 
 // bias table / squeeze operand blocks of this form: 16-wide passes (see sqd_fire_bridge_fwd)
-template <int NSQ, bool SQZ = true>
-static int launch_wino_bridge16(WinoArgs a, hipStream_t stream) {
+template <int NSQ, bool SQZ, int NCH>
+static int launch_wino_bridge16_t(WinoArgs a, hipStream_t stream) {
   constexpr int WV = 8, NTHR = WV * 64;
   const int nchunks = a.C >> 3;
-  if (nchunks < 1 || nchunks > 2) return SQD_ERR_UNSUPPORTED;
+  if (nchunks != NCH) return SQD_ERR_UNSUPPORTED;
   const int P3 = sqd_cdiv(a.N, 16), P1 = 2 * sqd_cdiv(a.N1, 128);
   if (a.Npad != sqd_cdiv(a.N, 32) * 32 + sqd_cdiv(a.N1, 128) * 32) return SQD_ERR_BAD_ARG;
   // the expand1x1 passes are the 16-wide slices of the packed axis behind ceil32(N3)
   const int first1 = sqd_cdiv(a.N, 32) * 2;
+  if (first1 > 4 || P1 > 2) return SQD_ERR_UNSUPPORTED;          // the kernel enumerates at most 4 + 2 passes
   const int e1_stage = a.N1 <= 64 ? 1024 : 2048;
   const int nblk = SQZ ? first1 + 4 * P1 : 0;
   const size_t lds = (size_t)(2 * WV * 256 * 4 + first1 * nchunks * 2048 + P1 * nchunks * e1_stage + nblk * 4 * NSQ * 64 + (first1 + P1) * 64) * sizeof(float);
   (void)P3;
   if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
-  auto kern = fire_bridge16_kernel<NSQ, SQZ>;
+  auto kern = fire_bridge16_kernel<NSQ, SQZ, NCH>;
   if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
@@ -773,4 +781,11 @@ static int launch_wino_bridge16(WinoArgs a, hipStream_t stream) {
   a.nslices3 = first1; a.nslices = first1 + P1; a.gx = gx;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NTHR), lds, stream, a);
   return sqd_launch_status();
+}
+
+template <int NSQ, bool SQZ = true>
+static int launch_wino_bridge16(WinoArgs a, hipStream_t stream) {
+  if ((a.C >> 3) == 1) return launch_wino_bridge16_t<NSQ, SQZ, 1>(a, stream);
+  if ((a.C >> 3) == 2) return launch_wino_bridge16_t<NSQ, SQZ, 2>(a, stream);
+  return SQD_ERR_UNSUPPORTED;
 }

@@ -18,12 +18,12 @@
 //   * the expand ReLU runs behind the pool (it commutes with max), which also makes 0 the neutral element everywhere (DPP
 //     shifts with zero fill, pixels outside the map);
 //   * the pooled values leave the max in exactly the lane layout the squeeze product wants (lane = pooled pixel, 4 channels).
-template <int NSQ>
+template <int NSQ, int NCH>
 __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
   constexpr int WV = 8, NTHR = WV * 64, RP = 113, RAW_IT = 4, RSLOTS = 224;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int P3 = a.nslices3, P = a.nslices;            // 16-wide passes: expand3x3, then expand1x1
-  const int nchunks = a.C >> 3;                        // 1 or 2
+  constexpr int nchunks = NCH;                         // C / 8 (1 or 2)
   const bool e1_half = a.N1 <= 64;
   const int e1_stage = e1_half ? 1024 : 2048;
   const int rb1 = e1_half ? 2 : 4;                     // channel blocks of an expand1x1 pass
@@ -164,14 +164,9 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::: "memory");
     // ---- input transform of the whole group (both chunks) ----
-    f32x2 vv[2][16];
+    f32x2 vv[NCH][16];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (c >= nchunks) {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) vv[c][p] = (f32x2){0.f, 0.f};
-        continue;
-      }
+    for (int c = 0; c < NCH; ++c) {
       const float* const rawL = rawW + c * WV * RSLOTS * 4 + rawL_off;
       f32x2 t[4][4];
 #pragma unroll
@@ -258,9 +253,10 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
         float bA[E1 ? 4 : 1];
 #pragma unroll
         for (int k = 0; k < (E1 ? (KIND == 2 ? 2 : 4) : 1); ++k) bA[k] = bL[k * 16];
-        for (int cc = 0; cc < nchunks; ++cc) {
-          const float* const uR = (E1 ? U1B + ((pass - P3) * nchunks + cc) * e1_stage : UB + (pass * nchunks + cc) * 2048) + u_ln;
+        {
           auto chunk = [&](auto first_c, auto cc_c) {
+            constexpr int cc = decltype(cc_c)::value;
+            const float* const uR = (E1 ? U1B + ((pass - P3) * nchunks + cc) * e1_stage : UB + (pass * nchunks + cc) * 2048) + u_ln;
             constexpr bool FIRST = decltype(first_c)::value;
             constexpr int CC = decltype(cc_c)::value;
             f32x4 af0 = *(const f32x4*)uR, af1;
@@ -288,8 +284,8 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
                 }
             }
           };
-          if (cc == 0) chunk(std::true_type{}, std::integral_constant<int, 0>{});
-          else chunk(std::false_type{}, std::integral_constant<int, 1>{});
+          chunk(std::true_type{}, std::integral_constant<int, 0>{});
+          if constexpr (NCH > 1) chunk(std::false_type{}, std::integral_constant<int, 1>{});
         }
         if constexpr (E1) {
           const int bi0 = P3 + rb1 * (pass - P3);
@@ -367,18 +363,18 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSQ>
+template <int NSQ, int NCH>
 __global__ __launch_bounds__(512, 1) void fire_poolbridge16_kernel(WinoArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  wino_poolbridge16_body<NSQ>(a);
+  wino_poolbridge16_body<NSQ, NCH>(a);
 #endif
 }
 
-template <int NSQ>
-static int launch_wino_poolbridge16(WinoArgs a, int nseg, hipStream_t stream) {
+template <int NSQ, int NCH>
+static int launch_wino_poolbridge16_t(WinoArgs a, int nseg, hipStream_t stream) {
   constexpr int WV = 8, NTHR = WV * 64, RSLOTS = 224;
   const int nchunks = a.C >> 3;
-  if (nchunks < 1 || nchunks > 2) return SQD_ERR_UNSUPPORTED;
+  if (nchunks != NCH) return SQD_ERR_UNSUPPORTED;
   const int P1 = 2 * sqd_cdiv(a.N1, 128);
   if (a.Npad != sqd_cdiv(a.N, 32) * 32 + sqd_cdiv(a.N1, 128) * 32) return SQD_ERR_BAD_ARG;
   const int first1 = sqd_cdiv(a.N, 32) * 2;
@@ -388,7 +384,7 @@ static int launch_wino_poolbridge16(WinoArgs a, int nseg, hipStream_t stream) {
   const int nblk = first1 + rb1 * P1;
   const size_t lds = (size_t)(2 * WV * RSLOTS * 4 + first1 * nchunks * 2048 + P1 * nchunks * e1_stage + nblk * 4 * NSQ * 64 + (first1 + P1) * 64 + NSQ * 16) * sizeof(float);
   if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
-  auto kern = fire_poolbridge16_kernel<NSQ>;
+  auto kern = fire_poolbridge16_kernel<NSQ, NCH>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
@@ -408,4 +404,11 @@ static int launch_wino_poolbridge16(WinoArgs a, int nseg, hipStream_t stream) {
   a.nslices3 = first1; a.nslices = first1 + P1; a.gx = gx;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NTHR), lds, stream, a);
   return sqd_launch_status();
+}
+
+template <int NSQ>
+static int launch_wino_poolbridge16(WinoArgs a, int nseg, hipStream_t stream) {
+  if ((a.C >> 3) == 1) return launch_wino_poolbridge16_t<NSQ, 1>(a, nseg, stream);
+  if ((a.C >> 3) == 2) return launch_wino_poolbridge16_t<NSQ, 2>(a, nseg, stream);
+  return SQD_ERR_UNSUPPORTED;
 }
