@@ -9,9 +9,11 @@ from squeezedet_pytorch_amd import ops
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 tab = ops.cfg_table()
-t0 = time.time(); n_ok = 0; worst = 0.0
+t0 = time.time(); n_ok = 0; worst = 0.0; t_say = t0
 def nhwc(t): return t.permute(0, 2, 3, 1).contiguous()
 while time.time() - t0 < budget:
+    if time.time() - t_say > 30:
+        print(f'  .. {n_ok} cases ok after {time.time() - t0:.0f} s', flush=True); t_say = time.time()
     cid = int(rs.choice(list(tab)))
     taps, kc, px, bn = tab[cid]
     B = int(rs.randint(1, 4)); H = int(rs.choice([1, 2, 3, 5, 8, 9, 16, 17, 24, 31])); W = int(rs.choice([1, 3, 7, 15, 16, 17, 33, 47, 78]))
