@@ -375,6 +375,7 @@ def test_fire_bridge_one_launch(C, E1, E3, S, B, H, W):
     (16, 64, 64, 32, 1, 8, 32, 1), (16, 64, 64, 32, 1, 8, 32, 2), (16, 64, 64, 32, 2, 9, 37, 1), (8, 32, 40, 12, 1, 5, 17, 1),
     (16, 48, 64, 16, 2, 12, 30, 3), (16, 64, 32, 24, 3, 13, 50, 2), (8, 16, 16, 32, 1, 24, 14, 6), (16, 64, 64, 32, 3, 96, 312, 4),
     (8, 16, 8, 4, 1, 3, 3, 1), (16, 64, 64, 32, 1, 31, 45, 5), (16, 64, 64, 32, 2, 7, 100, 9),
+    (16, 64, 64, 32, 4, 96, 312, 24),      # 2208 wave tasks > 2048 wave slots: waves walk on to a second task (the bs >= 32 rows do)
 ])
 def test_fire_pool_bridge_one_launch(C, E1, E3, S, B, H, W, nseg):
     """Fire k's expand pair + concat + MaxPool2d(3, 2, ceil_mode=True) + Fire k+1's squeeze in ONE launch (sqd_fire_pool_bridge_fwd)
