@@ -275,3 +275,24 @@ def test_conv_dma_multi_round_persistent(taps, C, N, B, H, W):
         torch.cuda.synchronize()
         assert (y[..., 4:4 + N].cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, float(ref.abs().max())), cfg_id
         assert bool((y[..., :4] == -7.0).all()) and bool((y[..., 4 + N:] == -7.0).all())
+
+
+@pytest.mark.parametrize("bs", [4, 32])
+def test_bridged_forward_equals_plain_at_other_batch_sizes(bs, monkeypatch):
+    """The shipped table also switches the two bridge launches on at bs = 4 ... 64 (whole-step A/B per batch size,
+    profiles/r02v_bridge_rows_other_batch_sizes.log).  There the bridged forward must reproduce the plain launch sequence (same
+    1e-4 class: different summation order only) and the oracle on a sample of images."""
+    cfg, det, sd = _infer_model('squeezedet')
+    x = synthetic.make_images(bs, SIZE, seed=3)
+    log = LaunchLog(monkeypatch)
+    with torch.no_grad():
+        pred = det.model.base(x.cuda())
+        assert sum(1 for c in log.calls if c[0] in ('bridge', 'poolbridge')) == 2
+        det.model.base.fuse_fire_bridge = False
+        plain = det.model.base(x.cuda())
+        det.model.base.fuse_fire_bridge = True
+    assert float((pred - plain).abs().max()) <= 5e-5
+    sel = [0, bs - 1]
+    with torch.no_grad():
+        ref = oracle.backbone_forward(x[sel], sd)
+    assert float((pred[sel].cpu() - ref).abs().max()) <= TOL
