@@ -502,7 +502,7 @@ def fire_wino_cfg_ok(cfg_id, C, E1=None, E3=None):
     """Whether ``fire_wino`` can run configuration ``cfg_id`` on a Fire with squeeze width C (and, for the small-C form 12 whose
     LDS plan holds every channel pass's U, expand widths E1 / E3)."""
     if cfg_id % 1000 == 12:
-        if C % 8 or C > 16 or E1 is None or E3 is None:
+        if C % 8 or C > 16 or E1 is None or E3 is None or E3 > 64 or E1 > 128:      # (the kernel enumerates at most 4 + 2 channel passes)
             return False
         P3, P1 = -(-E3 // 32), -(-E1 // 128)
         lds = 4 * (2 * 8 * 256 * 4 + 2 * P3 * (C // 8) * 2048 + 2 * P1 * (C // 8) * (1024 if E1 <= 64 else 2048) + (2 * P3 + 2 * P1) * 64)
@@ -584,7 +584,7 @@ def fire_bridge_lds_bytes(cfg_id, C, N3, N1, Nsq):
 def fire_bridge_cfg_ok(cfg_id, C, N3, N1, Nsq):
     """Whether ``fire_bridge`` can run this Fire pair: 8 | C, 16 | N1, 4 | N3, Nsq <= 32, and the LDS plan fits one CU."""
     return (cfg_id % 1000 in FIRE_BRIDGE_CFGS and C % 8 == 0 and N1 % 16 == 0 and N3 % 4 == 0 and Nsq % 4 == 0 and Nsq <= 32
-            and (cfg_id % 1000 != 12 or C <= 16) and fire_bridge_lds_bytes(cfg_id, C, N3, N1, Nsq) <= 160 * 1024)
+            and (cfg_id % 1000 != 12 or (C <= 16 and N3 <= 64 and N1 <= 128)) and fire_bridge_lds_bytes(cfg_id, C, N3, N1, Nsq) <= 160 * 1024)
 
 
 def choose_fire_bridge_cfg(C, N1, N3, Nsq, npix):
