@@ -951,7 +951,7 @@ def filter_dense(class_ids, scores, boxes, num_classes, keep_top_k=64, nms_thres
 # training-side ops
 # ---------------------------------------------------------------------------------------------
 _TARGET_WGS = 1536          # workgroups a 3x3 weight-gradient launch aims for (measured sweep 768 / 1536 / 3072)
-_TARGET_WGS_1X1 = 1024      # 1x1: fewer, longer pixel streams (less slab traffic per MFMA)
+_TARGET_WGS_1X1 = 512       # 1x1: fewer, longer pixel streams (less slab traffic per MFMA; round 2, inside the training step: 512 6.26 ms, 1024 6.29, 384 6.40)
 
 
 WINO_WGRAD = True          # 3x3 weight gradients: Winograd kernel where it applies (N % 64 == 0)
@@ -971,12 +971,18 @@ def _wino_wgrad_tc(N, C):
 
 
 def wgrad_split(N, C, taps, B, H, W, wino=None):
-    """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab."""
+    """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab.
+    S comes from the workgroup targets below unless the measured table has a row 'G:taps:N:C:npix' (tools/tune_insitu.py --mode
+    train: the split of each layer tried inside the training step)."""
+    tuned = _tuning().get(f'G:{taps}:{N}:{C}:{B * H * W}')
     if wgrad_uses_wino(N, C, taps, B, H, W, wino):
         ngroups = B * -(-H // 4) * -(-W // 16)                    # 4x16-pixel groups = the K axis of the 16 position GEMMs
         # (out-channel, in-channel) blocks of dU per workgroup: 64 x 16|32, or all of N <= 80 x 16 (ConvDet)
         blocks = -(-C // 16) if N % 64 else (N // 64) * -(-C // (16 * _wino_wgrad_tc(N, C)))
-        return max(1, min(ngroups, _TARGET_WGS_WINO // blocks if blocks <= _TARGET_WGS_WINO else 1)), N * taps * C + N
+        S = max(1, min(ngroups, _TARGET_WGS_WINO // blocks if blocks <= _TARGET_WGS_WINO else 1))
+        if tuned is not None and tuned >= 1:
+            S = max(1, min(ngroups, int(tuned)))
+        return S, N * taps * C + N
     tn = 4 if N >= 64 else -(-N // 16)
     if taps == 9:
         if 64 < N <= 80:
@@ -993,6 +999,8 @@ def wgrad_split(N, C, taps, B, H, W, wino=None):
         nblocks = -(-(B * H * W) // 128)
     groups = -(-N // (tn * 16)) * -(-C // (tc * 16))
     S = max(1, min(nblocks, (_TARGET_WGS if taps == 9 else _TARGET_WGS_1X1) // groups, 256))
+    if tuned is not None and tuned >= 1:
+        S = max(1, min(nblocks, int(tuned), 256))
     return S, N * taps * C + N
 
 

@@ -27,6 +27,9 @@ def test_every_tuned_entry_names_a_compiled_configuration(table):
             assert cid % 1000 in ops.wino_cfgs() and cid // 1000 <= 8 and int(C) % 8 == 0, key
             assert v["us"] > 0 and "direct_us" in v
             continue
+        if key.startswith("G:"):                                                  # split-K slabs of a weight gradient
+            assert cid >= 1 and v["us"] > 0, key
+            continue
         if key.startswith(("Y:", "Z:")):                                          # Fire bridges: Y = configuration id, Z = segments per strip
             _, C, E1, E3, Nsq, npix = key.split(":")
             if key.startswith("Y:"):

@@ -34,6 +34,8 @@ def main():
                     help="train: time the TRAINING step (fwd + loss + bwd + clip + SGD, hipGraph) and walk the rows only it consults "
                          "(data-gradient orientations, measured in isolation WITHOUT their ReLU-mask / accumulate epilogues, and the forward "
                          "rows the inference step no longer uses)")
+    ap.add_argument('--splits', action='store_true', help='(train) also walk the split-K factors of the weight-gradient kernels (G: rows)')
+    ap.add_argument('--rows', type=int, default=1, help='(train) 0 = skip the conv-configuration rows')
     ap.add_argument('--replays', type=int, default=40)
     ap.add_argument('--passes', type=int, default=1)
     ap.add_argument('--gain', type=float, default=0.0015, help='relative step-time gain a change must show (noise floor)')
@@ -81,10 +83,17 @@ def main():
             if k in full and k not in train_keys:
                 train_keys.append(k)
             return real_wino(C, N, npix, *a, **kw)
-        ops.choose_cfg, ops.choose_wino_cfg = rec_choose, rec_wino
+        wgrad_keys = {}                              # 'G:taps:N:C:npix' -> split the heuristic (or the table) gives today
+        real_split = ops.wgrad_split
+
+        def rec_split(N, C, taps, Bq, H, W, wino=None):
+            S, stride = real_split(N, C, taps, Bq, H, W, wino)
+            wgrad_keys.setdefault(f'G:{taps}:{N}:{C}:{Bq * H * W}', S)
+            return S, stride
+        ops.choose_cfg, ops.choose_wino_cfg, ops.wgrad_split = rec_choose, rec_wino, rec_split
         train_step()
         torch.cuda.synchronize()
-        ops.choose_cfg, ops.choose_wino_cfg = real_choose, real_wino
+        ops.choose_cfg, ops.choose_wino_cfg, ops.wgrad_split = real_choose, real_wino, real_split
 
     def run_step():
         if args.mode == 'train':
@@ -95,6 +104,8 @@ def main():
     def step_ms():
         """Median hipGraph replay time of the whole step with the current table."""
         (tmodel.base if args.mode == 'train' else model.base).invalidate_plans()
+        if args.mode == 'train':
+            tmodel.base._wgrad_batches.clear()          # (slab workspaces are sized by the splits)
         for _ in range(2):
             run_step()
         torch.cuda.synchronize()
@@ -138,7 +149,7 @@ def main():
     print(f'start: {base:.4f} ms/step ({B / base * 1e3:.0f} img/s), {len(keys)} table rows in play', flush=True)
     changed = {}
     for p in range(args.passes):
-        for k in keys:
+        for k in (keys if args.rows else []):
             cands = sorted(full[k].get('all', {}).items(), key=lambda kv: kv[1])[:args.top]
             cands = [int(c) for c, _ in cands if int(c) != tab[k]]
             if args.ws and k.startswith('1:'):
@@ -177,6 +188,31 @@ def main():
             else:
                 base = min(base, best_t) if best_t else base
         print(f'pass {p}: {base:.4f} ms/step ({B / base * 1e3:.0f} img/s)', flush=True)
+    # ---- split-K factors of the weight-gradient kernels (training mode): each layer's split tried inside the step ----
+    if args.mode == 'train' and args.splits:
+        for k, s0 in wgrad_keys.items():
+            cands = sorted({max(1, int(round(s0 * f))) for f in (0.5, 0.67, 0.8, 1.25, 1.5, 2.0)} - {s0})
+            best_c, best_t = s0, base
+            for c in cands:
+                tab[k] = c
+                t = step_ms()
+                if t < best_t * (1.0 - args.gain):
+                    best_c, best_t = c, t
+            tab.pop(k, None)
+            print(f'  .. {k}: split {s0}, best {best_c} ({best_t:.4f} ms vs {base:.4f})', flush=True)
+            if best_c != s0:
+                tab[k] = best_c
+                t2 = step_ms()
+                tab.pop(k, None)
+                t1 = step_ms()
+                if t2 < t1 * (1.0 - args.gain / 2):
+                    tab[k] = best_c
+                    full[k] = {'cfg': best_c, 'us': round(t2 * 1e3, 1), 'separate_us': round(t1 * 1e3, 1),
+                               'note': f'split-K slabs of this weight gradient (heuristic {s0}); WHOLE training step (us) with / without, tools/tune_insitu.py --mode train --splits'}
+                    base = t2
+                    print(f'  {k:24s} split {s0} -> {best_c}: step {t1:.4f} -> {t2:.4f} ms', flush=True)
+                else:
+                    base = t1
     for k, (old, new, t1, t2) in changed.items():
         full[k]['cfg'] = new
         full[k]['insitu'] = {'from': old, 'step_ms_before': round(t1, 4), 'step_ms_after': round(t2, 4)}
