@@ -255,6 +255,14 @@ int sqd_fire_pool_bridge_fwd(const float* x, const float* u_packed, const float*
                              float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total, int Nsq,
                              int Hp, int Wp, int y_pitch, int y_coff, int nseg, void* stream);
 
+/* clip_grad_norm_ + torch.optim.SGD(momentum, weight_decay).step() (src/engine/trainer.py:47-50) for every parameter tensor in ONE
+ * launch.  descs_dev: n records of 4 int64 {param ptr, grad, momentum-buffer ptr, elements}, grad = element offset into grad_base (the
+ * backward's flat gradient buffer) or the gradient's address when grad_base is NULL; total_norm: device float, the L2
+ * norm of all gradients (read on the device: no host sync; NULL allowed when max_norm <= 0 = no clipping).  Per element, in torch's
+ * order: g = grad * min(1, max_norm / (total_norm + 1e-6)); g += wd * p; buf = momentum * buf + g; p -= lr * buf. */
+int sqd_sgd_clip_step(const void* descs_dev, int n, const float* grad_base, const float* total_norm, float max_norm, float lr,
+                      float momentum, float weight_decay, int blocks_per_desc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,7 @@ _SIGNATURES = {
     'sqd_pack_wino_fire': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_fire_wino_fwd': [c_p] * 5 + [c_i] * 13 + [c_p],
     'sqd_fire_bridge_fwd': [c_p] * 6 + [c_i] * 13 + [c_p],
+    'sqd_sgd_clip_step': [c_p, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p],
     'sqd_fire_pool_bridge_fwd': [c_p] * 6 + [c_i] * 15 + [c_p],
     'sqd_encode_gt_fwd': [c_p] * 8 + [c_i, c_i, c_i, c_i, c_p],
     'sqd_loss_fwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],

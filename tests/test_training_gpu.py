@@ -300,3 +300,67 @@ def test_train_step_vs_golden_through_winograd_kernels(golden_dir, monkeypatch):
     monkeypatch.setattr(ops, 'conv_wino', counting)
     test_train_step_vs_golden(golden_dir)
     assert calls['wino'] >= 21                               # 11 forward + >= 10 data gradients went through conv_wino
+
+
+def test_fused_clip_sgd_matches_torch():
+    """trainer.FusedClipSGD (clip_grad_norm_ + SGD with momentum and weight decay in one launch, csrc/optim.hip) against the two
+    torch calls of the reference's training step (src/engine/trainer.py:47-50) over several steps: parameters and momentum agree to
+    fp32 rounding (torch contracts `g + wd * p` into an fma), with the clip active (large gradients) and inactive (small)."""
+    from squeezedet_pytorch_amd.trainer import FusedClipSGD
+    torch.manual_seed(0)
+    shapes = [(64, 3, 3, 3), (64,), (16, 64, 1, 1), (16,), (72, 768, 3, 3), (72,), (5,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, device='cuda') * 0.1) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    topt = torch.optim.SGD(ref, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    fopt = FusedClipSGD(mine, lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=5.0)
+    for step in range(5):
+        scale = 3.0 if step % 2 == 0 else 1e-3            # clipped / not clipped
+        grads = [torch.randn(*s, device='cuda') * scale for s in shapes]
+        for p, q, g in zip(ref, mine, grads):
+            p.grad = g.clone(); q.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        topt.step()
+        v0 = mine[0]._version
+        fn = fopt.step()
+        assert mine[0]._version > v0                        # the packed-weight caches key on it
+        assert abs(float(tn) - float(fn)) <= 1e-5 * float(tn)
+        for p, q in zip(ref, mine):
+            assert torch.allclose(p, q, rtol=2e-6, atol=1e-8), (step, float((p - q).abs().max()))
+        for p, b in zip(ref, fopt._bufs):
+            assert torch.allclose(topt.state[p]['momentum_buffer'].reshape(-1), b, rtol=2e-6, atol=1e-8)
+    sd = fopt.state_dict()
+    fopt2 = FusedClipSGD(mine, lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=5.0)
+    fopt2.load_state_dict(sd)
+    assert torch.equal(fopt2.momentum_flat, fopt.momentum_flat)
+
+
+def test_train_steps_with_fused_optimizer_vs_torch_and_golden(golden_dir):
+    """The training step bench.py times -- fwd, loss.mean(), HIP backward into the flat gradient buffer, FusedClipSGD (clip + SGD in
+    one launch, gradients addressed as offsets into the flat buffer) -- against (a) the reference's own run of the first step
+    (golden: loss, total gradient norm, |params| after the update) and (b) three steps of the same model driven by
+    clip_grad_norm_ + torch.optim.SGD: parameters agree to fp32 rounding, and the packed-weight caches follow the in-place updates
+    (the second step's loss matches)."""
+    from squeezedet_pytorch_amd.trainer import FusedClipSGD
+    g = np.load(os.path.join(golden_dir, "train_step_small.npz"))
+    size = (64, 96)
+    cfg, ma, sd = _train_model('squeezedet', size)
+    _, mb, _ = _train_model('squeezedet', size)
+    x = synthetic.make_images(2, size, seed=3).cuda()
+    gt = synthetic.make_gt(2, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3).cuda()
+    fo = FusedClipSGD(ma.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=5.0, flat_grad=lambda: ma.base.last_grad_flat)
+    to = torch.optim.SGD(mb.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for step in range(3):
+        la, _ = ma({'image': x, 'gt': gt}); la = la.mean(); fo.zero_grad(); la.backward()
+        lb, _ = mb({'image': x, 'gt': gt}); lb = lb.mean(); to.zero_grad(); lb.backward()
+        assert fo._flat_base([p.grad for p in fo.params]) is not None          # the one-reduction norm / offset table path
+        norm = float(fo.step())
+        tn = float(torch.nn.utils.clip_grad_norm_(mb.parameters(), 5.0)); to.step()
+        assert abs(norm - tn) <= 1e-5 * tn
+        assert abs(la.item() - lb.item()) <= 1e-5 * abs(lb.item()), step
+        for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), (step, n, float((p - q).abs().max()))
+        if step == 0:
+            assert abs(norm - g["total_norm"][0]) <= 1e-2 * g["total_norm"][0]
+            assert abs(la.item() - g["loss"][0]) <= 1e-4 * abs(g["loss"][0])
+            ps = np.array([float(p.double().abs().sum()) for _, p in ma.named_parameters()])
+            np.testing.assert_allclose(ps, g["new_param_abs"], rtol=1e-4)
