@@ -21,13 +21,27 @@ __global__ __launch_bounds__(256) void sgd_clip_batched_kernel(const SgdDesc* __
     coef = coef < 1.f ? coef : 1.f;
   }
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
-    const float p = d.p[i];
-    float g = dg[i] * coef;
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  auto one = [&](float p, float gr, float m, float& pn, float& mn) {
+    float g = gr * coef;
     g = g + wd * p;
-    const float b = momentum * d.m[i] + g;
-    d.m[i] = b;
-    d.p[i] = p - lr * b;
+    mn = momentum * m + g;
+    pn = p - lr * mn;
+  };
+  // 16-byte accesses where the three pointers allow it (they do for every tensor of the model), scalar tail / fallback
+  const bool vec = ((((uintptr_t)d.p) | ((uintptr_t)dg) | ((uintptr_t)d.m)) & 15) == 0;
+  const long long n4 = vec ? d.n >> 2 : 0;
+  for (long long i = tid; i < n4; i += stride) {
+    const f32x4 p = ((const f32x4*)d.p)[i], gr = ((const f32x4*)dg)[i], m = ((const f32x4*)d.m)[i];
+    float pn[4], mn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) one(p[e], gr[e], m[e], pn[e], mn[e]);
+    ((f32x4*)d.m)[i] = (f32x4){mn[0], mn[1], mn[2], mn[3]}; ((f32x4*)d.p)[i] = (f32x4){pn[0], pn[1], pn[2], pn[3]};
+  }
+  for (long long i = 4 * n4 + tid; i < d.n; i += stride) {
+    float pn, mn;
+    one(d.p[i], dg[i], d.m[i], pn, mn);
+    d.m[i] = mn; d.p[i] = pn;
   }
 }
 

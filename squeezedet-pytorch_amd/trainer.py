@@ -382,7 +382,7 @@ class FusedClipSGD:
         if self.max_norm > 0:
             norm = flat[:self.total].norm() if flat is not None else torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
         nat.check(nat.lib().sqd_sgd_clip_step(nat.ptr(self._table), len(self.params), nat.ptr(flat), nat.ptr(norm), self.max_norm, self.lr,
-                                              self.momentum, self.weight_decay, 32, nat.stream_handle(self.params[0].device)),
+                                              self.momentum, self.weight_decay, 64, nat.stream_handle(self.params[0].device)),
                   'sqd_sgd_clip_step')
         torch.autograd.graph.increment_version(self.params)        # (the packed-weight caches key on the version counters)
         self.last_norm = norm
