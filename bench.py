@@ -306,17 +306,25 @@ def main():
         torch.cuda.synchronize()
         graph = None
         if capture and not args.no_graph:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()                                   # allocations of the capture stream's pool
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step()                                   # allocations of the capture stream's pool
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    # with a process group alive other threads of this process (the collective library's watchdog) may touch
+                    # the runtime while this thread captures: only this thread's calls belong to the capture
+                    mode = {'capture_error_mode': 'thread_local'} if dist is not None else {}
+                    with torch.cuda.graph(graph, stream=side, **mode):
+                        step()
+                torch.cuda.current_stream().wait_stream(side)
+                graph.replay(); graph.replay()
                 torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph.replay(); graph.replay()
-            torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001 -- a failed capture must not cost the measurement: time eager launches
+                print(f'[bench] step not captured ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
         run = graph.replay if graph is not None else step
         barrier()
         t0 = time.perf_counter()
