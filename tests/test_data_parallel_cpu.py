@@ -172,3 +172,12 @@ def test_allreduce_flat_view_fast_path():
     ps[1].grad = torch.full((5,), 7.0)
     out2 = allreduce_gradients(ps, world=1)
     assert out2.data_ptr() != flat.data_ptr() and torch.equal(out2[6:11], torch.full((5,), 7.0))
+
+
+def test_fused_optimizer_refuses_cpu_parameters():
+    """trainer.FusedClipSGD is a HIP launch over device pointers: CPU parameters are an error, not a silent fallback."""
+    import pytest as _pytest
+    import torch as _torch
+    from squeezedet_pytorch_amd.trainer import FusedClipSGD
+    with _pytest.raises(ValueError):
+        FusedClipSGD([_torch.nn.Parameter(_torch.zeros(4))], lr=0.1)

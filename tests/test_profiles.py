@@ -36,3 +36,18 @@ def test_launch_plan_totals():
     # without the bridges: the plain launch set
     q = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_fire_bridge=False)
     assert len(q) == 1 + 2 + 30 + 1 + 1 and sum(1 for n, _ in q if n.startswith('conv_wino')) == 11
+
+
+def test_launch_plan_bridges_follow_the_table_rows():
+    """The two bridge launches are taken exactly where the shipped table has Y: / Z: rows: bs = 4 ... 64, not bs = 1 (measured slower)
+    and not SqueezeDet+ (squeeze widths above the bridge's limit)."""
+    from squeezedet_pytorch_amd import ops, plan
+    for bs in (4, 8, 16, 20, 32, 40, 64):
+        names = [n for n, _ in plan.inference_launch_plan('squeezedet', bs, (384, 1248))]
+        assert names.count('fire_bridge') == 1 and names.count('fire_pool_bridge') == 1, bs
+    names = [n for n, _ in plan.inference_launch_plan('squeezedet', 1, (384, 1248))]
+    assert 'fire_bridge' not in names and 'fire_pool_bridge' not in names and names.count('maxpool_fwd') == 2
+    names = [n for n, _ in plan.inference_launch_plan('squeezedetplus', 16, (384, 1248))]
+    assert 'fire_bridge' not in names and 'fire_pool_bridge' not in names
+    assert ops.fire_pool_bridge_ok(16, 64, 64, 32) and not ops.fire_pool_bridge_ok(32, 128, 128, 48)
+    assert ops.fire_bridge_cfg_ok(12, 16, 64, 64, 16) and not ops.fire_bridge_cfg_ok(12, 32, 128, 128, 32)
