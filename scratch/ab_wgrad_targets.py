@@ -13,7 +13,7 @@ import squeezedet_pytorch_amd as sqd
 from squeezedet_pytorch_amd import ops, synthetic
 from squeezedet_pytorch_amd.model import SqueezeDetWithLoss
 for kv in sys.argv[1:]:
-    k, v = kv.split('='); setattr(ops, k, int(v))
+    k, v = kv.split("="); setattr(ops.tiles, k, int(v))
 cfg = sqd.make_cfg(arch='squeezedet', device='cuda')
 m = SqueezeDetWithLoss(cfg); m.load_state_dict(synthetic.make_state_dict('squeezedet', seed=1234)); m = m.cuda().train()
 params = [p for p in m.parameters() if p.requires_grad]

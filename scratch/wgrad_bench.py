@@ -14,7 +14,7 @@ def timeit(fn, iters=20):
 B = int(os.environ.get('BATCH', 20))
 for (C, N, H, W) in [(16, 64, 96, 312), (32, 128, 48, 156), (48, 192, 24, 78), (64, 256, 24, 78), (96, 384, 24, 78), (768, 72, 24, 78)]:
     x = torch.randn(B, H, W, C, device='cuda'); dy = torch.randn(B, H, W, 2 * N, device='cuda')
-    ops._TARGET_WGS_WINO = int(os.environ.get('WTARGET', 512))
+    ops.tiles._TARGET_WGS_WINO = int(os.environ.get('WTARGET', 512))
     td = timeit(lambda: ops.conv_wgrad(dy, N, N, x, 0, C, 9, wino=False))
     tw = timeit(lambda: ops.conv_wgrad(dy, N, N, x, 0, C, 9, wino=True))
     a = ops.conv_wgrad(dy, N, N, x, 0, C, 9, wino=False); b = ops.conv_wgrad(dy, N, N, x, 0, C, 9, wino=True)

@@ -1,0 +1,274 @@
+"""Operand plans of the HIP kernels: packed / transformed weight copies (``ConvPlan``, ``WinoPlan``, ``FusedExpandPlan``,
+``FireWinoPlan``, ``FireBridgePlan``), their batched one-launch refresh after an optimizer step, and the split-K slab
+workspace of the weight gradients (``WgradBatch``).  Built once per (parameter, configuration), pointer-stable afterwards so
+hipGraph replays stay valid."""
+from __future__ import annotations
+
+import torch
+
+from . import _native as nat
+from . import timing
+from .timing import _Bracket
+from .tiles import (cfg_table, wino_cfgs, fused_expand_cfgs, fire_wino_cfg_ok, fire_bridge_cfg_ok, fire_pool_bridge_ok,
+                    wgrad_split)
+
+
+class ConvPlan:
+    """Packed weights ([C/KC][TAPS][Npad][KC], zero padded) + bias for one conv in one direction.
+    ``dgrad=True`` packs the data-gradient orientation of the same OIHW parameter (in/out channels
+    swapped, taps flipped).  Packing is one HIP kernel launch on the current stream."""
+    __slots__ = ('cfg_id', 'taps', 'kc', 'bn', 'C', 'N', 'Npad', 'w', 'bias')
+
+    def __init__(self, w_oihw, bias, cfg_id, dgrad=False):
+        taps_cfg, kc, _px, bn = cfg_table()[cfg_id % 1000]
+        No, Ci, kh, kw = w_oihw.shape
+        taps = kh * kw
+        if taps != taps_cfg or kh != kw or taps not in (1, 9):
+            raise ValueError(f'weight {tuple(w_oihw.shape)} does not fit conv cfg {cfg_id} (taps={taps_cfg})')
+        N, C = (Ci, No) if dgrad else (No, Ci)
+        if C % 4 or N % 4:
+            raise ValueError('channel counts must be multiples of 4')
+        if not w_oihw.is_cuda or w_oihw.dtype != torch.float32:
+            raise ValueError('weights must be fp32 CUDA tensors')
+        self.cfg_id, self.taps, self.kc, self.bn, self.C, self.N = cfg_id, taps, kc, bn, C, N
+        self.Npad = -(-N // bn) * bn
+        nchunks = -(-C // kc)
+        src = w_oihw.detach().contiguous()
+        self.w = torch.empty(nchunks, taps, self.Npad, kc, device=src.device, dtype=torch.float32)
+        rc = nat.lib().sqd_pack_conv_weight(nat.ptr(src), nat.ptr(self.w), No, Ci, taps, kc, self.Npad, int(dgrad),
+                                            nat.stream_handle(src.device))
+        nat.check(rc, 'sqd_pack_conv_weight')
+        self.bias = None if (bias is None or dgrad) else bias.detach().contiguous()
+
+
+_PACK_TABLES = {}
+
+
+def repack_batched(plans_and_weights, is_dgrad):
+    """Refresh many packed weight copies with ONE kernel launch.  plans_and_weights: [(ConvPlan, weight)],
+    is_dgrad: parallel list of bools."""
+    if not plans_and_weights:
+        return
+    rows = []
+    for (plan, w), dg in zip(plans_and_weights, is_dgrad):
+        if not w.is_contiguous():
+            raise ValueError('repack_batched: parameters must be contiguous')
+        rows.append([w.data_ptr(), plan.w.data_ptr(), w.shape[0], w.shape[1], plan.taps, plan.kc, plan.Npad, plan.w.shape[0],
+                     int(dg), plan.w.numel()])
+    dev = plans_and_weights[0][1].device
+    # the descriptor table only holds pointers and shapes: after the first optimizer step it is the same every step, so the
+    # device copy is cached (no host-to-device copy per step; also what makes the training step hipGraph-capturable)
+    key = (str(dev), tuple(tuple(r) for r in rows))
+    table = _PACK_TABLES.get(key)
+    if table is None:
+        if len(_PACK_TABLES) > 16:
+            _PACK_TABLES.clear()
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _PACK_TABLES[key] = table
+    rc = nat.lib().sqd_pack_conv_weights_batched(nat.ptr(table), len(rows), 16, nat.stream_handle(dev))
+    nat.check(rc, 'sqd_pack_conv_weights_batched')
+    return table
+
+
+def dgrad_weight(w_oihw):
+    """Weights of the convolution that computes dX from dY: swap in/out channels, flip taps."""
+    return w_oihw.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+
+
+class FusedExpandPlan(object):
+    """Packed weights of one Fire's expand pair for ``fire_expand``: the 2E output channels in alternating 16-channel
+    groups (expand1x1 group as a centre-tap-only 3x3, then the expand3x3 group), packed like any 3x3 conv."""
+
+    def __init__(self, w1, b1, w3, b3, cfg_id):
+        E, C = w1.shape[0], w1.shape[1]
+        if tuple(w1.shape) != (E, C, 1, 1) or tuple(w3.shape) != (E, C, 3, 3) or E % 16:
+            raise ValueError(f'fused expand: need expand1x1 [E,C,1,1] and expand3x3 [E,C,3,3] with E % 16 == 0, got {tuple(w1.shape)}, {tuple(w3.shape)}')
+        if cfg_id % 1000 not in fused_expand_cfgs(E):
+            raise ValueError(f'conv cfg {cfg_id} cannot run the fused expand with E={E}')
+        w1 = w1.detach(); w3 = w3.detach()
+        wf = torch.zeros(E // 16, 2, 16, C, 3, 3, device=w3.device, dtype=torch.float32)
+        wf[:, 0, :, :, 1, 1] = w1.reshape(E // 16, 16, C)
+        wf[:, 1] = w3.reshape(E // 16, 16, C, 3, 3)
+        bf = torch.stack([b1.detach().reshape(E // 16, 16), b3.detach().reshape(E // 16, 16)], 1).reshape(-1)
+        self.plan = ConvPlan(wf.reshape(2 * E, C, 3, 3), bf, cfg_id)
+        self.E, self.C, self.cfg_id = E, C, cfg_id
+
+
+class WinoPlan:
+    """Transformed weights U = G g G^T ([C/8][16][Npad][8]) + bias of one 3x3 conv for ``conv_wino``."""
+    __slots__ = ('cfg_id', 'C', 'N', 'Npad', 'bn', 'w', 'bias')
+
+    def __init__(self, w_oihw, bias, cfg_id, dgrad=False):
+        No, Ci, kh, kw = w_oihw.shape
+        if (kh, kw) != (3, 3):
+            raise ValueError(f'Winograd plan needs a 3x3 weight, got {tuple(w_oihw.shape)}')
+        if not w_oihw.is_cuda or w_oihw.dtype != torch.float32:
+            raise ValueError('weights must be fp32 CUDA tensors')
+        N, C = (Ci, No) if dgrad else (No, Ci)
+        if C % 8 or N % 4:
+            raise ValueError('Winograd conv: C must be a multiple of 8 and N of 4')
+        bn = wino_cfgs()[cfg_id % 1000][0]
+        self.cfg_id, self.C, self.N, self.bn = cfg_id, C, N, bn
+        self.Npad = -(-N // bn) * bn
+        src = w_oihw.detach().contiguous()
+        self.w = torch.empty(C // 8, 16, self.Npad, 8, device=src.device, dtype=torch.float32)
+        nat.check(nat.lib().sqd_pack_wino_weight(nat.ptr(src), nat.ptr(self.w), No, Ci, self.Npad, int(dgrad),
+                                                 nat.stream_handle(src.device)), 'sqd_pack_wino_weight')
+        self.bias = None if (bias is None or dgrad) else bias.detach().contiguous()
+
+    def repack(self, w_oihw, bias, dgrad=False):
+        """Re-transform into the same buffer after the parameter changed (pointer-stable: hipGraph replays stay valid)."""
+        src = w_oihw.detach()
+        if not src.is_contiguous():
+            raise ValueError('WinoPlan.repack: parameters must be contiguous')
+        nat.check(nat.lib().sqd_pack_wino_weight(nat.ptr(src), nat.ptr(self.w), src.shape[0], src.shape[1], self.Npad, int(dgrad),
+                                                 nat.stream_handle(src.device)), 'sqd_pack_wino_weight')
+        if self.bias is not None:
+            self.bias = bias.detach()
+
+
+def repack_wino_batched(plans_and_weights, is_dgrad):
+    """Re-transform many WinoPlans with ONE kernel launch (pointer-stable).  plans_and_weights: [(WinoPlan, weight)]."""
+    if not plans_and_weights:
+        return None
+    rows = []
+    for (plan, w), dg in zip(plans_and_weights, is_dgrad):
+        if not w.is_contiguous():
+            raise ValueError('repack_wino_batched: parameters must be contiguous')
+        rows.append([w.data_ptr(), plan.w.data_ptr(), w.shape[0], w.shape[1], plan.Npad, int(dg), (plan.C // 8) * plan.Npad * 8])
+    dev = plans_and_weights[0][1].device
+    key = ('wino', str(dev), tuple(tuple(r) for r in rows))
+    table = _PACK_TABLES.get(key)
+    if table is None:
+        if len(_PACK_TABLES) > 16:
+            _PACK_TABLES.clear()
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _PACK_TABLES[key] = table
+    nat.check(nat.lib().sqd_pack_wino_weights_batched(nat.ptr(table), len(rows), 16, nat.stream_handle(dev)), 'sqd_pack_wino_weights_batched')
+    return table
+
+
+class FireWinoPlan:
+    """Transformed weights of a Fire's expand pair for ``fire_wino``: expand3x3's U followed by expand1x1's four inner
+    positions as virtual channels (csrc/conv_wino.hip, sqd_pack_wino_fire)."""
+    __slots__ = ('cfg_id', 'C', 'N3', 'N1', 'Npad', 'w', 'b3', 'b1')
+
+    def __init__(self, w1, b1, w3, b3, cfg_id):
+        N3, C = w3.shape[0], w3.shape[1]
+        N1 = w1.shape[0]
+        if tuple(w3.shape) != (N3, C, 3, 3) or tuple(w1.shape) != (N1, C, 1, 1) or C % 8 or N1 % 16 or N3 % 4:
+            raise ValueError(f'fire_wino: need expand3x3 [N3,C,3,3] and expand1x1 [N1,C,1,1], C % 8 == 0, got {tuple(w3.shape)}, {tuple(w1.shape)}')
+        if not fire_wino_cfg_ok(cfg_id, C, N1, N3):
+            raise ValueError(f'fire_wino: configuration {cfg_id} cannot run C={C} E={N1}+{N3}')
+        self.cfg_id, self.C, self.N3, self.N1 = cfg_id, C, N3, N1
+        self.Npad = -(-N3 // 32) * 32 + -(-N1 // 128) * 32
+        self.w = torch.empty(C // 8, 16, self.Npad, 8, device=w3.device, dtype=torch.float32)
+        nat.check(nat.lib().sqd_pack_wino_fire(nat.ptr(w3.detach().contiguous()), nat.ptr(w1.detach().contiguous()), nat.ptr(self.w),
+                                               N3, N1, C, self.Npad, nat.stream_handle(w3.device)), 'sqd_pack_wino_fire')
+        self.b3 = None if b3 is None else b3.detach().contiguous()
+        self.b1 = None if b1 is None else b1.detach().contiguous()
+
+
+class FireBridgePlan:
+    """Operands of ``fire_bridge``: the Fire's expand pair transformed as in FireWinoPlan, the per-pass bias table, and the next
+    Fire's squeeze weights laid out as MFMA A operands (include/sqd_hip.h, sqd_fire_bridge_fwd)."""
+    __slots__ = ('cfg_id', 'C', 'N3', 'N1', 'Npad', 'Nsq', 'w', 'bias_tab', 'sq_ops', 'sq_bias', 'pooled')
+
+    def __init__(self, w1, b1, w3, b3, wsq, bsq, cfg_id, pooled=False):
+        N3, C = w3.shape[0], w3.shape[1]
+        N1, Nsq = w1.shape[0], wsq.shape[0]
+        if tuple(w3.shape) != (N3, C, 3, 3) or tuple(w1.shape) != (N1, C, 1, 1) or tuple(wsq.shape) != (Nsq, N1 + N3, 1, 1):
+            raise ValueError(f'fire_bridge: need expand3x3 [N3,C,3,3], expand1x1 [N1,C,1,1] and the next squeeze [Nsq,N1+N3,1,1], got '
+                             f'{tuple(w3.shape)}, {tuple(w1.shape)}, {tuple(wsq.shape)}')
+        if pooled:
+            if not fire_pool_bridge_ok(C, N3, N1, Nsq):
+                raise ValueError(f'fire_pool_bridge: cannot run C={C} E={N1}+{N3} -> {Nsq}')
+            cfg_id = 12                              # (the operand layout of the 16-wide-pass form)
+        elif not fire_bridge_cfg_ok(cfg_id, C, N3, N1, Nsq):
+            raise ValueError(f'fire_bridge: configuration {cfg_id} cannot run C={C} E={N1}+{N3} -> {Nsq}')
+        self.pooled = pooled
+        dev = w3.device
+        self.cfg_id, self.C, self.N3, self.N1, self.Nsq = cfg_id, C, N3, N1, Nsq
+        P3, P1 = -(-N3 // 32), -(-N1 // 128)
+        self.Npad = 32 * (P3 + P1)
+        self.w = torch.empty(C // 8, 16, self.Npad, 8, device=dev, dtype=torch.float32)
+        nat.check(nat.lib().sqd_pack_wino_fire(nat.ptr(w3.detach().contiguous()), nat.ptr(w1.detach().contiguous()), nat.ptr(self.w),
+                                               N3, N1, C, self.Npad, nat.stream_handle(dev)), 'sqd_pack_wino_fire')
+        # cat channel of every 16-channel block, in pass order: expand3x3 slices (cat offset N1), then expand1x1 slices
+        narrow = cfg_id % 1000 == 12                 # 16-wide passes: 1 block per expand3x3 pass, 4 per expand1x1 pass
+        if narrow:
+            rb = 2 if pooled else 4               # (the pooled form keeps only the blocks that exist when N1 <= 64)
+            base = [N1 + 16 * p for p in range(2 * P3)] + [128 * (s1 >> 1) + (2 * r + (s1 & 1)) * 16 for s1 in range(2 * P1) for r in range(rb)]
+        else:
+            base = [N1 + 32 * s + 16 * j for s in range(P3) for j in range(2)] + [128 * s + 16 * blk for s in range(P1) for blk in range(8)]
+        limit = [N1 + N3] * (2 * P3) + [N1] * (len(base) - 2 * P3)
+        nblk, nq = len(base), -(-Nsq // 16)
+        ch = torch.tensor(base, device=dev).view(nblk, 1) + torch.arange(16, device=dev).view(1, 16)          # [blk][c16]
+        ok = ch < torch.tensor(limit, device=dev).view(nblk, 1)
+        chs = torch.where(ok, ch, torch.zeros_like(ch))
+        wz = torch.zeros(16 * nq, N1 + N3, device=dev, dtype=torch.float32)
+        wz[:Nsq] = wsq.detach().reshape(Nsq, N1 + N3)
+        g = wz[:, chs.reshape(-1)].view(nq, 16, nblk, 4, 4) * ok.view(1, 1, nblk, 4, 4)                        # [q][lr][blk][g][t]
+        self.sq_ops = g.permute(2, 4, 0, 3, 1).contiguous()                                                   # [blk][t][q][g][lr]
+        bcat = torch.cat([torch.zeros(N1, device=dev) if b1 is None else b1.detach().float(),
+                          torch.zeros(N3, device=dev) if b3 is None else b3.detach().float()])
+        bvals = bcat[chs.reshape(-1)].view(nblk, 16) * ok
+        if narrow:
+            bt = torch.zeros(2 * P3 + 2 * P1, 4, 16, device=dev, dtype=torch.float32)
+            bt[:2 * P3, 0] = bvals[:2 * P3]
+            rb = 2 if pooled else 4
+            bt[2 * P3:, :rb] = bvals[2 * P3:].view(2 * P1, rb, 16)
+        else:
+            bt = torch.zeros(P3 + P1, 8, 16, device=dev, dtype=torch.float32)
+            bt[:P3, :2] = bvals[:2 * P3].view(P3, 2, 16)
+            bt[P3:] = bvals[2 * P3:].view(P1, 8, 16)
+        self.bias_tab = bt.contiguous()
+        self.sq_bias = (torch.zeros(Nsq, device=dev) if bsq is None else bsq.detach().float()).contiguous()
+
+
+_WGR_OUT = 64               # outputs per workgroup of the slab-reduction kernels (csrc/wgrad.hip WGR_OUT)
+
+
+class WgradBatch:
+    """Workspace + descriptor table for reducing the partial slabs of many conv weight gradients with ONE launch into a
+    flat gradient buffer.  ``entries``: [(key, N, C, taps, B, H, W, dw_offset, db_offset)] (offsets in floats into the flat
+    buffer).  Slab workspace and table are allocated once and reused every step (pointer-stable)."""
+
+    def __init__(self, entries, device):
+        rows, self.slabs, off, blk = [], {}, 0, 0
+        self.row_blocks = [0]                  # first workgroup of every record (+ the total at the end)
+        for key, N, C, taps, B, H, W, dw_off, db_off in entries:
+            S, stride = wgrad_split(N, C, taps, B, H, W)
+            rows.append([off, dw_off, db_off, S, stride, N, C, taps, blk])
+            self.slabs[key] = (off, S * stride)
+            off += S * stride
+            blk += -(-stride // _WGR_OUT)
+            self.row_blocks.append(blk)
+        self.total_blocks = blk
+        self.row_of = {key: i for i, (key, *_rest) in enumerate(entries)}
+        self.workspace = torch.empty(off, device=device, dtype=torch.float32)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.nrows = len(rows)
+        self.bytes = 4.0 * off
+
+    def slab(self, key):
+        off, n = self.slabs[key]
+        return self.workspace[off:off + n]
+
+    def reduce(self, grad_flat, row_lo=0, row_hi=None):
+        """Reduce the slabs of records [row_lo, row_hi) (default: all) into ``grad_flat``."""
+        row_hi = self.nrows if row_hi is None else row_hi
+        if not (0 <= row_lo < row_hi <= self.nrows):
+            raise ValueError('WgradBatch.reduce: bad record range')
+        nrec = row_hi - row_lo
+        b0, b1 = self.row_blocks[row_lo], self.row_blocks[row_hi]
+        br = _Bracket('wgrad_reduce_batched', f'{nrec} layers', 0.0, self.bytes * (b1 - b0) / max(self.total_blocks, 1)) if timing._timer is not None else None
+        if nrec == self.nrows:
+            rc = nat.lib().sqd_wgrad_reduce_batched(nat.ptr(self.table), self.nrows, self.total_blocks, nat.ptr(self.workspace),
+                                                    nat.ptr(grad_flat), nat.stream_handle(grad_flat.device))
+        else:
+            rc = nat.lib().sqd_wgrad_reduce_batched_range(nat.c_p(self.table.data_ptr() + row_lo * 9 * 8), nrec, b0, b1 - b0,
+                                                          nat.ptr(self.workspace), nat.ptr(grad_flat), nat.stream_handle(grad_flat.device))
+        nat.check(rc, 'sqd_wgrad_reduce_batched')
+        if br is not None:
+            br.done()
