@@ -91,29 +91,60 @@ def _is_rank0():
     return d is None or d.get_rank() == 0
 
 
-def _rng_state_here():
-    """This process's random streams: the CPU generator and the generator of the GPU it computes on."""
+def _model_device(model):
+    """The GPU this process computes on: the device of the model's parameters (a process that set ``cfg.device='cuda:N'`` without
+    ``torch.cuda.set_device`` has another *current* device), else the current device, else None."""
+    for p in _unwrap(model).parameters():
+        if p.is_cuda:
+            return p.device
+        break
+    return torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+
+
+def _rng_state_here(model):
+    """This process's random streams: the CPU generator and the generator of the GPU the model lives on."""
     st = {'torch': torch.get_rng_state()}
-    if torch.cuda.is_available():
-        st['cuda'] = torch.cuda.get_rng_state(torch.cuda.current_device())
+    dev = _model_device(model)
+    if dev is not None:
+        st['cuda'] = torch.cuda.get_rng_state(dev)
     return st
 
 
-def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, rng=True, extra=None):
+def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, epoch=0, rng=True, extra=None, all_ranks=True):
     """Reference-compatible file plus optimizer / scheduler / RNG state.  Tensors are moved to the CPU; written
-    atomically (tmp + rename) by rank 0.  With a process group EVERY rank must call this (it is a collective): the
-    random streams differ per rank (dropout masks), so each rank's state is gathered into the file."""
+    atomically (tmp + rename) by rank 0.
+
+    Collective contract (one process per GPU): with ``all_ranks=True`` (default) EVERY rank must call this -- the random
+    streams differ per rank (dropout masks), so each rank's state is gathered into the file, and the call ends with a
+    barrier: when it returns on any rank the file is complete and ``load_checkpoint`` may read it.  A caller that keeps
+    the reference's ``if rank == 0: save(...)`` pattern (src/train.py:70-78 saves from its single process) must pass
+    ``all_ranks=False``: no collective is entered, only the calling rank's streams are stored and ranks > 0 resume from
+    stream 0 with a warning (not an exact multi-GPU resume)."""
     d = _dist()
+    multi = d is not None and d.get_world_size() > 1
     rng_states = None
     if rng:
-        mine = _rng_state_here()
-        if d is not None and d.get_world_size() > 1:
+        mine = _rng_state_here(model)
+        if multi and all_ranks:
             rng_states = [None] * d.get_world_size() if d.get_rank() == 0 else None
             d.gather_object(mine, rng_states, dst=0)
         else:
             rng_states = [mine]
-    if not _is_rank0():
+    if multi and all_ranks:
+        try:
+            if _is_rank0():
+                _write_checkpoint(path, model, optimizer, lr_scheduler, epoch, rng, rng_states, extra)
+        finally:
+            d.barrier()                       # the file is in place before any rank goes on (and may load it)
         return
+    if multi and not all_ranks and not _is_rank0():
+        import warnings
+        warnings.warn('save_checkpoint(all_ranks=False) called on a rank > 0: nothing written (rank 0 writes the file)')
+        return
+    _write_checkpoint(path, model, optimizer, lr_scheduler, epoch, rng, rng_states, extra)
+
+
+def _write_checkpoint(path, model, optimizer, lr_scheduler, epoch, rng, rng_states, extra):
     data = {'epoch': epoch,
             'state_dict': {k: v.detach().cpu() for k, v in _unwrap(model).state_dict().items()}}
     if optimizer is not None:
@@ -154,6 +185,11 @@ def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, restore_rng=
                           f'rank {rank} resumes from stream {rank % len(states)} (not an exact resume)')
         st = states[rank % len(states)]
         torch.set_rng_state(st['torch'])
-        if torch.cuda.is_available() and 'cuda' in st:
-            torch.cuda.set_rng_state(st['cuda'], torch.cuda.current_device())
+        dev = _model_device(model)
+        if dev is not None and 'cuda' in st:
+            torch.cuda.set_rng_state(st['cuda'], dev)
+        if len(states) == world:
+            # this rank's own streams are back: a later attach_data_parallel / Trainer(...) must not re-seed them
+            from .trainer import mark_rank_streams_set
+            mark_rank_streams_set(True)
     return ckpt['epoch']

@@ -129,11 +129,22 @@ def find_base(model):
     raise TypeError('no SqueezeDetBase inside the model')
 
 
+_RANK_STREAMS = {'set': False}     # this process's random streams already differ from the other ranks' (seeded here or restored)
+
+
+def mark_rank_streams_set(flag=True):
+    """Tell ``attach_data_parallel`` that this process's random streams are already rank-specific (``checkpoint.load_checkpoint``
+    calls this after restoring the rank's own streams, so a later ``Trainer(...)`` / ``attach_data_parallel`` leaves them alone)."""
+    _RANK_STREAMS['set'] = bool(flag)
+
+
 def attach_data_parallel(model, optimizer=None, group=None, overlap=True, broadcast=True, seed_offset=True):
     """Process-per-GPU replacement of the reference's ``DataParallel`` wrapper (src/engine/trainer.py:83-85): after this
     call ``loss.mean().backward()`` on the local shard leaves the gradient of the GLOBAL batch mean in ``p.grad`` on every
     rank.  Also replicates rank 0's weights (and optimizer state tensors) once and de-correlates the dropout streams of
-    the ranks.  No-op without an initialised process group.  Returns the ``GradientExchange`` (or None)."""
+    the ranks -- ONCE per process: a second call (the INTEGRATION.md recipe followed by ``Trainer``), or a call after
+    ``load_checkpoint`` has restored this rank's own streams (the reference's resume order: load, then ``Trainer(...)``), does
+    not touch the generators again.  No-op without an initialised process group.  Returns the ``GradientExchange`` (or None)."""
     d = _dist()
     base = find_base(model)
     if d is None:
@@ -152,10 +163,11 @@ def attach_data_parallel(model, optimizer=None, group=None, overlap=True, broadc
                     off = 0
                     for t in tensors:
                         t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
-    if seed_offset:
+    if seed_offset and not _RANK_STREAMS['set']:
         rank = d.get_rank(group)
         if rank:
             torch.manual_seed(torch.initial_seed() + rank)     # seeds the CPU and every GPU generator of this process
+        _RANK_STREAMS['set'] = True
     return ex
 
 
@@ -317,19 +329,28 @@ class Trainer(object):
         return self.run_epoch('val', epoch, data_loader)
 
 
-class FusedClipSGD:
+class FusedClipSGD(torch.optim.Optimizer):
     """``torch.nn.utils.clip_grad_norm_(params, max_norm)`` + ``torch.optim.SGD(params, lr, momentum, weight_decay).step()``
     (src/engine/trainer.py:47-50) as ONE launch over all parameter tensors (csrc/optim.hip, sqd_sgd_clip_step): torch runs the pair
     as ~10 foreach / elementwise launches over the 64 tensors (about 0.15 ms of a 6.3 ms training step).  Same arithmetic in the
     same order per element; the gradient norm is one reduction over the backward's flat gradient buffer when the gradients are
     consecutive views of it (the HIP backward's layout), else torch's foreach norm; it is read on the device (no host sync, hipGraph
-    capturable).  Drop-in for the two calls: ``opt.zero_grad(); loss.backward(); opt.step()``; ``state_dict`` carries the momentum."""
+    capturable).
+
+    A ``torch.optim.Optimizer`` with ONE parameter group: ``param_groups[0]`` carries ``lr`` / ``momentum`` / ``weight_decay`` /
+    ``max_norm`` and is read at every ``step()``, so ``torch.optim.lr_scheduler.StepLR(opt, 60, 0.5)`` (the reference's schedule,
+    src/train.py:36, stepped at src/engine/trainer.py:67) drives it like ``torch.optim.SGD``.  ``max_norm > 0`` clips INSIDE
+    ``step()``: a caller that keeps the reference's explicit ``clip_grad_norm_`` line must construct it with ``max_norm=0`` (or
+    drop the line, as ``Trainer._iteration`` does) -- otherwise the gradient is clipped twice.  The hyper-parameters are launch
+    arguments: a hipGraph replay of a captured step keeps the values of the capture (re-capture after an LR change)."""
 
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, max_norm=0.0, flat_grad=None):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params or any(p.dtype != torch.float32 or not p.is_cuda for p in self.params):
+        params = [p for p in params if p.requires_grad]
+        if not params or any(p.dtype != torch.float32 or not p.is_cuda for p in params):
             raise ValueError('FusedClipSGD: fp32 parameters on the GPU only (the product path has no CPU fallback)')
-        self.lr, self.momentum, self.weight_decay, self.max_norm = float(lr), float(momentum), float(weight_decay), float(max_norm)
+        super().__init__(params, dict(lr=float(lr), momentum=float(momentum), weight_decay=float(weight_decay), max_norm=float(max_norm)))
+        if len(self.param_groups) != 1:
+            raise ValueError('FusedClipSGD: one parameter group (the kernel applies one set of hyper-parameters to all tensors)')
         self.flat_grad = flat_grad                     # callable -> the flat gradient tensor the .grad views live in (or None)
         dev = self.params[0].device
         self.total = sum(p.numel() for p in self.params)
@@ -337,16 +358,26 @@ class FusedClipSGD:
         self._bufs, off = [], 0
         for p in self.params:
             self._bufs.append(self.momentum_flat[off:off + p.numel()]); off += p.numel()
+            self.state[p]['momentum_buffer'] = self._bufs[-1]       # views: attach_data_parallel broadcasts optimizer state tensors in place
         self._table = self._table_key = None
         self.last_norm = None
-        self.state = {0: {'momentum_flat': self.momentum_flat}}      # (attach_data_parallel broadcasts optimizer state tensors)
 
-    def zero_grad(self, set_to_none=True):
-        for p in self.params:
-            if set_to_none:
-                p.grad = None
-            elif p.grad is not None:
-                p.grad.zero_()
+    @property
+    def params(self):
+        return self.param_groups[0]['params']
+
+    def _hyper(self, name):
+        return float(self.param_groups[0][name])
+
+    lr = property(lambda self: self._hyper('lr'))
+    momentum = property(lambda self: self._hyper('momentum'))
+    weight_decay = property(lambda self: self._hyper('weight_decay'))
+    max_norm = property(lambda self: self._hyper('max_norm'))
+
+    def add_param_group(self, param_group):
+        if getattr(self, 'param_groups', None):
+            raise ValueError('FusedClipSGD: one parameter group only')
+        super().add_param_group(param_group)
 
     def _flat_base(self, grads):
         """The flat gradient tensor if the gradients are consecutive views of it (the HIP backward's layout), else None."""
@@ -361,41 +392,57 @@ class FusedClipSGD:
         return flat
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
         from . import _native as nat
-        grads = [p.grad for p in self.params]
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        params = self.params
+        grads = [p.grad for p in params]
         if any(g is None for g in grads):
             raise RuntimeError('FusedClipSGD.step: a parameter has no gradient')
         flat = self._flat_base(grads)
         if flat is None:
             grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
-        # the descriptor table: with a flat gradient buffer it holds offsets and never changes (the buffer's address is a launch
-        # argument), otherwise the gradients' addresses
-        key = ('flat',) if flat is not None else tuple(g.data_ptr() for g in grads)
+        # the descriptor table holds the parameter and momentum addresses and, per tensor, its offset into the flat gradient
+        # buffer (whose own address is a launch argument) or the gradient's address.  Everything baked into it is part of the key:
+        # a parameter whose storage was replaced after the first step (model.to() / p.data = ...) rebuilds the table instead of
+        # letting the kernel write through a stale pointer
+        key = (('flat',) if flat is not None else tuple(g.data_ptr() for g in grads),
+               tuple(p.data_ptr() for p in params), self.momentum_flat.data_ptr())
         if key != self._table_key:
             off, rows = 0, []
-            for p, g, b in zip(self.params, grads, self._bufs):
+            for p, g, b in zip(params, grads, self._bufs):
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                    raise RuntimeError('FusedClipSGD.step: parameters must stay contiguous fp32 GPU tensors')
                 rows.append([p.data_ptr(), off if flat is not None else g.data_ptr(), b.data_ptr(), p.numel()]); off += p.numel()
-            self._table = torch.tensor(rows, dtype=torch.int64).to(self.params[0].device)
+            self._table = torch.tensor(rows, dtype=torch.int64).to(params[0].device)
             self._table_key = key
         norm = None
-        if self.max_norm > 0:
+        max_norm = self.max_norm
+        if max_norm > 0:
             norm = flat[:self.total].norm() if flat is not None else torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
-        nat.check(nat.lib().sqd_sgd_clip_step(nat.ptr(self._table), len(self.params), nat.ptr(flat), nat.ptr(norm), self.max_norm, self.lr,
-                                              self.momentum, self.weight_decay, 64, nat.stream_handle(self.params[0].device)),
+        nat.check(nat.lib().sqd_sgd_clip_step(nat.ptr(self._table), len(params), nat.ptr(flat), nat.ptr(norm), max_norm, self.lr,
+                                              self.momentum, self.weight_decay, 64, nat.stream_handle(params[0].device)),
                   'sqd_sgd_clip_step')
-        torch.autograd.graph.increment_version(self.params)        # (the packed-weight caches key on the version counters)
+        torch.autograd.graph.increment_version(params)        # (the packed-weight caches key on the version counters)
         self.last_norm = norm
-        return norm
+        return norm if closure is None else loss
 
     def state_dict(self):
-        return {'momentum_flat': self.momentum_flat.clone(), 'lr': self.lr, 'momentum': self.momentum, 'weight_decay': self.weight_decay,
-                'max_norm': self.max_norm}
+        g = self.param_groups[0]
+        return {'momentum_flat': self.momentum_flat.clone(), 'lr': g['lr'], 'momentum': g['momentum'], 'weight_decay': g['weight_decay'],
+                'max_norm': g['max_norm'], 'initial_lr': g.get('initial_lr')}
 
     def load_state_dict(self, sd):
         self.momentum_flat.copy_(sd['momentum_flat'].to(self.momentum_flat.device))
-        self.lr, self.momentum = float(sd.get('lr', self.lr)), float(sd.get('momentum', self.momentum))
-        self.weight_decay, self.max_norm = float(sd.get('weight_decay', self.weight_decay)), float(sd.get('max_norm', self.max_norm))
+        g = self.param_groups[0]
+        for k in ('lr', 'momentum', 'weight_decay', 'max_norm'):
+            if sd.get(k) is not None:
+                g[k] = float(sd[k])
+        if sd.get('initial_lr') is not None:
+            g['initial_lr'] = float(sd['initial_lr'])
 
 
 def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1, force_exchange=False, fused_optimizer=True):

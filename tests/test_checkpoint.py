@@ -182,3 +182,80 @@ def test_world2_resume_restores_each_ranks_random_stream(tmp_path):
     assert not torch.equal(r0['got'], r1['got'])
     ckpt = torch.load(path, weights_only=False)
     assert len(ckpt['rng']['per_rank']) == 2 and set(ckpt['state_dict']) == {'0.weight', '0.bias'}
+
+
+def _resume_then_trainer_worker(rank, world, port, path, out_dir):
+    """The reference's resume order (src/train.py: load the checkpoint, THEN build Trainer, whose set_device attaches the
+    data-parallel exchange): the attach must not re-seed the streams load_checkpoint has just restored."""
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd import checkpoint as ckp, trainer as tr
+    from squeezedet_pytorch_amd.model import SqueezeDetWithLoss
+    cfg = sqd.make_cfg(input_size=(64, 96), device='cpu', gpus=[0, 1], chunk_sizes=[1, 1])
+
+    def build():
+        m = SqueezeDetWithLoss(cfg)
+        opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+        return m, opt, torch.optim.lr_scheduler.StepLR(opt, 60, 0.5)
+    torch.manual_seed(7)
+    m, opt, sched = build()
+    t = tr.Trainer(m, opt, sched, cfg)                              # first attach: ranks > 0 get their own stream (once)
+    first = torch.initial_seed()
+    tr.attach_data_parallel(m, opt)                                 # INTEGRATION.md recipe + Trainer = two attaches: no second offset
+    assert torch.initial_seed() == first and first == 7 + rank
+    torch.rand(5)
+    ckp.save_checkpoint(path, m, opt, sched, epoch=1)               # collective, ends with a barrier: the file is complete here
+    want = torch.rand(8)                                            # the uninterrupted run's next draw
+    # "restart" in the same processes: fresh objects, streams elsewhere, and the process-level flag cleared as in a new process
+    torch.manual_seed(999)
+    tr.mark_rank_streams_set(False)
+    m2, opt2, sched2 = build()
+    assert ckp.load_checkpoint(path, m2, opt2, sched2) == 1
+    tr.Trainer(m2, opt2, sched2, cfg)                               # set_device -> attach_data_parallel: must leave the streams alone
+    got = torch.rand(8)
+    torch.save({'want': want, 'got': got}, os.path.join(out_dir, f't{rank}.pt'))
+    assert t.exchange is not None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_load_checkpoint_then_trainer_keeps_restored_streams(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, 35500 + (os.getpid() % 2000)
+    path = str(tmp_path / 'dp_resume_trainer.pth')
+    mp.spawn(_resume_then_trainer_worker, args=(world, port, path, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(str(tmp_path / 't0.pt')); r1 = torch.load(str(tmp_path / 't1.pt'))
+    assert torch.equal(r0['want'], r0['got']) and torch.equal(r1['want'], r1['got'])
+    assert not torch.equal(r0['got'], r1['got'])
+
+
+def _rank0_only_save_worker(rank, world, port, path, out_dir):
+    import sys
+    import warnings
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from squeezedet_pytorch_amd import checkpoint as ckp
+    net = torch.nn.Linear(3, 3)
+    if rank == 0:                                                    # the reference's pattern: only rank 0 saves -- must not hang
+        ckp.save_checkpoint(path, net, epoch=5, all_ranks=False)
+    dist.barrier()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert ckp.load_checkpoint(path, torch.nn.Linear(3, 3)) == 5
+    assert any('not an exact resume' in str(x.message) for x in w)  # one stream in the file, two ranks
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_rank0_only_save_does_not_deadlock(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, 37500 + (os.getpid() % 2000)
+    mp.spawn(_rank0_only_save_worker, args=(world, port, str(tmp_path / 'r0only.pth'), str(tmp_path)), nprocs=world, join=True)

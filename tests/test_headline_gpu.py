@@ -55,7 +55,7 @@ class LaunchLog:
         monkeypatch.setattr(ops, 'conv_wino', conv_wino)
         monkeypatch.setattr(ops, 'fire_expand', fire_expand)
 
-    def assert_exact_table_hits(self, expect_3x3, allow_fused=False, expect_bridges=0):
+    def assert_exact_table_hits(self, expect_3x3, allow_fused=False, expect_bridges=0, wino_only=True):
         """Every launch ran the configuration the shipped table holds for EXACTLY this shape (no nearest-shape or
         heuristic fallback), and every 3x3 layer ran the Winograd kernel (``allow_fused``: or the one-launch fused
         expand where the table's ``F:`` row says it wins; ``expect_bridges``: Fire -> Fire bridge launches, each standing
@@ -73,8 +73,8 @@ class LaunchLog:
                 key = f'F:{C}:{N}:{npix}'
             elif taps == 9:
                 n3 += 1
-                assert kind == 'wino', f'3x3 layer C{C} N{N} npix {npix} ran {kind}, expected the Winograd kernel'
-                key = f'W:{C}:{N}:{npix}'
+                assert kind == 'wino' or not wino_only, f'3x3 layer C{C} N{N} npix {npix} ran {kind}, expected the Winograd kernel'
+                key = f'W:{C}:{N}:{npix}' if kind == 'wino' else f'9:{C}:{N}:{npix}'
             else:
                 key = f'{taps}:{C}:{N}:{npix}'
             assert key in tab, f'{key}: no exact entry in tuning.json'
@@ -159,8 +159,8 @@ def test_squeezedet_bs20_inference_vs_oracle(monkeypatch):
 
 
 def test_squeezedetplus_bs16_inference_vs_oracle(monkeypatch):
-    """BASELINE config 5: SqueezeDet+ bs=16 at 1248x384 with the shipped table.  The oracle (83 GFLOP per image on the
-    CPU) checks the first, a middle and the last image of the batch -- different rounds of the persistent grids."""
+    """BASELINE config 5: SqueezeDet+ bs=16 at 1248x384 with the shipped table, ALL 16 images against the oracle (83 GFLOP per
+    image on the CPU: 1.3 TFLOP, tens of seconds on the box's 16 cores), processed in chunks of 4 to bound host memory."""
     cfg, det, sd = _infer_model('squeezedetplus')
     x = synthetic.make_images(16, SIZE, seed=0)
     xg = x.cuda()
@@ -168,11 +168,13 @@ def test_squeezedetplus_bs16_inference_vs_oracle(monkeypatch):
     with torch.no_grad():
         pred = det.model.base(xg)
     log.assert_exact_table_hits(expect_3x3=11, allow_fused=True)
-    sel = [0, 7, 15]
+    pc = pred.cpu()
+    errs = []
     with torch.no_grad():
-        ref = oracle.backbone_forward(x[sel], sd, arch='squeezedetplus')
-    err = (pred[sel].cpu() - ref).abs().amax(dim=(1, 2))
-    assert float(err.max()) <= TOL, err.tolist()
+        for lo in range(0, 16, 4):
+            ref = oracle.backbone_forward(x[lo:lo + 4], sd, arch='squeezedetplus')
+            errs += (pc[lo:lo + 4] - ref).abs().amax(dim=(1, 2)).tolist()
+    assert len(errs) == 16 and max(errs) <= TOL, errs
     out = det.detect_device(xg)
     torch.cuda.synchronize()
     _check_detect(pred.cpu(), cfg, out)
@@ -190,28 +192,43 @@ def _flat_views_intact(model):
         off += p.numel()
 
 
-def test_squeezedet_bs20_training_step_vs_oracle(monkeypatch):
-    """BASELINE config 3: one bs=20 training iteration (fwd, loss.mean(), backward, clip 5.0, SGD) vs the oracle's CPU
-    autograd run of the same step, dropout off (RNG cannot match, SURVEY 8a row E)."""
+def _check_sgd_update(named_params, old_sd, new_ref, grads_ref, lr, tight=('base.convdet.weight', 'base.convdet.bias')):
+    """Post-step weights, per tensor, as the relative L2 error of the UPDATE (new - old): what the optimizer step adds is
+    lr * (clip * g + wd * p), so this is the gradient's own relative-L2 bar (2e-2 flip-aware, 1e-3 on ConvDet whose gradient
+    has no mask between it and the loss) applied to every tensor separately -- a systematic 4 % error in one layer's gradient
+    fails its row, which a max-abs bound scaled by the tensor's largest gradient entry would pass."""
+    worst = {}
+    for n, p in named_params:
+        old = old_sd[n.replace('base.', '', 1) if n.replace('base.', '', 1) in old_sd else n].float()
+        du = (p.detach().cpu() - old).double()
+        dr = (new_ref[n.replace('base.', '', 1) if n.replace('base.', '', 1) in new_ref else n].float() - old).double()
+        rel = float((du - dr).norm() / max(float(dr.norm()), 1e-30))
+        worst[n] = rel
+        bar = 1e-3 if n in tight else 2e-2
+        assert rel <= bar, f'{n}: update relative L2 {rel:.3e} > {bar}'
+    return worst
+
+
+def _training_step_vs_oracle(arch, bs, monkeypatch, expect_3x3):
     from squeezedet_pytorch_amd.model import SqueezeDetWithLoss
     from test_training_gpu import _check_grads_flip_aware
-    cfg = sqd.make_cfg(arch='squeezedet', dropout_prob=0.0, device='cuda')
+    cfg = sqd.make_cfg(arch=arch, dropout_prob=0.0, device='cuda')
     m = SqueezeDetWithLoss(cfg)
-    sd = synthetic.make_state_dict('squeezedet', seed=1234)
+    sd = synthetic.make_state_dict(arch, seed=1234)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
-    x = synthetic.make_images(20, SIZE, seed=0)
-    gt = synthetic.make_gt(20, cfg.anchors, SIZE, seed=1)
+    x = synthetic.make_images(bs, SIZE, seed=0)
+    gt = synthetic.make_gt(bs, cfg.anchors, SIZE, seed=1)
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     log = LaunchLog(monkeypatch)
     loss_vec, stats = m({'image': x.cuda(), 'gt': gt.cuda()})
     loss = loss_vec.mean()
     opt.zero_grad()
     loss.backward()
-    # forward 11 + data gradients 10 expand3x3 + ConvDet = 22 Winograd launches, all on exact table rows
-    log.assert_exact_table_hits(expect_3x3=22)
+    # forward 11 + data gradients 10 expand3x3 + ConvDet = 22 3x3 launches, all on exact table rows
+    log.assert_exact_table_hits(expect_3x3=expect_3x3, allow_fused=(arch != 'squeezedet'), wino_only=(arch == 'squeezedet'))
     _flat_views_intact(m)
-    new_p, _, grads, total, loss_o, stats_o = oracle.train_step_reference(sd, None, x, gt, cfg.anchors, SIZE)
+    new_p, _, grads, total, loss_o, stats_o = oracle.train_step_reference(sd, None, x, gt, cfg.anchors, SIZE, arch=arch)
     np.testing.assert_allclose(loss_vec.detach().cpu().numpy(), loss_o.numpy(), rtol=1e-4)
     for k in ('class_loss', 'score_loss', 'bbox_loss'):
         np.testing.assert_allclose(stats[k].detach().cpu().numpy(), stats_o[k].numpy(), rtol=1e-4, atol=1e-7)
@@ -219,9 +236,23 @@ def test_squeezedet_bs20_training_step_vs_oracle(monkeypatch):
     tn = float(torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0))
     assert abs(tn - total) <= 1e-2 * total
     opt.step()
-    for n, p in m.named_parameters():
-        ref = new_p[n]
-        assert (p.detach().cpu() - ref).abs().max().item() <= 5e-2 * 0.01 * max(float(grads[n].abs().max()), 1e-3) + 1e-7, n
+    names = {n: n for n, _ in m.named_parameters()}
+    worst = _check_sgd_update(m.named_parameters(), {k: v for k, v in sd.items()}, new_p, grads, 0.01)
+    print(f'[{arch} bs={bs}] worst update relL2: ' + ', '.join(f'{k}={v:.2e}' for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:4]))
+    assert names
+
+
+def test_squeezedet_bs20_training_step_vs_oracle(monkeypatch):
+    """BASELINE config 3: one bs=20 training iteration (fwd, loss.mean(), backward, clip 5.0, SGD) vs the oracle's CPU
+    autograd run of the same step, dropout off (RNG cannot match, SURVEY 8a row E)."""
+    _training_step_vs_oracle('squeezedet', 20, monkeypatch, expect_3x3=22)
+
+
+def test_squeezedetplus_bs16_training_step_vs_oracle(monkeypatch):
+    """BASELINE config 5, training: one bs=16 SqueezeDet+ iteration at 1248x384 (the step profiles/*_bench_squeezedetplus.json
+    times) vs the oracle's CPU autograd run: losses 1e-4, ConvDet gradients 2e-4, every other gradient flip-aware, the SGD
+    update per tensor in relative L2."""
+    _training_step_vs_oracle('squeezedetplus', 16, monkeypatch, expect_3x3=22)
 
 
 @pytest.mark.parametrize("cfg_id,B,H,W,C,N", [

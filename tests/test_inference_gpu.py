@@ -395,3 +395,23 @@ def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
     np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
     np.testing.assert_allclose(pred1[0].cpu().numpy()[gk["top_idx"]], gk["pred_top"], atol=TOL, rtol=0)
     assert used['n'] == 6                                   # three bridges x two SqueezeDet forwards
+
+
+def test_filter_nms_boundary_gpu():
+    """IoU == nms_thresh exactly (see tests/test_oracle_golden.py::test_nms_exactly_at_threshold_is_kept): the HIP filter keeps the
+    box (strict >), and suppresses it with the threshold one float32 ulp lower -- same side of the boundary as the oracle."""
+    from squeezedet_pytorch_amd import ops
+    from test_oracle_golden import nms_boundary_case
+    boxes, scores, half, below, above = nms_boundary_case()
+    A = 70                                                  # more anchors than keep_top_k; the rest score below everything
+    sc = np.full((1, A), 0.01, np.float32); sc[0, :2] = scores
+    bx = np.zeros((1, A, 4), np.float32); bx[0, :2] = boxes
+    bx[0, 2:, 0] = 100 + 10 * np.arange(A - 2); bx[0, 2:, 2] = bx[0, 2:, 0] + 5; bx[0, 2:, 3] = 5
+    ids = np.zeros((1, A), np.int64)
+    for thr, want in ((float(half), [0, 1]), (float(below), [0]), (float(above), [0, 1])):
+        cnt, cls, s2, b2, idx = ops.filter_dense(torch.from_numpy(ids).cuda(), torch.from_numpy(sc).cuda(), torch.from_numpy(bx).cuda(),
+                                                 3, 64, thr, 0.3)
+        n = int(cnt[0])
+        assert idx[0, :n].cpu().tolist() == want, (thr, idx[0, :n].cpu().tolist())
+        d = oracle.filter_detections(ids[0], sc[0], bx[0], 64, thr, 0.3)
+        assert list(d['anchor_idx']) == want

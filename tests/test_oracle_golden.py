@@ -41,7 +41,15 @@ def test_backbone_small(golden_dir, arch):
     np.testing.assert_allclose(pred.numpy(), g[f"{arch}_pred"], atol=TOL, rtol=0)
     np.testing.assert_allclose(sc.numpy(), g[f"{arch}_scores"], atol=TOL, rtol=0)
     np.testing.assert_allclose(bx.numpy(), g[f"{arch}_boxes"], atol=2e-3, rtol=0)   # pixels
-    assert (ids.numpy() == g[f"{arch}_class_ids"]).mean() > 0.999
+    # class ids are an argmax over class score: bit-exact wherever the runner-up is more than 2e-4 behind on the REFERENCE's pred
+    # (a 1e-4 difference between two CPU builds' preds cannot move the winner there); only anchors inside that margin may differ
+    gp = torch.from_numpy(g[f"{arch}_pred"])
+    probs, _, conf, _, _ = oracle.resolve_predictions(gp, cfg.anchors, cfg.input_size, cfg.num_classes)
+    top2 = torch.topk(probs * conf, 2, dim=2)[0]
+    margin = (top2[..., 0] - top2[..., 1]).numpy()
+    diff = ids.numpy() != g[f"{arch}_class_ids"]
+    assert not (diff & (margin > 2e-4)).any(), int((diff & (margin > 2e-4)).sum())
+    assert diff.sum() <= (margin <= 2e-4).sum()
     np.testing.assert_allclose(cap["features.3"].numpy()[:, ::8], g[f"{arch}_feat3"], atol=TOL, rtol=0)
     for i in (0, 2, 3, 5, 14):
         t = cap[f"features.{i}"].double()
@@ -127,6 +135,33 @@ def test_nms_known_answers():
     # negative-width box (x2<x1): negative area, inter clamps to 0 -> never suppressed / never suppresses
     n = np.array([[10, 0, 4, 10], [0, 0, 10, 10]], np.float32)
     assert list(oracle.nms(n, np.array([.9, .8], np.float32), 0.4)) == [0, 1]
+
+
+def nms_boundary_case():
+    """Two boxes whose float32 IoU equals the float32 threshold EXACTLY, plus the cases one ulp either side.
+    A = [0,0,4,4] (area 16), B = [0,0,2,4] (area 8): inter 8, union 16, IoU = 0.5 exactly in float32; threshold 0.5."""
+    boxes = np.array([[0, 0, 4, 4], [0, 0, 2, 4]], np.float32)
+    scores = np.array([.9, .8], np.float32)
+    half = np.float32(0.5)
+    return boxes, scores, half, np.nextafter(half, np.float32(0)), np.nextafter(half, np.float32(1))
+
+
+def test_nms_exactly_at_threshold_is_kept():
+    """The boundary the build takes at IoU == nms_thresh (src/engine/detector.py:104 calls torchvision.ops.nms, third party,
+    pinned at 0.3.0 by requirements.txt:27 and absent here).  This build suppresses on IoU > threshold (strict): a box whose IoU
+    with a kept box EQUALS the threshold survives.  torchvision's CPU/CUDA kernels of every release this project could verify
+    by reading (0.5 ... 0.20: ``if (ovr > iou_threshold) suppressed``) are strict as well; SURVEY 8c records a belief that
+    0.3.0 used ``>=`` which cannot be checked without that wheel.  The two readings differ ONLY on this measure-zero
+    boundary; the HIP kernel is tested for the same behaviour (tests/test_inference_gpu.py::test_filter_nms_boundary_gpu)."""
+    boxes, scores, half, below, above = nms_boundary_case()
+    assert list(oracle.nms(boxes, scores, float(half))) == [0, 1]          # IoU == thr: kept (strict >)
+    assert list(oracle.nms(boxes, scores, float(below))) == [0]            # thr one ulp lower: suppressed
+    assert list(oracle.nms(boxes, scores, float(above))) == [0, 1]
+    cls = np.zeros(2, np.int64)
+    d = oracle.filter_detections(cls, scores, boxes, 64, float(half), 0.3)
+    assert list(d['anchor_idx']) == [0, 1]
+    d = oracle.filter_detections(cls, scores, boxes, 64, float(below), 0.3)
+    assert list(d['anchor_idx']) == [0]
 
 
 def test_filter_known_answers():

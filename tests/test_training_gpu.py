@@ -364,3 +364,42 @@ def test_train_steps_with_fused_optimizer_vs_torch_and_golden(golden_dir):
             assert abs(la.item() - g["loss"][0]) <= 1e-4 * abs(g["loss"][0])
             ps = np.array([float(p.double().abs().sum()) for _, p in ma.named_parameters()])
             np.testing.assert_allclose(ps, g["new_param_abs"], rtol=1e-4)
+
+
+def test_trainer_with_steplr_and_fused_optimizer():
+    """FusedClipSGD is a torch.optim.Optimizer: the reference's schedule (src/train.py:36 StepLR, stepped once per epoch at
+    src/engine/trainer.py:67) drives its learning rate, Trainer clips exactly once (inside the fused launch), and two epochs through
+    ``Trainer`` equal the same two epochs driven by clip_grad_norm_ + torch.optim.SGD + StepLR.  Also: a parameter whose storage is
+    replaced after the first step rebuilds the descriptor table (no write through a stale pointer)."""
+    from squeezedet_pytorch_amd.trainer import FusedClipSGD, Trainer
+    size = (64, 96)
+    cfg, ma, sd = _train_model('squeezedet', size)
+    _, mb, _ = _train_model('squeezedet', size)
+    cfg.num_iters, cfg.print_interval = -1, 1000
+    x = synthetic.make_images(2, size, seed=3)
+    gt = synthetic.make_gt(2, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3)
+    loader = [{'image': x, 'gt': gt}, {'image': x.flip(0), 'gt': gt.flip(0)}]
+    fo = FusedClipSGD(ma.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=cfg.grad_norm, flat_grad=lambda: ma.base.last_grad_flat)
+    fs = torch.optim.lr_scheduler.StepLR(fo, 1, 0.5)               # raises TypeError on a non-Optimizer
+    to = torch.optim.SGD(mb.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    ts = torch.optim.lr_scheduler.StepLR(to, 1, 0.5)
+    ta, tb = Trainer(ma, fo, fs, cfg), Trainer(mb, to, ts, cfg)
+    for epoch in range(2):
+        ra, rb = ta.train_epoch(epoch, loader), tb.train_epoch(epoch, loader)
+        assert abs(ra['loss'] - rb['loss']) <= 1e-5 * abs(rb['loss'])
+        assert fo.param_groups[0]['lr'] == to.param_groups[0]['lr'] == 0.02 * 0.5 ** (epoch + 1)
+        for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
+            assert torch.allclose(p, q, rtol=2e-5, atol=1e-7), (epoch, n, float((p - q).abs().max()))
+    sd1 = fo.state_dict()
+    assert sd1['lr'] == 0.005 and sd1['initial_lr'] == 0.02
+    # storage replaced behind the optimizer's back: the table must follow (same update as torch on the new storage)
+    key0 = fo._table_key
+    with torch.no_grad():
+        for p, q in zip(ma.parameters(), mb.parameters()):
+            p.data = p.data.clone()
+    la, _ = ma({'image': x.cuda(), 'gt': gt.cuda()}); fo.zero_grad(); la.mean().backward(); fo.step()
+    lb, _ = mb({'image': x.cuda(), 'gt': gt.cuda()}); to.zero_grad(); lb.mean().backward()
+    torch.nn.utils.clip_grad_norm_(mb.parameters(), cfg.grad_norm); to.step()
+    assert fo._table_key != key0
+    for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.allclose(p, q, rtol=2e-5, atol=1e-7), n
