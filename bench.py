@@ -35,7 +35,7 @@ FWD_GFLOP_PER_IMAGE = {'squeezedet': 10.566, 'squeezedetplus': 83.386}   # SURVE
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=100, help='timed steps (default 100: a >= 160 ms window; the driver passes its own K)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=0, help='images per GPU per step (default 20; 16 for squeezedetplus)')
     ap.add_argument('--mode', default='both', choices=['both', 'infer', 'train'],
@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
     ap.add_argument('--layers', action='store_true', help='add per-layer (kernel, shape) event times to the line')
     ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even at N=1 (exercises the RCCL path on one GPU)')
+    ap.add_argument('--no-pipeline', action='store_true', help='skip the end-to-end leg (pinned uint8 -> H2D -> preprocess -> net -> detect -> D2H)')
     return ap.parse_args()
 
 
@@ -86,29 +87,56 @@ def spawn_ranks(args):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU leg (rank 0, N = 1 only): the oracle as reported baseline AND as the checker of the step that was just timed
 # ------------------------------------------------------------------------------------------------------------------
+def physical_cores():
+    """(physical cores, logical CPUs) of the host: distinct thread-sibling sets in sysfs (falls back to the logical count)."""
+    import glob
+    logical = os.cpu_count() or 1
+    sib = set()
+    for f in glob.glob('/sys/devices/system/cpu/cpu[0-9]*/topology/thread_siblings_list'):
+        try:
+            with open(f) as fh:
+                sib.add(fh.read().strip())
+        except OSError:
+            pass
+    return (len(sib) if sib else logical), logical
+
+
 def cpu_baseline_and_parity(cfg, sd, batch, hip_pred, hip_det, train_probe, seconds_budget=25.0):
     """The oracle (CPU restatement of the reference, kind='port') on the host cores, on a bounded sample of the same
-    workload: whole inference path for `batch` images.  Its first pass doubles as the parity check of the timed step:
-    ``hip_pred`` [B,A,8] / ``hip_det`` (count, class_ids, scores, boxes, anchor_idx) are the HIP outputs for the same
-    batch; ``train_probe`` = (gt, hip eval-mode loss vector before the first optimizer step) or None."""
+    workload: the whole inference path (backbone + decode + top-64 / class-wise NMS / threshold) at
+    bs=`batch` and bs=1, with all usable threads and with 1 thread.  Its first pass (bs=`batch`, all threads) doubles as the
+    parity check of the timed step: ``hip_pred`` [B,A,8] / ``hip_det`` (count, class_ids, scores, boxes, anchor_idx) are the
+    HIP outputs for the same batch; ``train_probe`` = (gt, hip eval-mode loss vector before the first optimizer step) or None."""
     import numpy as np
     import torch
     import oracle
     from squeezedet_pytorch_amd import synthetic
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    cores, logical = physical_cores()
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = logical
+    try:                                               # a container's CPU quota (cgroup v2): quota / period CPUs
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            q, per = fh.read().split()[:2]
+        if q != 'max':
+            usable = max(1, min(usable, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    threads = max(1, min(usable, cores, 64))          # one thread per physical core this process may run on, at most 64
     torch.set_num_threads(threads)
     x = synthetic.make_images(batch, cfg.input_size, seed=0)
     keep = {}
 
-    def one():
+    def one(xs=x):
         with torch.no_grad():
-            pred = oracle.backbone_forward(x, sd, cfg.arch)
+            pred = oracle.backbone_forward(xs, sd, cfg.arch)
             ids, sc, bx = oracle.inference_head(pred, cfg.anchors, cfg.input_size, cfg.num_classes)
-        for b in range(batch):
+        for b in range(xs.shape[0]):
             oracle.filter_detections(ids[b].numpy(), sc[b].numpy(), bx[b].numpy(), cfg.keep_top_k, cfg.nms_thresh,
                                      cfg.score_thresh, cfg.num_classes)
         keep['pred'] = pred
+    t_start = time.time()
     t0 = time.time(); one(); warm = time.time() - t0
     parity = None
     if hip_pred is not None:
@@ -138,27 +166,57 @@ def cpu_baseline_and_parity(cfg, sd, batch, hip_pred, hip_det, train_probe, seco
             rel = float(((hip_loss - lo).abs() / lo.abs().clamp_min(1e-12)).max())
             parity['train_loss_max_rel_err'] = rel
             parity['ok'] = bool(parity['ok'] and rel <= 1e-4)
+
+    def timed(xs, nthreads, share, min_n=2, max_n=10):
+        """>= min_n passes over ``xs`` within ``share`` seconds (at most max_n); returns (images/sec, passes, seconds)."""
+        torch.set_num_threads(nthreads)
+        t0 = time.time(); one(xs); first = time.time() - t0        # warm-up at this shape / thread count
+        n, acc = 0, 0.0
+        while n < min_n or (acc + first < share and n < max_n):
+            t0 = time.time(); one(xs); acc += time.time() - t0; n += 1
+            if acc + first > share and n >= min_n:
+                break
+        return xs.shape[0] * n / acc, n, acc + first
+    # budget split: the headline leg (bs=batch, all threads) gets what the warm pass leaves of ~45 %; the other three share the rest
+    left = max(seconds_budget - (time.time() - t_start), 6.0)
     n, t_acc = 0, 0.0
-    while n < 3 or (t_acc + warm < seconds_budget and n < 10):
+    while n < 2 or (t_acc < 0.45 * left and n < 10):
         t0 = time.time(); one(); t_acc += time.time() - t0; n += 1
-        if t_acc + warm > seconds_budget:
-            break
-    cpu = {'value': round(batch * n / t_acc, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+    legs = {f'bs{batch}_threads{threads}': {'value': round(batch * n / t_acc, 2), 'passes': n, 'images_per_pass': batch}}
+    left = max(seconds_budget - (time.time() - t_start), 4.0)
+    v, k, _ = timed(x[:1], threads, 0.15 * left)
+    legs[f'bs1_threads{threads}'] = {'value': round(v, 2), 'passes': k, 'images_per_pass': 1}
+    v, k, _ = timed(x[:1], 1, 0.3 * left)
+    legs['bs1_threads1'] = {'value': round(v, 2), 'passes': k, 'images_per_pass': 1}
+    # bs=batch on ONE thread would take minutes: a 2-image sample of the same batch (the per-image cost of a 1-thread pass does
+    # not depend on the batch size: no parallelism to amortise)
+    sample = min(2, batch)
+    v, k, _ = timed(x[:sample], 1, 0.45 * left, min_n=1, max_n=3)
+    legs[f'bs{batch}_threads1'] = {'value': round(v, 2), 'passes': k, 'images_per_pass': sample,
+                                   'note': f'{sample}-image sample of the bs={batch} batch'}
+    torch.set_num_threads(threads)
+    cpu = {'value': legs[f'bs{batch}_threads{threads}']['value'], 'unit': 'images/sec', 'cores': cores, 'threads': threads,
+           'logical_cpus': logical, 'kind': 'port', 'legs': legs,
            'sample': f'{n} timed passes (1 warm-up) of the oracle CPU path (torch CPU fp32 backbone + numpy decode/top-k/NMS) '
-                     f'on the same bs={batch} 1248x384 synthetic batch, {threads} threads of {cores} host CPUs'}
+                     f'on the same bs={batch} 1248x384 synthetic batch, {threads} threads on a host with {cores} physical cores / '
+                     f'{logical} logical CPUs ({usable} usable by this process); legs: bs={batch} and bs=1, all threads and 1 thread '
+                     f'(BASELINE.md section 4), {time.time() - t_start:.0f} s of CPU work in total'}
     return cpu, parity
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # roofline of the dominant kernel from the per-launch HIP-event pass
 # ------------------------------------------------------------------------------------------------------------------
-def measured_traffic(kernel, launches_per_step):
+def measured_traffic(kernel, launches_per_step, mode='infer'):
     """HBM-side bytes per launch of `kernel` from the committed PMC pass (profiles/traffic.json, written by
-    scratch/traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for gfx950) -- only if that pass
-    profiled the SAME launch set (launches of this kernel per step), else None."""
+    scratch/traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for gfx950; inference entries at
+    the top level, the training step's under "train") -- only if that pass profiled the SAME launch set (launches of
+    this kernel per step), else None."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
             t = json.load(f)
+        if mode == 'train':
+            t = t['train']
         e = t[kernel]
         per_step = e.get('launches_per_step')
         if per_step is not None and int(per_step) != int(launches_per_step):
@@ -168,7 +226,7 @@ def measured_traffic(kernel, launches_per_step):
         return None
 
 
-def roofline_of(summ, ms_per_step, nprof):
+def roofline_of(summ, ms_per_step, nprof, mode='infer'):
     if not summ:
         return None, None
     dominant = max(summ.items(), key=lambda kv: kv[1]['ms'])[0]
@@ -185,7 +243,9 @@ def roofline_of(summ, ms_per_step, nprof):
         ach = bytes_per_launch / avg_s / 1e9
         roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None}
-    roof['traffic'] = measured_traffic(dominant, int(round(d['launches'])))
+    roof['traffic'] = measured_traffic(dominant, int(round(d['launches'])), mode)
+    if roof['traffic'] is not None and bytes_per_launch > 0:
+        roof['traffic_over_algorithmic'] = round(roof['traffic'] / bytes_per_launch, 3)
     if dominant.startswith('conv_wino') or dominant.startswith('conv_wgrad_wino'):
         # Winograd F(2x2,3x3): `achieved` counts the multiply-adds the MFMA pipe executes; the same launch expressed in
         # direct-form 3x3 flops (what the implicit-GEMM kernel would have to execute) is 2.25x that
@@ -325,6 +385,13 @@ def main():
                 print(f'[bench] step not captured ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
+            if dist is not None and capture:
+                # every rank replays or every rank launches eagerly: a rank whose capture failed would otherwise issue its
+                # collectives from another code path than its peers
+                ok = torch.tensor([1.0 if graph is not None else 0.0], device=dev if args.backend == 'nccl' else 'cpu')
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if float(ok.item()) < 1.0:
+                    graph = None
         run = graph.replay if graph is not None else step
         barrier()
         t0 = time.perf_counter()
@@ -355,6 +422,106 @@ def main():
 
     result = {}
     hip_pred = hip_det = train_probe = None
+
+    # ---------------- end-to-end leg (reported beside the main line, never `value`) ----------------
+    def pipeline_leg(det, model):
+        """What the reference's only published figure measures (README 117 FPS on V100: ``detect_dataset``,
+        src/engine/detector.py:52-85 = data loading + network + per-image NMS + D2H), minus disk and JPEG decode: per batch a
+        pinned uint8 HWC buffer of B KITTI-sized (375x1242) images -> H2D on a copy stream -> ``preprocess_kernel`` (whiten +
+        cv2-style bilinear resize + CHW) -> backbone -> fused detect -> D2H of the compact results into pinned memory.  Two slots:
+        batch i+1 uploads while batch i computes.  Timed like the main leg (barrier + synchronize both sides, K batches)."""
+        import ctypes
+        import numpy as np
+        from squeezedet_pytorch_amd import _native as nat
+        from squeezedet_pytorch_amd.preprocess import KITTI_RGB_MEAN, KITTI_RGB_STD
+        H0, W0 = 375, 1242
+        Hn, Wn = cfg.input_size
+        per = H0 * W0 * 3
+        total = B * per
+        rs = np.random.RandomState(7 + rank)
+        mean = (ctypes.c_float * 3)(*KITTI_RGB_MEAN.tolist()); std = (ctypes.c_float * 3)(*KITTI_RGB_STD.tolist())
+        d_off = (torch.arange(B, dtype=torch.int64) * per).to(dev)
+        d_sizes = torch.tensor([[H0, W0]] * B, dtype=torch.int32).to(dev)
+        copy_stream, comp = torch.cuda.Stream(), torch.cuda.current_stream()
+        K = cfg.keep_top_k
+        slots = []
+        for _ in range(2):
+            host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+            host.numpy()[:] = rs.randint(0, 256, total, dtype=np.uint8)
+            out = ops._det_buffers(B, K, dev, cfg.num_anchors)
+            slots.append(dict(host=host, src=torch.empty(total, dtype=torch.uint8, device=dev),
+                              img=torch.empty(B, 3, Hn, Wn, device=dev), sc=torch.empty(B, 2, device=dev), out=out,
+                              res=[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out[:5]],
+                              uploaded=torch.cuda.Event(), consumed=torch.cuda.Event(), done=torch.cuda.Event(), graph=None))
+        d2h_bytes = sum(t.numel() * t.element_size() for t in slots[0]['res'])
+
+        def compute(sl):
+            rc = nat.lib().sqd_preprocess_u8_fwd(nat.ptr(sl['src']), nat.ptr(d_off), nat.ptr(d_sizes), nat.ptr(sl['img']), nat.ptr(sl['sc']),
+                                                 mean, std, B, Hn, Wn, nat.stream_handle(dev))
+            nat.check(rc, 'sqd_preprocess_u8_fwd')
+            det.detect_device(sl['img'], scales=sl['sc'], out=sl['out'])
+
+        def upload(sl):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(sl['consumed'])            # the previous batch in this slot has been pre-processed
+                sl['src'].copy_(sl['host'], non_blocking=True)
+                sl['uploaded'].record(copy_stream)
+
+        def one(i):
+            sl = slots[i & 1]
+            comp.wait_event(sl['uploaded'])
+            if sl['graph'] is not None:
+                sl['graph'].replay()
+            else:
+                compute(sl)
+            sl['consumed'].record(comp)
+            upload(slots[(i + 1) & 1])                           # next batch's upload overlaps this batch's compute
+            for t, r in zip(sl['out'][:5], sl['res']):
+                r.copy_(t, non_blocking=True)                    # compact results -> pinned host memory (same stream: after detect)
+            sl['done'].record(comp)
+        for sl in slots:
+            sl['consumed'].record(comp)
+        upload(slots[0])
+        for i in range(4):
+            one(i)
+        torch.cuda.synchronize()
+        how = 'eager launches'
+        if not args.no_graph:
+            try:
+                side = torch.cuda.Stream()
+                for sl in slots:
+                    side.wait_stream(comp)
+                    with torch.cuda.stream(side):
+                        g = torch.cuda.CUDAGraph()
+                        mode = {'capture_error_mode': 'thread_local'} if dist is not None else {}
+                        with torch.cuda.graph(g, stream=side, **mode):
+                            compute(sl)
+                    comp.wait_stream(side)
+                    sl['graph'] = g
+                how = 'hipGraph replay of preprocess + net + detect per slot; copies eager on their streams'
+            except Exception as e:  # noqa: BLE001
+                print(f'[bench] pipeline step not captured ({type(e).__name__}: {e}); eager launches', file=sys.stderr)
+                for sl in slots:
+                    sl['graph'] = None
+            torch.cuda.synchronize()
+        for i in range(4):
+            one(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one(i)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        ms = elapsed / args.steps * 1e3
+        # sanity: the last batch's results arrived on the host and agree with the device buffers
+        last = slots[(args.steps - 1) & 1]
+        ok = all(bool(torch.equal(r, t.cpu())) for t, r in zip(last['out'][:5], last['res']))
+        return {'value': round(B * joined * args.steps / elapsed, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4),
+                'h2d_bytes_per_step': total, 'd2h_bytes_per_step': d2h_bytes,
+                'pcie_h2d_gbs_implied': round(total / (ms / 1e3) / 1e9, 2), 'timed_with': how, 'results_on_host_ok': ok,
+                'what': f'per batch: pinned uint8 {B}x{H0}x{W0}x3 -> H2D (copy stream) -> preprocess_kernel -> backbone -> fused detect -> '
+                        f'D2H of (count, class_ids, scores, boxes, anchor_idx) into pinned memory; two slots, upload of batch i+1 '
+                        f'overlaps compute of batch i; excludes disk read and JPEG decode; NOT part of `value`'}
 
     # ---------------- inference ----------------
     def bench_infer():
@@ -388,6 +555,13 @@ def main():
                               'frac_of_fp32_mfma_peak': round(value / joined * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                               'note': 'direct-form flops of the network; layers run by the Winograd kernel execute 2.25x fewer'},
         }
+        if not args.no_pipeline and args.arch == 'squeezedet':
+            try:
+                result['infer']['pipeline'] = pipeline_leg(det, model)
+            except Exception as e:  # noqa: BLE001 -- the end-to-end leg is a reported extra: its failure must not cost the main line
+                print(f'[bench] pipeline leg failed ({type(e).__name__}: {e})', file=sys.stderr)
+                result['infer']['pipeline'] = None
+                torch.cuda.synchronize()
         if rank == 0 and joined == 1 and not args.no_cpu_baseline:
             # outputs of the step that was timed, for the parity check of the CPU leg: the detections the last replay left
             # in out_bufs, and pred from one more (bitwise identical: tests/test_headline_gpu.py) eager backbone pass
@@ -408,13 +582,21 @@ def main():
     def bench_train():
         nonlocal train_probe
         from squeezedet_pytorch_amd.trainer import make_train_step
-        step, describe, probe = make_train_step(cfg, sd, x, rank, joined, dist, force_exchange=args.force_dist)
+        step_parts = {}
+        step, describe, probe = make_train_step(cfg, sd, x, rank, joined, dist, force_exchange=args.force_dist, parts=step_parts)
         if rank == 0 and joined == 1 and not args.no_cpu_baseline and args.mode == 'both':
             train_probe = probe()                    # (gt, eval-mode loss of the initial weights), before any optimizer step
-        # one GPU: the whole step (fwd, loss, bwd, clip, SGD, weight re-pack) replays as a hipGraph; with an RCCL
-        # all-reduce inside the step (N > 1) it stays eager
+        # the whole step (fwd, loss, bwd, gradient exchange, clip, SGD, weight re-pack) replays as a hipGraph: RCCL collectives
+        # issued through torch.distributed are capturable (the bucketed all-reduces on the side stream fork from and join the
+        # capturing stream); a gloo group copies through the host and stays eager
+        eager_steps = [0]
+        inner = step
+
+        def step():
+            eager_steps[0] += 1
+            return inner()
         try:
-            elapsed, repeat, how, run = measure(step, capture=(joined == 1 and dist is None))
+            elapsed, repeat, how, run = measure(step, capture=(dist is None or args.backend == 'nccl'))
         except Exception as e:  # noqa: BLE001
             print(f'[bench] training step not captured ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
             torch.cuda.synchronize()
@@ -422,10 +604,24 @@ def main():
             elapsed, repeat, how, run = measure(step, capture=False)
         summ, nprof = event_profile(step, run, nprof=3)
         ms = elapsed / args.steps * 1e3
-        roof, kernels = roofline_of(summ, ms, nprof)
+        roof, kernels = roofline_of(summ, ms, nprof, mode='train')
+        if os.environ.get('SQD_EXCHANGE_TRACE'):
+            # diagnostics: host wall time of single synchronized eager steps, the time the host spent inside the gradient
+            # exchange's calls, and the sum of the kernels' own HIP-event times -- where does a slow step spend its time?
+            from squeezedet_pytorch_amd.trainer import find_base
+            for k in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter(); inner(); t_enq = time.perf_counter() - t0
+                torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+                print(f'[bench trace r{rank}] eager training step {k}: host enqueue {t_enq * 1e3:.1f} ms, until GPU idle {t_all * 1e3:.1f} ms; '
+                      f'kernel event sum {sum(v["ms"] for v in summ.values()):.2f} ms', file=sys.stderr)
+            tr = getattr(getattr(step_parts.get('base'), 'grad_sync', None), 'trace', None)
+            if tr:
+                print(f'[bench trace r{rank}] gradient exchange host time, last step: ' + ', '.join(f'{n} {t * 1e3:.2f} ms' for n, t in tr[-4:]), file=sys.stderr)
         result['train'] = {
             'value': round(B * joined * args.steps / elapsed, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4), 'timed_with': how,
             'repeat_window_ms_per_step': round(repeat / args.steps * 1e3, 4),
+            'eager_steps_launched': eager_steps[0],
             'workload': describe, 'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
             'layers': {f'{k} | {tag}': round(t[1] * 1e3, 1) for k, v in summ.items() for tag, t in v['tags'].items()},
         }
@@ -435,6 +631,8 @@ def main():
     # replay phase at 95..1500 ms instead of 20 ms (hardware-queue oversubscription of the shared GPU); on one rank per GPU the
     # order made no difference, so the safe order is used whenever ranks communicate.
     order = ('train', 'infer') if dist is not None else ('infer', 'train')
+    if os.environ.get('SQD_BENCH_ORDER'):              # diagnostics: force the order of the two halves ("infer,train")
+        order = tuple(os.environ['SQD_BENCH_ORDER'].split(','))
     for half in order:
         if half == 'infer' and args.mode in ('both', 'infer'):
             bench_infer()
@@ -463,6 +661,8 @@ def main():
         }
         if 'eager_steps_launched' in head:
             line['eager_steps_launched'] = head['eager_steps_launched']
+        if head.get('pipeline') is not None:
+            line['pipeline'] = head['pipeline']
         if args.layers:
             line['layers'] = layer_detail
         if args.mode == 'both':

@@ -1,10 +1,13 @@
-"""The launch plan of one inference step, computed on the host WITHOUT a GPU: which kernel instance (tile
-configuration from the measured table ``tuning.json``) every layer of ``SqueezeDetBase.forward`` + the fused detect
-launches for a given architecture / batch / input size.  It mirrors the decisions of ``autograd.run_backbone_forward``
-(a GPU test asserts the two agree launch for launch) and exists so that profiles can be checked against the code that
-shipped: ``profiles/traffic.json`` records the launch set it was measured on, and a CPU test recomputes that set here.
+"""The launch plan of one inference or training step, computed on the host WITHOUT a GPU: which kernel instance (tile
+configuration from the measured table ``tuning.json``) every layer launches for a given architecture / batch / input
+size.  ``inference_launch_plan`` mirrors the decisions of ``autograd.run_backbone_forward`` + the fused detect launch,
+``training_launch_plan`` those of the saving forward, ``LossFn`` and ``backward.run_backbone_backward``; GPU tests assert
+both agree with the real launches name for name and shape for shape (tests/test_surface_gpu.py), for the default and for
+non-default model flags.  They exist so that profiles can be checked against the code that shipped:
+``profiles/traffic.json`` records the launch set it was measured on (inference at top level, training under ``"train"``)
+and a CPU test recomputes that set here.
 
-Reference for the layer sequence: src/model/squeezedet.py:33-87, src/engine/detector.py:20-50.
+Reference for the layer sequence: src/model/squeezedet.py:33-87, src/engine/detector.py:20-50, src/engine/trainer.py:42-50.
 """
 from __future__ import annotations
 
@@ -14,9 +17,23 @@ from . import ops
 from .synthetic import convdet_in_channels, layer_table
 
 
+def _conv3x3(batch, H, W, Cin, N, use_winograd):
+    npix = batch * H * W
+    wc = ops.choose_wino_cfg(Cin, N, npix) if use_winograd else None
+    if wc is not None:
+        return (ops.wino_kernel_name(wc), f'9tap C{Cin} N{N} {H}x{W}')
+    return (ops.cfg_kernel_name(ops.choose_cfg(9, Cin, N, npix)), f'9tap C{Cin} N{N} {H}x{W}')
+
+
+def _conv1x1(batch, H, W, Cin, N):
+    return (ops.cfg_kernel_name(ops.choose_cfg(1, Cin, N, batch * H * W)), f'1tap C{Cin} N{N} {H}x{W}')
+
+
 def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
-                          use_winograd=True, fuse_expand=True, fuse_fire_bridge=True):
-    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order."""
+                          use_winograd=True, fuse_expand=True, fuse_fire_bridge=True, fuse_expand_wino=True,
+                          fuse_pool_squeeze=False):
+    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order.  The five switches are
+    ``SqueezeDetBase``'s attributes of the same names, one to one."""
     layers = layer_table(arch)
     H, W = ops.stem_out_size(input_size[0], input_size[1], layers[0][3])
     C = layers[0][2]
@@ -29,25 +46,29 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
     else:
         plan.append((f'stem_conv<{layers[0][3]}>', f'stem {input_size[0]}x{input_size[1]}'))
 
-    def conv3x3(Cin, N):
-        npix = batch * H * W
-        wc = ops.choose_wino_cfg(Cin, N, npix) if use_winograd else None
-        if wc is not None:
-            return (ops.wino_kernel_name(wc), f'9tap C{Cin} N{N} {H}x{W}')
-        return (ops.cfg_kernel_name(ops.choose_cfg(9, Cin, N, npix)), f'9tap C{Cin} N{N} {H}x{W}')
-
     bridged = False
+    unpooled = None                        # (H, W) of the un-pooled map when the pool is folded into the next squeeze
     for i in range(first, len(layers)):
         l = layers[i]
         if l[0] == 'pool':
-            if not bridged:
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            if bridged:
+                pass
+            elif fuse_pool_squeeze and nxt is not None and nxt[0] == 'fire' and ops.pool_squeeze_ok(C, nxt[2]):
+                unpooled = (H, W)
+            else:
                 plan.append(('maxpool_fwd', f'pool C{C} {H}x{W}'))
             H, W = ops.pool_out_size(H, W)
             continue
         _, cin, s, e1, e3 = l
         npix = batch * H * W
-        if not bridged:
-            plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, cin, s, npix)), f'1tap C{cin} N{s} {H}x{W}'))
+        if bridged:
+            pass
+        elif unpooled is not None:
+            plan.append(('pool_squeeze', f'pool+squeeze C{cin} N{s} {unpooled[0]}x{unpooled[1]}'))
+            unpooled = None
+        else:
+            plan.append(_conv1x1(batch, H, W, cin, s))
         bridged = False
         C = e1 + e3
         nxt = layers[i + 1] if i + 1 < len(layers) else None
@@ -62,17 +83,96 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
                 plan.append(('fire_bridge', f'fire C{s} E{e1}+{e3} -> S{nxt[2]} {H}x{W}'))
                 bridged = True
                 continue
-        xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fuse_expand and use_winograd) else None
+        xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fuse_expand_wino and use_winograd) else None
         fcfg = ops.choose_fused_cfg(s, e1, npix) if (xcfg is None and fuse_expand and e1 == e3) else None
         if xcfg is not None:
             plan.append((ops.fire_wino_kernel_name(xcfg), f'fire C{s} E{e1}+{e3} {H}x{W}'))
         elif fcfg is not None:
             plan.append((ops.cfg_kernel_name(fcfg).replace('conv_dma', 'fire_expand'), f'expand C{s} E{e1} {H}x{W}'))
         else:
-            plan.append((ops.cfg_kernel_name(ops.choose_cfg(1, s, e1, npix)), f'1tap C{s} N{e1} {H}x{W}'))
-            plan.append(conv3x3(s, e3))
-    plan.append(conv3x3(convdet_in_channels(arch), anchors_per_grid * (num_classes + 5)))
+            plan.append(_conv1x1(batch, H, W, s, e1))
+            plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
+    plan.append(_conv3x3(batch, H, W, convdet_in_channels(arch), anchors_per_grid * (num_classes + 5), use_winograd))
     plan.append(('detect', f'detect A{H * W * anchors_per_grid}'))
+    return plan
+
+
+def _wgrad(batch, H, W, N, C, taps):
+    if ops.wgrad_uses_wino(N, C, taps, batch, H, W):
+        return ('conv_wgrad_wino', f'wgrad 9tap C{C} N{N} {H}x{W}')
+    return (f'conv_wgrad<{taps}>', f'wgrad {taps}tap C{C} N{N} {H}x{W}')
+
+
+def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
+                         use_winograd=True, data_parallel_stages=False):
+    """Launches of one training iteration's forward (activations saved, no inference-only fusion: ``autograd.py`` gates
+    the bridges and fused expands on ``not save``), multi-task loss forward / backward and the backbone backward, as
+    (kernel name, shape tag) in launch order.  The optimizer launch and torch's own elementwise kernels (dropout mask,
+    ``loss.mean()``) are not KernelTimer-bracketed and not listed.  ``data_parallel_stages``: with a gradient exchange
+    attached the slab reduction runs once per backward stage instead of once at the end."""
+    layers = layer_table(arch)
+    ks = layers[0][3]
+    H, W = ops.stem_out_size(input_size[0], input_size[1], ks)
+    C = layers[0][2]
+    plan = []
+    fused_stem = layers[2][0] == 'pool'
+    first = 2
+    if fused_stem:
+        plan.append((f'stem_pool<{ks}>', f'stem+pool {input_size[0]}x{input_size[1]}'))
+        H, W = ops.pool_out_size(H, W)
+        first = 3
+    else:
+        plan.append((f'stem_conv<{ks}>', f'stem {input_size[0]}x{input_size[1]}'))
+    geo = {}                                            # layer index -> (H, W, C_in) at its input
+    for i in range(first, len(layers)):
+        l = layers[i]
+        geo[i] = (H, W, C)
+        if l[0] == 'pool':
+            plan.append(('maxpool_fwd', f'pool C{C} {H}x{W}'))
+            H, W = ops.pool_out_size(H, W)
+            continue
+        _, cin, s, e1, e3 = l
+        plan.append(_conv1x1(batch, H, W, cin, s))
+        plan.append(_conv1x1(batch, H, W, s, e1))
+        plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
+        C = e1 + e3
+    ncd = anchors_per_grid * (num_classes + 5)
+    ccd = convdet_in_channels(arch)
+    plan.append(_conv3x3(batch, H, W, ccd, ncd, use_winograd))
+    A = H * W * anchors_per_grid
+    plan.append(('loss_fwd', f'loss A{A}'))
+    plan.append(('loss_bwd', f'lossbwd A{A}'))
+    # ---- backward (backward.run_backbone_backward) ----
+    plan.append(_wgrad(batch, H, W, ncd, ccd, 9))
+    plan.append(_conv3x3(batch, H, W, ncd, ccd, use_winograd))                       # ConvDet data gradient
+    rows_total, rows_done = 1, 0                       # slab-reduction records: ConvDet, then 3 per Fire in backward order
+    last = len(layers) - 1
+    for i in range(last, 1, -1):
+        l = layers[i]
+        Hi, Wi, Ci = geo[i] if i in geo else (None, None, None)
+        if l[0] == 'pool':
+            if data_parallel_stages and rows_total > rows_done:         # a stage of the backward is complete: its bucket goes out
+                plan.append(('wgrad_reduce_batched', f'{rows_total - rows_done} layers'))
+                rows_done = rows_total
+            if i == 2 and fused_stem:
+                continue
+            plan.append(('maxpool_bwd', f'poolbwd C{Ci} {Hi}x{Wi}'))
+            continue
+        _, cin, s, e1, e3 = l
+        plan.append(_wgrad(batch, Hi, Wi, e1, s, 1))
+        plan.append(_wgrad(batch, Hi, Wi, e3, s, 9))
+        plan.append(_conv1x1(batch, Hi, Wi, e1, s))                                   # expand1x1 data gradient
+        plan.append(_conv3x3(batch, Hi, Wi, e3, s, use_winograd))                     # expand3x3 data gradient (accumulates)
+        plan.append(_wgrad(batch, Hi, Wi, s, cin, 1))
+        plan.append(_conv1x1(batch, Hi, Wi, s, cin))                                  # squeeze data gradient
+        rows_total += 3
+    Hs, Ws = input_size
+    if fused_stem:
+        plan.append((f'stem_wgrad_pooled<{ks}>', f'stem wgrad (pooled) {Hs}x{Ws}'))
+    else:
+        plan.append((f'stem_wgrad<{ks}>', f'stem wgrad {Hs}x{Ws}'))
+    if rows_total > rows_done:
+        plan.append(('wgrad_reduce_batched', f'{rows_total - rows_done} layers'))
     return plan
 
 

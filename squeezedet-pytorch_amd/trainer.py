@@ -54,6 +54,9 @@ class GradientExchange:
         self._flat = None
         self._pending = []
         self.buckets_last_step = []            # [(lo, hi)] of the latest backward, for tests / logging
+        # diagnostics (SQD_EXCHANGE_TRACE=1): host wall time spent inside ready() / finish() per step, [(name, seconds)]
+        import os
+        self.trace = [] if os.environ.get('SQD_EXCHANGE_TRACE') else None
 
     def world(self):
         d = _dist()
@@ -72,6 +75,7 @@ class GradientExchange:
     def ready(self, lo, hi):
         if not self._active or hi <= lo:
             return
+        t_in = time.perf_counter() if self.trace is not None else 0.0
         d = _dist()
         if hi == self._total:
             hi = self._flat.numel()             # the count slot travels with the tail bucket
@@ -88,12 +92,17 @@ class GradientExchange:
             self._flat[lo:grad_hi].mul_(self._b)
             work = d.all_reduce(self._flat[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append(work)
+        if self.trace is not None:
+            self.trace.append((f'ready[{lo}:{hi}]', time.perf_counter() - t_in))
 
     def finish(self):
         if not self._active:
             return
+        t_in = time.perf_counter() if self.trace is not None else 0.0
         for w in self._pending:
             w.wait()                            # CUDA: the current stream waits for the collective; CPU: blocks
+        if self.trace is not None:
+            self.trace.append(('finish.wait', time.perf_counter() - t_in))
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._pending = []
@@ -445,7 +454,7 @@ class FusedClipSGD(torch.optim.Optimizer):
             g['initial_lr'] = float(sd['initial_lr'])
 
 
-def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1, force_exchange=False, fused_optimizer=True):
+def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1, force_exchange=False, fused_optimizer=True, parts=None):
     """Benchmark helper: returns (step_fn, description, probe_fn).  A step = fwd + loss + bwd (with the bucketed RCCL
     gradient exchange when a process group exists) + clip_grad_norm_(5.0) + SGD(lr .01, momentum .9, wd 1e-4) on a
     device-resident batch.  ``probe_fn()`` -> (gt on the CPU, eval-mode per-image loss of the current weights on the CPU):
@@ -468,6 +477,8 @@ def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1, force_
     ex = attach_data_parallel(model, opt) if dist is not None else None
     if ex is not None:
         ex.force = bool(force_exchange)
+    if parts is not None:                            # (bench.py diagnostics: the objects behind the closure)
+        parts.update(model=model, optimizer=opt, base=find_base(model), exchange=ex)
 
     def step():
         loss, stats = model(batch)

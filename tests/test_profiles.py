@@ -51,3 +51,25 @@ def test_launch_plan_bridges_follow_the_table_rows():
     assert 'fire_bridge' not in names and 'fire_pool_bridge' not in names
     assert ops.fire_pool_bridge_ok(16, 64, 64, 32) and not ops.fire_pool_bridge_ok(32, 128, 128, 48)
     assert ops.fire_bridge_cfg_ok(12, 16, 64, 64, 16) and not ops.fire_bridge_cfg_ok(12, 32, 128, 128, 32)
+
+
+def test_training_traffic_profile_matches_shipped_launch_set():
+    """The same tie for the TRAINING half (``train.roofline.traffic`` of bench.py's line): the "train" section of profiles/traffic.json
+    was measured on the launch set plan.training_launch_plan computes from the shipped table (the plan itself is asserted equal
+    to the real launches by tests/test_surface_gpu.py::test_training_launch_plan_equals_real_launches)."""
+    from squeezedet_pytorch_amd import plan
+    with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+        prof = json.load(f)
+    assert 'train' in prof, 'profiles/traffic.json has no training section (scratch/traffic.sh <tag> "infer train")'
+    tr = prof['train']
+    assert '_meta' in tr and 'bs=20' in tr['_meta']['workload'] and '--mode train' in tr['_meta']['workload']
+    want = plan.launches_per_kernel(plan.training_launch_plan('squeezedet', 20, (384, 1248)))
+    skip = ('loss_fwd', 'loss_bwd')             # (two kernels each: listed under their own kernel names in the profile)
+    for kernel, n in want.items():
+        if kernel in skip:
+            continue
+        assert kernel in tr, f'{kernel}: launched by the shipped training plan but absent from the profile'
+        assert tr[kernel].get('launches_per_step') == n, (kernel, tr[kernel].get('launches_per_step'), n)
+    for kernel in tr:
+        if kernel.startswith(('conv_', 'fire_', 'stem_', 'maxpool', 'wgrad_reduce_batched')):
+            assert kernel in want, f'{kernel}: in the training profile but not launched by the shipped plan'

@@ -114,3 +114,95 @@ def test_bench_rccl_path_single_rank():
     flat gradient buffer on the side stream, barrier + max-over-ranks timing -- in a one-rank group."""
     line = _run_bench('--gpus', '1', '--force-dist', '--mode', 'train', '--steps', '3', '--warmup', '2')
     assert line['n_gpus'] == 1 and 'RCCL' in line['config']['workload'] and line['value'] > 0
+
+
+def test_bench_gloo_world4_training_rehearsal():
+    """More ranks than two without an 8-GPU node: four gloo ranks share this box's one GPU (the box admits at most six GPU
+    processes) and run the real HIP backward with the bucketed, count-weighted exchange; the line counts four ranks and a
+    global batch of 16."""
+    line = _run_bench('--gpus', '4', '--backend', 'gloo', '--mode', 'train', '--steps', '2', '--warmup', '1', '--batch', '4',
+                      '--no-cpu-baseline')
+    assert line['n_gpus'] == 4 and line['config']['global_batch'] == 16 and line['value'] > 0
+    assert 'bucket' in line['config']['workload']
+
+
+def test_bench_rccl_training_step_is_captured():
+    """With an RCCL process group the training step -- collectives included -- is timed as a hipGraph replay (one-rank group
+    on this box; the N > 1 run uses the same code path, every rank agreeing through an all-reduce that the capture succeeded)."""
+    line = _run_bench('--gpus', '1', '--force-dist', '--mode', 'train', '--steps', '3', '--warmup', '2')
+    assert line['timed_with'] == 'hipGraph replay', line['timed_with']
+
+
+def test_bench_default_line_has_pipeline_and_cpu_legs():
+    """The default line carries the end-to-end leg (pinned uint8 -> H2D -> preprocess -> net -> detect -> D2H, never `value`) and
+    the four CPU-baseline legs of BASELINE.md section 4."""
+    line = _run_bench('--steps', '10', '--warmup', '3', '--mode', 'infer')
+    pl = line['pipeline']
+    assert pl['value'] > 0 and pl['results_on_host_ok'] and pl['h2d_bytes_per_step'] == 20 * 375 * 1242 * 3
+    assert line['value'] >= pl['value'] * 0.5              # same kernels: the end-to-end rate is of the same order as the resident one
+    cb = line['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['threads'] >= 1 and cb['cores'] >= 1
+    legs = cb['legs']
+    assert {k.split('_')[0] for k in legs} == {'bs1', 'bs20'} and len(legs) == 4
+    assert all(v['value'] > 0 for v in legs.values())
+    assert line['parity']['ok']
+
+
+@pytest.mark.parametrize("flags", [{}, {'fuse_fire_bridge': False}, {'fuse_fire_bridge': False, 'fuse_expand_wino': False},
+                                   {'fuse_fire_bridge': False, 'fuse_expand': False, 'fuse_expand_wino': False},
+                                   {'fuse_fire_bridge': False, 'fuse_pool_squeeze': True}, {'use_winograd': False}])
+def test_inference_launch_plan_equals_real_launches(flags):
+    """plan.inference_launch_plan (host only; what tests/test_profiles.py checks profiles/traffic.json against) lists exactly
+    the launches the model issues -- kernel name and shape tag, in order -- for the default flags and for non-default ones."""
+    from squeezedet_pytorch_amd import ops, plan
+    from squeezedet_pytorch_amd.detector import Detector
+    from squeezedet_pytorch_amd.model import SqueezeDet
+    cfg = sqd.make_cfg(device='cuda')
+    m = SqueezeDet(cfg)
+    m.load_state_dict(synthetic.make_state_dict('squeezedet', seed=1234))
+    det = Detector(m, cfg)
+    for k, v in flags.items():
+        assert hasattr(m.base, k), k
+        setattr(m.base, k, v)
+    x = synthetic.make_images(20, (384, 1248), seed=0).cuda()
+    det.detect_device(x)                                       # packs happen here, outside the bracketed pass
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    try:
+        det.detect_device(x)
+    finally:
+        ops.set_timer(None)
+    torch.cuda.synchronize()
+    got = [(r[0], r[1]) for r in timer.records]
+    want = plan.inference_launch_plan('squeezedet', 20, (384, 1248), **flags)
+    assert got == want, [(a, b) for a, b in zip(got, want) if a != b][:4]
+
+
+@pytest.mark.parametrize("arch,bs", [("squeezedet", 20), ("squeezedetplus", 4)])
+def test_training_launch_plan_equals_real_launches(arch, bs):
+    """plan.training_launch_plan against the bracketed launches of one training iteration (forward with saved activations,
+    loss forward / backward, backbone backward)."""
+    from squeezedet_pytorch_amd import ops, plan
+    from squeezedet_pytorch_amd.model import SqueezeDetWithLoss
+    cfg = sqd.make_cfg(arch=arch, device='cuda')
+    m = SqueezeDetWithLoss(cfg)
+    m.load_state_dict(synthetic.make_state_dict(arch, seed=1234))
+    m = m.cuda().train()
+    batch = {'image': synthetic.make_images(bs, (384, 1248), seed=0).cuda(),
+             'gt': synthetic.make_gt(bs, cfg.anchors, (384, 1248), seed=1).cuda()}
+
+    def step():
+        loss, _ = m(batch)
+        m.zero_grad()
+        loss.mean().backward()
+    step()
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    try:
+        step()
+    finally:
+        ops.set_timer(None)
+    torch.cuda.synchronize()
+    got = [(r[0], r[1]) for r in timer.records]
+    want = plan.training_launch_plan(arch, bs, (384, 1248))
+    assert got == want, [(i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b][:4] + [len(got), len(want)]
