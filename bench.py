@@ -375,7 +375,7 @@ def main():
                     graph = torch.cuda.CUDAGraph()
                     # with a process group alive other threads of this process (the collective library's watchdog) may touch
                     # the runtime while this thread captures: only this thread's calls belong to the capture
-                    mode = {'capture_error_mode': 'thread_local'} if dist is not None else {}
+                    mode = {'capture_error_mode': 'thread_local'} if (dist is not None and not os.environ.get('SQD_BENCH_GLOBAL_CAPTURE')) else {}
                     with torch.cuda.graph(graph, stream=side, **mode):
                         step()
                 torch.cuda.current_stream().wait_stream(side)
@@ -570,9 +570,10 @@ def main():
             with torch.no_grad():
                 hip_pred = model.base(x).cpu()
             hip_det = tuple(t.cpu().numpy() for t in out_bufs[:5])
-        # release the captured step (graph exec, its memory pool, the side stream's queue) before the training half: with
-        # several ranks on ONE GPU (gloo rehearsal) a live graph exec next to the eager training step oversubscribed the
-        # hardware queues (20 -> 95..1500 ms per step); one rank per GPU never showed it, but nothing after this needs the graph
+        # release the captured step (graph exec, its memory pool) before the training half: nothing after this needs it
+        if os.environ.get('SQD_BENCH_KEEP_GRAPH'):       # diagnostics: leave the captured step alive next to the training half
+            result['_keep'] = (model, det, run)
+            return
         del model, det, run, infer_step
         import gc
         gc.collect()
@@ -583,7 +584,8 @@ def main():
         nonlocal train_probe
         from squeezedet_pytorch_amd.trainer import make_train_step
         step_parts = {}
-        step, describe, probe = make_train_step(cfg, sd, x, rank, joined, dist, force_exchange=args.force_dist, parts=step_parts)
+        step, describe, probe = make_train_step(cfg, sd, x, rank, joined, dist, force_exchange=args.force_dist, parts=step_parts,
+                                                fused_optimizer=not os.environ.get('SQD_BENCH_TORCH_SGD'))
         if rank == 0 and joined == 1 and not args.no_cpu_baseline and args.mode == 'both':
             train_probe = probe()                    # (gt, eval-mode loss of the initial weights), before any optimizer step
         # the whole step (fwd, loss, bwd, gradient exchange, clip, SGD, weight re-pack) replays as a hipGraph: RCCL collectives
@@ -626,11 +628,12 @@ def main():
             'layers': {f'{k} | {tag}': round(t[1] * 1e3, 1) for k, v in summ.items() for tag, t in v['tags'].items()},
         }
 
-    # One rank per GPU with a process group: the training half (eager, with the gradient exchange) runs FIRST, in a process
-    # that has not captured or replayed a graph yet -- a two-ranks-on-one-GPU gloo rehearsal showed eager steps behind a graph
-    # replay phase at 95..1500 ms instead of 20 ms (hardware-queue oversubscription of the shared GPU); on one rank per GPU the
-    # order made no difference, so the safe order is used whenever ranks communicate.
-    order = ('train', 'infer') if dist is not None else ('infer', 'train')
+    # Order of the two halves: inference, then training, with or without a process group.  (Round 2 ran training first when ranks
+    # communicate, after a two-ranks-on-one-GPU gloo rehearsal showed eager training steps behind the graph-replay phase at
+    # 95..1500 ms.  Round 3 isolated the trigger -- DESIGN.md section 6: torch's own clip_grad_norm_ + torch.optim.SGD launches in
+    # that situation; with the fused optimizer step this bench uses, both orders run at 16-20 ms there and inference-first is
+    # the faster one -- so the special order is gone.)
+    order = ('infer', 'train')
     if os.environ.get('SQD_BENCH_ORDER'):              # diagnostics: force the order of the two halves ("infer,train")
         order = tuple(os.environ['SQD_BENCH_ORDER'].split(','))
     for half in order:
@@ -643,6 +646,7 @@ def main():
         cpu = parity = None
         if joined == 1 and not args.no_cpu_baseline and args.mode != 'train':
             cpu, parity = cpu_baseline_and_parity(cfg, sd, B, hip_pred, hip_det, train_probe)
+        result.pop('_keep', None)
         layer_detail = {m: r.pop('layers', None) for m, r in result.items()}
         head = result['infer'] if 'infer' in result else result['train']
         what = 'inference' if 'infer' in result else 'training'
