@@ -58,6 +58,15 @@ int sqd_pack_conv_weights_batched(const void* descs_dev, int n, int blocks_per_d
 int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
                    int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int taps, int S,
                    void* stream);
+/* A Fire squeeze's whole backward in ONE launch (autograd of Fire.squeeze + squeeze_activation, src/model/squeezedet.py:12,19,
+ * as triggered by loss.backward(), src/engine/trainer.py:47): the weight / bias gradient slabs of sqd_conv_wgrad (taps = 1,
+ * partial slabs only: reduce with sqd_wgrad_reduce_batched) and the data gradient
+ * dx[p][dx_coff + c] = sum_n dy[p][dy_coff + n] * w[n][c], zeroed where relu_mask != 0 and x[p][x_coff + c] <= 0 (x = the
+ * squeeze's forward input when that is a ReLU output).  w_oihw: the layer's own [N][C][1][1] parameter.  N <= 96.
+ * S pixel-splits as in sqd_conv_wgrad with 64-channel in-tiles: slab = S * (N*C + N) floats. */
+int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_oihw, float* slab, float* dx, int B, int H, int W,
+                    int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int dx_pitch, int dx_coff,
+                    int relu_mask, int S, void* stream);
 /* Winograd F(2x2,3x3) form of sqd_conv_wgrad for the 3x3 layers (Fire expand3x3, src/model/squeezedet.py:14; autograd of
  * nn.Conv2d as triggered by loss.backward(), src/engine/trainer.py:47): same arguments (taps is 9), slab layout and
  * dw == NULL convention; executes 2.25x fewer multiply-adds.  Supported: (N % 64 == 0 or N <= 80) and S <= B * ceil(H/4) * ceil(W/16);
@@ -84,7 +93,8 @@ int sqd_stem_wgrad(const float* dy_nhwc, const float* img_nchw, float* slab, flo
                    int B, int Hin, int Win, int N, int ksize, int S, void* stream);
 
 /* The same when the forward ran fused (sqd_stem_conv_relu_pool_fwd): the backward of ReLU + MaxPool is folded
- * into the staging.  dpool / pooled: NHWC [B][Hp][Wp][N]; argmax: the uint8 tensor written by the forward. */
+ * into the staging.  dpool: NHWC [B][Hp][Wp][N]; argmax: the uint8 tensor written by the forward, whose codes carry the
+ * ReLU mask (15 = pooled value not > 0); pooled (NHWC like dpool) may be NULL -- when given, `pooled > 0` is ANDed in. */
 int sqd_stem_wgrad_pooled(const float* dpool, const float* pooled, const unsigned char* argmax, const float* img_nchw,
                           float* slab, float* dw_oihw, float* db, int B, int Hin, int Win, int N, int ksize, int S,
                           void* stream);
@@ -100,7 +110,8 @@ int sqd_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* bia
                       int B, int Hin, int Win, int N, int ksize, int relu, void* stream);
 
 /* Fused features[0..2]: conv + ReLU + MaxPool2d(3,2,ceil_mode=True) (src/model/squeezedet.py:34-36 / :52-54)
- * without materialising the conv output.  y: NHWC [B][Hp][Wp][N]; argmax (uint8, may be NULL) as below. */
+ * without materialising the conv output.  y: NHWC [B][Hp][Wp][N]; argmax (uint8, may be NULL): window position 0..8 of
+ * the maximum, or 15 where the pooled value is 0 (the ReLU mask the backward needs, as sqd_maxpool3x3s2_ceil_fwd_relu). */
 int sqd_stem_conv_relu_pool_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
                                 unsigned char* argmax, int B, int Hin, int Win, int N, int ksize, void* stream);
 
@@ -108,7 +119,13 @@ int sqd_stem_conv_relu_pool_fwd(const float* x_nchw, const float* w_oihw, const 
  * argmax (uint8, same shape as y, may be NULL) records the window position 0..8 for the backward. */
 int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C,
                               void* stream);
-/* relu_src (may be NULL): the pool's forward input when that was a ReLU output; its mask is folded in. */
+/* The same pool when its input is a ReLU output and a backward will follow (the training forward: every pool of
+ * src/model/squeezedet.py:33-49 sits behind a ReLU, :36,:39,:42): argmax (required) additionally carries the ReLU mask of the
+ * input -- code 15 where the pooled value is not > 0 -- so the backward below needs no relu_src. */
+int sqd_maxpool3x3s2_ceil_fwd_relu(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C,
+                                   void* stream);
+/* relu_src (may be NULL): the pool's forward input when that was a ReLU output; its mask is folded in (not needed -- pass NULL --
+ * with the codes of sqd_maxpool3x3s2_ceil_fwd_relu). */
 int sqd_maxpool3x3s2_ceil_bwd(const float* dy, const unsigned char* argmax, float* dx, const float* relu_src,
                               int B, int H, int W, int C, void* stream);
 

@@ -28,8 +28,8 @@ def short_name(k):
     if m: return m.group(1)
     m = re.match(r"wino_wgrad_kernel<", short)
     if m: return "conv_wgrad_wino"
-    m = re.match(r"conv_wgrad_kernel<(\d+),", short)
-    if m: return f"conv_wgrad<{m.group(1)}>"
+    m = re.match(r"conv_wgrad_kernel<(\d+), \d+, \d+, \d+(, (true|false))?>", short)
+    if m: return "squeeze_bwd" if m.group(3) == "true" else f"conv_wgrad<{m.group(1)}>"
     m = re.match(r"stem_wgrad_pooled_kernel<(\d+),", short)
     if m: return f"stem_wgrad_pooled<{m.group(1)}>"
     if short.startswith("wgrad_reduce_batched_kernel"): return "wgrad_reduce_batched"

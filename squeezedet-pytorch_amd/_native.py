@@ -34,12 +34,14 @@ _SIGNATURES = {
     'sqd_wgrad_reduce_batched': [c_p, c_i, c_i, c_p, c_p, c_p],
     'sqd_wgrad_reduce_batched_range': [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     'sqd_conv_wgrad_wino': [c_p] * 5 + [c_i] * 11 + [c_p],
+    'sqd_squeeze_bwd': [c_p] * 5 + [c_i] * 13 + [c_p],
     'sqd_stem_wgrad': [c_p] * 5 + [c_i] * 6 + [c_p],
     'sqd_stem_wgrad_pooled': [c_p] * 7 + [c_i] * 6 + [c_p],
     'sqd_stem_conv_relu_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_stem_conv_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_stem_conv_relu_pool_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_fwd': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    'sqd_maxpool3x3s2_ceil_fwd_relu': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_bwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_resolve_fwd': [c_p] * 7 + [c_i] * 5 + [c_p],
     'sqd_decode_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -62,7 +62,8 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                 unpooled = a
                 continue
             am = torch.empty(Bq, *ops.pool_out_size(H, W), C, device=a.device, dtype=torch.uint8) if save else None
-            y = ops.maxpool(a, argmax=am)
+            # training: the codes carry the ReLU mask of the pool's input (a Fire output), the backward reads no mask tensor
+            y = ops.maxpool(a, argmax=am, relu_codes=save)
             if save:
                 saved[f'pool{i}'] = (am, (H, W))
             a = y

@@ -25,8 +25,8 @@ def _wgrad_layout(base, saved, B, H, W):
     layers = layer_table(base.arch)
     entries = []
 
-    def add(pre, N, C, taps, shp):
-        entries.append((pre, N, C, taps, shp[0], shp[1], shp[2], slots[pre + '.weight'][0], slots[pre + '.bias'][0]))
+    def add(pre, N, C, taps, shp, fused=False):
+        entries.append((pre, N, C, taps, shp[0], shp[1], shp[2], slots[pre + '.weight'][0], slots[pre + '.bias'][0], fused))
     add('convdet', base.convdet.out_channels, base.convdet.in_channels, 9, (B, H, W))
     for i in range(len(layers) - 1, 1, -1):
         if layers[i][0] != 'fire':
@@ -35,7 +35,7 @@ def _wgrad_layout(base, saved, B, H, W):
         shp = saved[f'fire{i}'][2].shape
         add(f'features.{i}.expand1x1', e1, s, 1, shp)
         add(f'features.{i}.expand3x3', e3, s, 9, shp)
-        add(f'features.{i}.squeeze', s, cin, 1, shp)
+        add(f'features.{i}.squeeze', s, cin, 1, shp, fused=bool(getattr(base, 'fuse_squeeze_bwd', False)) and ops.squeeze_bwd_ok(s, cin))
     return entries, slots, off
 
 
@@ -49,7 +49,7 @@ def run_backbone_backward(base, saved, dpred):
     cd = base.convdet
     a_in = saved['convdet_in']
     cin_cd = a_in.shape[3]
-    shape_key = (B, H, W) + tuple(tuple(saved[f'fire{i}'][2].shape) for i in range(len(layers)) if layers[i][0] == 'fire')
+    shape_key = (B, H, W, bool(getattr(base, 'fuse_squeeze_bwd', False))) + tuple(tuple(saved[f'fire{i}'][2].shape) for i in range(len(layers)) if layers[i][0] == 'fire')
     wb, slots, total = base.wgrad_batch(lambda: _wgrad_layout(base, saved, B, H, W), shape_key)
     # + 1: the data-parallel exchange carries this rank's image count through the same all-reduce (trainer.GradientExchange)
     grad_buf = torch.empty(total + 1, device=dpred.device, dtype=torch.float32)
@@ -57,6 +57,35 @@ def run_backbone_backward(base, saved, dpred):
     sync = getattr(base, 'grad_sync', None)
     if sync is not None:
         sync.begin(grad_buf, total, B)
+    # Weight gradients off the critical path: the data-gradient chain (ConvDet dgrad -> per Fire: expand dgrads -> squeeze dgrad ->
+    # pool backward -> ...) is what the next layer waits for; the 31 weight-gradient launches only feed the slab reduction at the
+    # end.  With ``base.wgrad_side_stream`` they run on a second stream (a parallel branch of the captured hipGraph), ordered
+    # behind the gradient tensor they read by an event, and joined before the slabs are reduced.  Tensors read by side-stream
+    # kernels are kept alive until that join (the caching allocator would otherwise hand their memory to a later layer).
+    side = None
+    if getattr(base, 'wgrad_side_stream', False) and dpred.is_cuda:
+        side = getattr(base, '_wgrad_stream', None)
+        if side is None or side.device != dpred.device:
+            side = base._wgrad_stream = torch.cuda.Stream(device=dpred.device)
+    keep = []
+
+    def on_side(fn, *tensors):
+        """Run ``fn`` (weight-gradient launches reading ``tensors``) behind everything enqueued so far -- on the side stream when
+        enabled, else inline."""
+        if side is None:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        keep.extend(tensors)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            fn()
+
+    def join_side():
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+
     # Stages of the backward = runs of layers between two pools.  With a gradient exchange attached, each stage's slabs
     # are reduced as soon as the stage is done and its slice of the flat buffer (named_parameters order: a stage is a
     # contiguous range, later stages of the network sit at higher offsets) is handed to the all-reduce; without one, all
@@ -67,6 +96,7 @@ def run_backbone_backward(base, saved, dpred):
         """Everything from ``first_param`` to the previous stage's start is final once the pending slabs are reduced."""
         if sync is None:
             return
+        join_side()                                        # the stage's slabs are complete
         row_hi = wb.row_of[first_param.rsplit('.', 1)[0]] + 1 if first_param is not None else wb.nrows
         if row_hi > stage['row']:
             wb.reduce(grad_flat, stage['row'], row_hi)
@@ -81,7 +111,7 @@ def run_backbone_backward(base, saved, dpred):
         for d in shape:
             n *= d
         return grad_flat[off:off + n].view(shape)
-    ops.conv_wgrad(dpred, 0, ncd, a_in, 0, cin_cd, 9, slab=wb.slab('convdet'))
+    on_side(lambda: ops.conv_wgrad(dpred, 0, ncd, a_in, 0, cin_cd, 9, slab=wb.slab('convdet')), dpred, a_in)
     last = len(layers) - 1
     assert layers[last][0] == 'fire'
     out_last = saved[f'fire{last}'][2]
@@ -94,9 +124,9 @@ def run_backbone_backward(base, saved, dpred):
             if i == 2 and 'stem_pool' in saved:
                 continue                                   # folded into the stem weight gradient below
             am, (Hi, Wi) = saved[f'pool{i}']
-            prev = layers[i - 1][0]
-            relu_src = saved[f'fire{i - 1}'][2] if prev == 'fire' else saved['stem_out']
-            dA = ops.maxpool_bwd(dA, am, (Hi, Wi), relu_src=relu_src)
+            # the forward recorded the ReLU mask of the pool's input inside the arg-max codes (ops.maxpool(relu_codes=True)):
+            # the gradient that leaves here already carries it, and no activation tensor is re-read for its sign
+            dA = ops.maxpool_bwd(dA, am, (Hi, Wi))
             continue
         _, cin, s, e1, e3 = l
         fire = feats[i]
@@ -104,24 +134,35 @@ def run_backbone_backward(base, saved, dpred):
         Bq, Hq, Wq, _ = out.shape
         npix = Bq * Hq * Wq
         pre = f'features.{i}.'
-        ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
-        ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
+        def expand_wgrads(dA=dA, sq=sq, e1=e1, e3=e3, s=s, pre=pre):
+            ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
+            ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
+        on_side(expand_wgrads, dA, sq)
         dSq = torch.empty_like(sq)
         ops.conv(dA, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, e1, s, npix), 'dgrad'), dSq, 0)
         base.dgrad3x3(f'{i}.expand3x3', fire.expand3x3, dA, e1, dSq, accumulate=True, ymask=sq)
-        ops.conv_wgrad(dSq, 0, s, x_in, 0, cin, 1, slab=wb.slab(pre + 'squeeze'))
         dIn = torch.empty_like(x_in)
         prev_is_fire = layers[i - 1][0] == 'fire'
-        ops.conv(dSq, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, s, cin, npix), 'dgrad'), dIn, 0,
-                 ymask=x_in if prev_is_fire else None)
+        if wb.fused.get(pre + 'squeeze'):
+            # weight gradient slabs AND the data gradient in one launch: x_in is streamed once (it used to be read by the weight
+            # gradient, and again -- for its sign only -- by the data-gradient kernel's ReLU-mask epilogue)
+            ops.squeeze_bwd(dSq, x_in, fire.squeeze.weight, wb.slab(pre + 'squeeze'), dIn, relu_mask=prev_is_fire)
+        else:
+            on_side(lambda dSq=dSq, x_in=x_in, s=s, cin=cin, pre=pre: ops.conv_wgrad(dSq, 0, s, x_in, 0, cin, 1, slab=wb.slab(pre + 'squeeze')),
+                    dSq, x_in)
+            ops.conv(dSq, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, s, cin, npix), 'dgrad'), dIn, 0,
+                     ymask=x_in if prev_is_fire else None)
         dA = dIn
     stem = feats[0]
     stem_out = (gview('features.0.weight'), gview('features.0.bias'))
     if 'stem_pool' in saved:
         am, pooled = saved['stem_pool']
-        ops.stem_wgrad_pooled(dA, pooled, am, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
+        # (the codes carry the ReLU mask: the pooled tensor is not read again)
+        ops.stem_wgrad_pooled(dA, None, am, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
     else:
         ops.stem_wgrad(dA, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
+    join_side()
+    keep.clear()
     if sync is None:
         wb.reduce(grad_flat)                               # all 31 Fire / ConvDet slab reductions: one launch
     else:

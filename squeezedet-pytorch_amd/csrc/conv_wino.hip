@@ -80,8 +80,13 @@ __device__ __forceinline__ f32x4 wino_relu4(f32x4 v, float lo) {
   return v;
 }
 
+// Residency: 4 waves x 32-channel slices = 80 KB of LDS and 253 VGPRs -> two workgroups per CU (two waves per SIMD).  The
+// 16-channel slice (NT = 1) needs half the accumulators and half the parking area: 48 KB and <= 168 VGPRs -> THREE workgroups per
+// CU, three waves per SIMD.  That is the ConvDet configuration of round 3: N = 72 runs as 5 slices of 16 (80 channels) instead of
+// 3 of 32 (96), i.e. 3000 wave-units of 3072 MFMAs on 3072 wave slots -- 9216 MFMAs on every SIMD -- where the 32-channel
+// slicing put 1800 units of 6144 on 2048 slots (12288 on the busiest SIMDs).
 template <int NT, int WV>
-__global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wino_kernel(WinoArgs a) {
+__global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT == 1) ? 3 : 1)) void conv_wino_kernel(WinoArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)    // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
   constexpr int NTHR = WV * 64;
   constexpr int BN = 16 * NT;
@@ -95,8 +100,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
   constexpr int NSTEP = 8;                    // MFMA steps of 2 positions
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const rawB = smem;                                 // [WV][256][4]
-  float* const VB = rawB + WV * 256 * 4;                    // [WV][16][16][8]
-  float* const UB = VB + WV * 2048;                         // [2][USLOTS][4]
+  float* const VB = rawB + WV * 256 * 4;                    // [WV][4 px][NT][64 lanes] f32x4: a finished tile's outputs, parked
+  float* const UB = VB + WV * 1024 * NT;                    // [2][USLOTS][4]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
@@ -105,7 +110,11 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
   const int tstride = a.gx;
   const int nchunks = a.C >> 3;
   const int ntiles = a.ntiles;
-  int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
+  // tile stream of this workgroup: the streams of ONE XCD (workgroup ids equal mod 8) cover a CONTIGUOUS run of super-groups --
+  // row-groups that are vertical neighbours share 2 of the 6 patch rows, and with the streams dealt round-robin (stream = 8 q + xcd,
+  // rounds 1 and 2) every XCD's L2 fetched those rows for itself: 125.7 MB of fabric traffic per launch against 70 MB algorithmic.
+  // The channel slices of a stream stay XCD-adjacent as before (consecutive wgq).
+  int tile = ((int)blockIdx.x & 7) * (a.gx >> 3) + wgq / a.nslices;
   if (tile >= ntiles) return;
   const int wv_s = __builtin_amdgcn_readfirstlane(wv);
 
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT <= 2) ? 2 : 1) void conv_wi
     }
   };
   float* const rawW = rawB + wv_s * 256 * 4;                 // this wave's raw patch / V image
-  float* const VW = VB + wv_s * 2048;
+  float* const VW = VB + wv_s * 1024 * NT;
   auto dma_raw_one = [&](int it, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_w_t)(rawW + it * 64 * 4), 16, r_offG[it], (int)soff, 0, 0);
   };
@@ -467,7 +476,11 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
   const int tstride = a.gx;
   const int nchunks = a.C >> 3;
   const int ntiles = a.ntiles;
-  int tile = (wgq / a.nslices) * 8 + ((int)blockIdx.x & 7);
+  // tile stream of this workgroup: the streams of ONE XCD (workgroup ids equal mod 8) cover a CONTIGUOUS run of super-groups --
+  // row-groups that are vertical neighbours share 2 of the 6 patch rows, and with the streams dealt round-robin (stream = 8 q + xcd,
+  // rounds 1 and 2) every XCD's L2 fetched those rows for itself: 125.7 MB of fabric traffic per launch against 70 MB algorithmic.
+  // The channel slices of a stream stay XCD-adjacent as before (consecutive wgq).
+  int tile = ((int)blockIdx.x & 7) * (a.gx >> 3) + wgq / a.nslices;
   if (tile >= ntiles) return;
   const int wv_s = __builtin_amdgcn_readfirstlane(wv);
 
@@ -864,7 +877,7 @@ static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
 template <int NT, int WV>
 static int launch_wino(WinoArgs a, hipStream_t stream) {
   constexpr int BN = 16 * NT, NTHR = WV * 64;
-  constexpr size_t lds = (size_t)(WV * 256 * 4 + WV * 2048 + 2 * 32 * BN * 4) * sizeof(float);
+  constexpr size_t lds = (size_t)(WV * 256 * 4 + WV * 1024 * NT + 2 * 32 * BN * 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv_wino_kernel<NT, WV>;
   static int wgs_per_cu = 0;

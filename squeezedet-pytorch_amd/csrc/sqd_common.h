@@ -23,6 +23,15 @@ static inline int sqd_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16], exact fp32 (k-ordered fma chain).
 // lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; acc reg r holds D[4*(l>>4)+r][l&15].
+// Workgroup id -> position in a persistent kernel's tile walk such that the workgroups of ONE XCD (ids w, w + 8, w + 16, ... share
+// an XCD under the round-robin dispatch: MI355X_MICROARCH.md, "Workgroup dispatch") own a CONTIGUOUS run of positions: tiles that are
+// neighbours in the walk -- and share halo rows / partial cache lines -- are then fetched through the same 4 MB L2 at about the
+// same time instead of once per XCD.  A permutation of [0, G) for any grid size G; placement is a speed matter only.
+__device__ __forceinline__ int sqd_xcd_contiguous(int w, int G) {
+  const int x = w & 7, q = G >> 3, r = G & 7;
+  return x * q + (x < r ? x : r) + (w >> 3);
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

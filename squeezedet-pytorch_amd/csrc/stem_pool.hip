@@ -297,7 +297,10 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : ((WM == 8 && KS
 
   const bool is_prod = (WM != 8) || wave_s < 4;       // uniform
   const bool is_pool = (WM != 8) || wave_s >= 4;
-  int tile = blockIdx.x;
+  // XCD-contiguous walk: horizontally adjacent tiles share two of the three 128-byte lines every 140-byte patch row touches and
+  // vertically adjacent ones 3 of 15 rows; with the plain id walk the eight neighbours of a run sat on eight XCDs and every
+  // L2 fetched its own copy (375 MB per batch of 20 for a 115 MB image, profiles/traffic.json of round 2)
+  int tile = sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
   if (tile >= a.ntiles) return;
   Tile cur = tile_at(tile);
   if (is_prod) dma_in(cur, 0);
@@ -421,6 +424,9 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : ((WM == 8 && KS
           az = (w[tt].z == m.z) ? tt : az; aw = (w[tt].w == m.w) ? tt : aw;
         }
         ax = (w[0].x == m.x) ? 0 : ax; ay = (w[0].y == m.y) ? 0 : ay; az = (w[0].z == m.z) ? 0 : az; aw = (w[0].w == m.w) ? 0 : aw;
+        // ... and the ReLU mask rides in the code: 15 where the pooled value is 0 (every tap of the window was <= 0 before the
+        // ReLU), so the backward never needs the pooled tensor for its sign (see maxpool_fwd_kernel<.., RELUMASK>)
+        ax = m.x > 0.f ? ax : 15; ay = m.y > 0.f ? ay : 15; az = m.z > 0.f ? az : 15; aw = m.w > 0.f ? aw : 15;
         *(f32x4*)(a.y + o) = m;
         *(uint32_t*)(a.amax + o) = (uint32_t)ax | ((uint32_t)ay << 8) | ((uint32_t)az << 16) | ((uint32_t)aw << 24);
       }
@@ -497,7 +503,12 @@ extern "C" int sqd_stem_conv_relu_pool_fwd(const float* x, const float* w, const
 // maximum in row-major window order, as PyTorch's CPU kernel scans it) is optionally recorded
 // for the backward pass.
 // ---------------------------------------------------------------------------------------------
-template <bool ARGMAX>
+// RELUMASK (training, pool input = a ReLU output): a pooled value that is not > 0 records code 15 instead of its window position.
+// The backward routes dy to the window position equal to the code, so such a window passes nothing on -- which IS the ReLU
+// backward of the pool's input at the arg-max element (its value is the pooled value; an all-zero window sends its gradient
+// to an element whose ReLU mask is 0).  The backward then needs no mask tensor: it used to re-read the whole pool input
+// (306 MB at 96x312x128, batch 20) for its sign.
+template <bool ARGMAX, bool RELUMASK = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ amax, int B, int H, int W, int C,
                                                           int Ho, int Wo) {
@@ -548,6 +559,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       }
     const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + 4 * c4;
     *(f32x4*)(y + o) = m;
+    if (RELUMASK) { ax = m.x > 0.f ? ax : 15; ay = m.y > 0.f ? ay : 15; az = m.z > 0.f ? az : 15; aw = m.w > 0.f ? aw : 15; }
     if (ARGMAX) *(uint32_t*)(amax + o) = (uint32_t)ax | ((uint32_t)ay << 8) | ((uint32_t)az << 16) | ((uint32_t)aw << 24);
   }
 }
@@ -561,6 +573,19 @@ extern "C" int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char
   const dim3 grid((unsigned)sqd_cdiv(((Wo + 1) / 2) * (C >> 2), 256), (unsigned)(B * Ho));
   if (argmax) hipLaunchKernelGGL(maxpool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
   else hipLaunchKernelGGL(maxpool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
+  return sqd_launch_status();
+}
+
+// The same pool for a ReLU-output input in training: argmax (required) carries the input's ReLU mask (code 15 where the pooled
+// value is not > 0), so sqd_maxpool3x3s2_ceil_bwd is called with relu_src = NULL and reads nothing but dy and the codes.
+extern "C" int sqd_maxpool3x3s2_ceil_fwd_relu(const float* x, float* y, unsigned char* argmax, int B, int H, int W,
+                                              int C, void* stream) {
+  SQD_CHECK_ARG(x && y && argmax && B > 0 && H >= 3 && W >= 3 && C > 0 && (C & 3) == 0);
+  SQD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)argmax & 3) == 0);
+  const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
+  SQD_CHECK_ARG((long long)B * Ho <= 65535);
+  const dim3 grid((unsigned)sqd_cdiv(((Wo + 1) / 2) * (C >> 2), 256), (unsigned)(B * Ho));
+  hipLaunchKernelGGL((maxpool_fwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
   return sqd_launch_status();
 }
 

@@ -25,6 +25,10 @@ struct WgradArgs {
   int tiles_x, tiles_y, nblocks, n_groups;
   long long total_px;
   long long slab_stride;
+  // DG instantiation (sqd_squeeze_bwd: a Fire squeeze's weight AND data gradient in one launch): the layer's own weight
+  // [N][C] (OIHW, 1x1), the data-gradient output window and whether x's ReLU mask applies to it
+  const float* w; float* dx;
+  int dx_pitch, dx_coff, dx_mask;
 };
 
 // LDS tiles are pixel-major rows of exactly TN*16 (dY) / TC*16 (X) floats, filled by LDS-DMA
@@ -38,8 +42,16 @@ struct WgradArgs {
 __device__ __attribute__((aligned(16))) float sqd_wg_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
 
-template <int TAPS, int TN, int TC, int TH>
+// DG = true (1x1 only, all N output channels in one group): the workgroup that streams pixel block pb for in-channels
+// [c0, c0 + TC*16) also emits that block's DATA gradient dx[p][c] = sum_n dy[p][n] w[n][c] (x's ReLU mask applied from the staged
+// x tile) -- both operands are already in LDS for the weight gradient, every pixel block is visited exactly once per channel
+// group, so the separate data-gradient launch and its second (mask) and third (weight-gradient) read of x go away.  MFMA form:
+// rows = in-channel, columns = pixel, k = out-channel with the k-slice permuted as in the Fire bridges (MFMA r of a 16-channel
+// block takes n = 16 j + 4 g + r from lane group g): one ds_read_b128 of a dy row piece / of a transposed-weight row piece feeds
+// four MFMAs, and a lane ends with four consecutive in-channels of one pixel = one 16-byte store.
+template <int TAPS, int TN, int TC, int TH, bool DG = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  static_assert(!DG || TAPS == 1, "the fused data gradient exists for 1x1 layers");
   constexpr int PB = TH * 16;                                 // pixels per block
   constexpr int RN = TN * 4, RC = TC * 4;                     // 16-byte slots per row
   constexpr bool SWN = (RN % 8) == 0, SWC = (RC % 8) == 0;    // row = multiple of 32 floats -> swizzle
@@ -52,9 +64,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int NACC = SHARED ? NU * TC * TAPS : (TILES + 3) / 4;
   constexpr int BACC = (TN + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: dy[0], dy[1], x[0], x[1]
+  // layout: dy[0], dy[1], x[0], x[1] (, transposed weights [TC*16][WP] for DG)
   float* const dyB = smem;
   float* const xB = smem + 2 * DSLOTS * 4;
+  constexpr int WP = ((TN * 16 + 63) / 64) * 64 + 8;          // row pitch = 8 (mod 64) floats: conflict-free ds_read_b128 over (row lr, piece g)
+  float* const wtT = xB + 2 * XSLOTS * 4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, kq = lane >> 4;
@@ -136,6 +150,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
   };
 
+  if (DG) {
+    // w[n][c0 + c] -> wtT[c][n] (zero beyond N / C: padded dy slots hold finite garbage, times 0); published by the first
+    // block barrier below
+    for (int idx = threadIdx.x; idx < TC * 16 * TN * 16; idx += 256) {
+      const int n = idx / (TC * 16), c = idx - n * (TC * 16);
+      wtT[c * WP + n] = (n < a.N && c0 + c < a.C) ? a.w[(long long)n * a.C + c0 + c] : 0.f;
+    }
+  }
   f32x4 acc[NACC], bacc[BACC];
   // Per-lane LDS float offsets, computed ONCE: in every k-step the pixel index is (compile-time part) + kq
   // (+ the tap shift), and because row strides / tap shifts (18*dy + dx) / 4*cq are even except dx, the
@@ -176,11 +198,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int ct = 0; ct < TC; ++ct) bS[par][ct] = kq * (RC * 4) + ((ct * 16 + lr) ^ (SWC ? (((kq + par) & 1) << 4) : 0));
 
+  // DG: the data-gradient stores go through a buffer resource and are ALWAYS issued (a lane without a pixel / channel carries an
+  // out-of-range offset: the hardware drops it), DG_ST per wave and block, so the block barrier can wait with a COUNTED vmcnt that
+  // covers the older LDS-DMA of this block but leaves the previous block's stores in flight (vector-memory operations retire in
+  // issue order); a vmcnt(0) there exposed the write latency of every block.
+  constexpr int DG_ST = DG ? ((TH * TC + 3) / 4) : 0;
+  typedef unsigned int wg_u32x4_t __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t dxres;
+  if (DG) dxres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dx + a.dx_coff + c0), 0, 0x7ffffff0, 0x00020000);
   int pb = blockIdx.x, buf = 0;
+  bool first_block = true;
   if (pb < a.nblocks) dma_block(pb, 0);
   for (; pb < a.nblocks; pb += (int)gridDim.x) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // explicit: every wave's share of the block's LDS-DMA has landed ...
-    __syncthreads();                   // ... before the barrier publishes it; previous compute finished
+    if (DG) {
+      if (first_block) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DG_ST) : "memory");
+      first_block = false;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // explicit: every wave's share of the block's LDS-DMA has landed ...
+      __syncthreads();                   // ... before the barrier publishes it; previous compute finished
+    }
     const int nxt = pb + (int)gridDim.x;
     if (nxt < a.nblocks) dma_block(nxt, buf ^ 1);
     const float* dyT = dyB + buf * DSLOTS * 4;
@@ -244,6 +282,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < NACC; ++i) acc[i] = mfma16(dyT[al[i] + immA], xT[bl[i] + immB], acc[i]);
 #pragma unroll
         for (int i = 0; i < BACC; ++i) bacc[i] = mfma16(dyT[abias[i] + immA], 1.0f, bacc[i]);   // always (stored by cg == 0 only)
+      }
+    }
+    if constexpr (DG) {
+      // ---- data gradient of this pixel block for this workgroup's in-channels ----
+      constexpr int PT = PB / 16, NTILE = PT * TC;
+      static_assert(DG_ST == (NTILE + 3) / 4, "store count per wave and block");
+      const long long p0 = (long long)pb * PB;
+      const unsigned soff = (unsigned)(p0 * a.dx_pitch * 4);    // (tensor < 4 GiB: checked by the launcher)
+#pragma unroll
+      for (int it = 0; it < DG_ST; ++it) {
+        const int t = wave_s + 4 * it;                        // (wave-uniform)
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int voff = (int)0x80000000;                           // out of range: the store is dropped
+        if (t < NTILE) {
+          const int pt = t / TC, ct = t - pt * TC;
+          const int px = pt * 16 + lr;
+          const int swd = SWN ? ((px & 1) << 2) : 0, swx = SWC ? ((px & 1) << 2) : 0;
+          const float* const drow = dyT + px * (RN * 4);
+          const float* const wrow = wtT + (ct * 16 + lr) * WP + 4 * kq;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const f32x4 bq = *(const f32x4*)(drow + (((4 * j + kq) ^ swd) << 2));      // dy[px][16 j + 4 kq .. + 3]
+            const f32x4 aq = *(const f32x4*)(wrow + 16 * j);                             // w[16 j + 4 kq .. + 3][c]
+            o = mfma16(aq.x, bq.x, o); o = mfma16(aq.y, bq.y, o); o = mfma16(aq.z, bq.z, o); o = mfma16(aq.w, bq.w, o);
+          }
+          if (a.dx_mask) {
+            const f32x4 m = *(const f32x4*)(xT + px * (RC * 4) + (((4 * ct + kq) ^ swx) << 2));
+            o.x = m.x > 0.f ? o.x : 0.f; o.y = m.y > 0.f ? o.y : 0.f; o.z = m.z > 0.f ? o.z : 0.f; o.w = m.w > 0.f ? o.w : 0.f;
+          }
+          const int c = ct * 16 + 4 * kq;
+          if (p0 + px < a.total_px && c0 + c < a.C) voff = (px * a.dx_pitch + c) * 4;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wg_u32x4_t, o), dxres, voff, (int)soff, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");                 // (MUBUF store with an SGPR soffset: write-after-read hazard, see conv_wino.hip)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     buf ^= 1;
@@ -317,14 +391,15 @@ __global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_kernel(const
   }
 }
 
-template <int TAPS, int TN, int TC, int TH>
+template <int TAPS, int TN, int TC, int TH, bool DG = false>
 static int launch_wgrad(WgradArgs a, int S, hipStream_t stream) {
   constexpr int PB = TH * 16;
   constexpr int XPIX = (TAPS == 9) ? (TH + 2) * 18 : PB;
   constexpr int DSLOTS = (PB * TN * 4 + 255) & ~255, XSLOTS = (XPIX * TC * 4 + 255) & ~255;
-  constexpr size_t lds = (size_t)(2 * DSLOTS + 2 * XSLOTS) * 16;
+  constexpr int WP = ((TN * 16 + 63) / 64) * 64 + 8;
+  constexpr size_t lds = (size_t)(2 * DSLOTS + 2 * XSLOTS) * 16 + (DG ? (size_t)TC * 16 * WP * 4 : 0);
   static_assert(lds <= 160 * 1024, "wgrad LDS budget");
-  auto kern = conv_wgrad_kernel<TAPS, TN, TC, TH>;
+  auto kern = conv_wgrad_kernel<TAPS, TN, TC, TH, DG>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return SQD_ERR_LAUNCH;
@@ -364,6 +439,7 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
   a.N = N; a.dy_pitch = dy_pitch; a.dy_coff = dy_coff; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.total_px = (long long)B * H * W;
   a.slab_stride = (long long)N * taps * C + N;
+  a.w = nullptr; a.dx = nullptr; a.dx_pitch = a.dx_coff = a.dx_mask = 0;
   hipStream_t s = (hipStream_t)stream;
   const int tn = N >= 64 ? 4 : sqd_cdiv(N, 16);
   int rc = SQD_ERR_UNSUPPORTED;
@@ -375,14 +451,24 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
     else if (tn == 2) rc = launch_wgrad<9, 2, 2, 4>(a, S, s);
     else rc = launch_wgrad<9, 3, 1, 4>(a, S, s);
   } else {
-    const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
+    // Round 3: wider output tiles where the layer is wide enough.  A workgroup that owns TC = 8 in-channel tiles (128 channels)
+    // re-reads dY half as often as with 4, and N = 96 (the squeeze of fire13 / fire14) runs as ONE 6-tile group instead of 64 + a
+    // half-empty 64 (X streamed once instead of twice, no padded MFMAs): the 24x78 1x1 weight gradients were bound by L2 -> LDS
+    // bytes per MFMA, not by HBM or the matrix pipe.  SQD_WGRAD_WIDE=0 restores the 64 x 64 tiles (A/B).
+    static const bool wide = [] { const char* e = getenv("SQD_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+    int tn1 = tn, tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
+    if (wide) {
+      if (N > 64 && N <= 96) tn1 = 6;
+      if (C >= 256) tc = 8;          // (C = 128 at 96x312 measured slower with the wide tile: 60.7 -> 74.2 us)
+    }
     // pixels per block sized so the double-buffered LDS image stays <= 40 KB: 4-5 workgroups per CU instead of one
     // (the late 24x78 layers have only ~300 blocks of 128 pixels: with one resident workgroup per CU nothing overlapped)
-#define SQD_WG_CASE(TNv, TCv) if (tn == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, ((TNv + TCv >= 6) ? 2 : ((TNv + TCv >= 3) ? 4 : 8))>(a, S, s);
-    SQD_WG_CASE(1, 1) SQD_WG_CASE(1, 2) SQD_WG_CASE(1, 3) SQD_WG_CASE(1, 4)
-    SQD_WG_CASE(2, 1) SQD_WG_CASE(2, 2) SQD_WG_CASE(2, 3) SQD_WG_CASE(2, 4)
-    SQD_WG_CASE(3, 1) SQD_WG_CASE(3, 2) SQD_WG_CASE(3, 3) SQD_WG_CASE(3, 4)
-    SQD_WG_CASE(4, 1) SQD_WG_CASE(4, 2) SQD_WG_CASE(4, 3) SQD_WG_CASE(4, 4)
+#define SQD_WG_CASE(TNv, TCv) if (tn1 == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, ((TNv + TCv >= 6) ? 2 : ((TNv + TCv >= 3) ? 4 : 8))>(a, S, s);
+    SQD_WG_CASE(1, 1) SQD_WG_CASE(1, 2) SQD_WG_CASE(1, 3) SQD_WG_CASE(1, 4) SQD_WG_CASE(1, 8)
+    SQD_WG_CASE(2, 1) SQD_WG_CASE(2, 2) SQD_WG_CASE(2, 3) SQD_WG_CASE(2, 4) SQD_WG_CASE(2, 8)
+    SQD_WG_CASE(3, 1) SQD_WG_CASE(3, 2) SQD_WG_CASE(3, 3) SQD_WG_CASE(3, 4) SQD_WG_CASE(3, 8)
+    SQD_WG_CASE(4, 1) SQD_WG_CASE(4, 2) SQD_WG_CASE(4, 3) SQD_WG_CASE(4, 4) SQD_WG_CASE(4, 8)
+    SQD_WG_CASE(6, 1) SQD_WG_CASE(6, 2) SQD_WG_CASE(6, 3) SQD_WG_CASE(6, 4) SQD_WG_CASE(6, 8)
 #undef SQD_WG_CASE
   }
   if (rc != SQD_OK) return rc;
@@ -391,6 +477,43 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs + WGR_OUT - 1) / WGR_OUT)), dim3(WGR_OUT * WGR_PARTS), 0, s, slab, dw, db, S,
                      a.slab_stride, N, C, taps);
   return sqd_launch_status();
+}
+
+// A Fire squeeze's backward in ONE launch (reference: autograd of Fire.squeeze + squeeze_activation, src/model/squeezedet.py:12,19,
+// as triggered by loss.backward(), src/engine/trainer.py:47): the weight / bias gradient slabs exactly as sqd_conv_wgrad writes
+// them (taps = 1, dw == NULL convention: the caller reduces the slabs) AND the data gradient
+//   dx[p][dx_coff + c] = (x[p][x_coff + c] > 0 or !relu_mask) ? sum_n dy[p][dy_coff + n] * w[n][c] : 0
+// for every pixel.  w: the squeeze weight itself, OIHW [N][C][1][1] (no packed copy).  N <= 96 (one out-channel group).
+// S as in sqd_conv_wgrad; the slab split uses 64-channel in-tiles (host: tiles.wgrad_split(..., fused_dgrad=True)).
+extern "C" int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_oihw, float* slab, float* dx, int B, int H, int W,
+                               int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int dx_pitch, int dx_coff,
+                               int relu_mask, int S, void* stream) {
+  SQD_CHECK_ARG(dy && x && w_oihw && slab && dx && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535);
+  SQD_CHECK_ARG((N & 3) == 0 && (C & 3) == 0 && (dy_pitch & 3) == 0 && (dy_coff & 3) == 0 && (x_pitch & 3) == 0 && (x_coff & 3) == 0);
+  SQD_CHECK_ARG((dx_pitch & 3) == 0 && (dx_coff & 3) == 0 && dx_coff >= 0 && dx_coff + C <= dx_pitch);
+  SQD_CHECK_ARG(dy_coff + N <= dy_pitch && x_coff + C <= x_pitch);
+  SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0);
+  SQD_CHECK_ARG((long long)B * H * W * dx_pitch * 4 < (1ll << 32) - (1ll << 24));       // 32-bit SGPR byte offset of a pixel block
+  SQD_CHECK_ARG((long long)32 * dx_pitch * 4 < (1ll << 30));                             // per-lane byte offsets inside a block
+  if (N > 96) return SQD_ERR_UNSUPPORTED;
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.slab = slab; a.B = B; a.H = H; a.W = W;
+  a.N = N; a.dy_pitch = dy_pitch; a.dy_coff = dy_coff; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.total_px = (long long)B * H * W;
+  a.slab_stride = (long long)N * C + N;
+  a.w = w_oihw; a.dx = dx; a.dx_pitch = dx_pitch; a.dx_coff = dx_coff; a.dx_mask = relu_mask;
+  hipStream_t s = (hipStream_t)stream;
+  const int tn = N > 64 ? 6 : sqd_cdiv(N, 16);
+  const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
+  int rc = SQD_ERR_UNSUPPORTED;
+#define SQD_SB_CASE(TNv, TCv) if (tn == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, 2, true>(a, S, s);
+  SQD_SB_CASE(1, 1) SQD_SB_CASE(1, 2) SQD_SB_CASE(1, 3) SQD_SB_CASE(1, 4)
+  SQD_SB_CASE(2, 1) SQD_SB_CASE(2, 2) SQD_SB_CASE(2, 3) SQD_SB_CASE(2, 4)
+  SQD_SB_CASE(3, 1) SQD_SB_CASE(3, 2) SQD_SB_CASE(3, 3) SQD_SB_CASE(3, 4)
+  SQD_SB_CASE(4, 1) SQD_SB_CASE(4, 2) SQD_SB_CASE(4, 3) SQD_SB_CASE(4, 4)
+  SQD_SB_CASE(6, 1) SQD_SB_CASE(6, 2) SQD_SB_CASE(6, 3) SQD_SB_CASE(6, 4)
+#undef SQD_SB_CASE
+  return rc;
 }
 
 // The slab reduction of MANY layers in one launch (a training step has 32 of them, 8 us each when launched one by one).
@@ -538,12 +661,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradArgs a) {
           if ((py & 1) != (phase >> 1) || (px & 1) != (phase & 1)) continue;
           const long long o = (((long long)b * a.Hp + py) * a.Wp + px) * a.N + 4 * q;
           const unsigned am = *(const unsigned*)(a.amax + o);
-          const f32x4 pl = *(const f32x4*)(a.pooled + o);
+          const f32x4 pl = a.pooled ? *(const f32x4*)(a.pooled + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
           const f32x4 dp = *(const f32x4*)(a.dy + o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (!(pl[e] > 0.f)) continue;
             const int t = (int)((am >> (8 * e)) & 255u);
+            if (t >= 9) continue;                                              // code 15: pooled value not > 0 (ReLU mask)
             const int oy = 2 * py + t / 3 - y0, ox = 2 * px + t % 3 - x0;
             if (oy >= 0 && oy < TH && ox >= 0 && ox < 16) dyT[(oy * 16 + ox) * PN + 4 * q + e] += dp[e];
           }
@@ -728,6 +852,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_pooled_kernel(StemWgradArgs a)
   };
   // dPool / pooled / argmax words of a tile's items -> registers
   unsigned r_am[4][SL]; f32x4 r_dp[4][SL], r_pl[4][SL];
+  const bool has_pl = a.pooled != nullptr;
   auto fetch_items = [&](const Tile q) {
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph)
@@ -741,17 +866,19 @@ __global__ __launch_bounds__(256) void stem_wgrad_pooled_kernel(StemWgradArgs a)
           ok = ok && (unsigned)wy < (unsigned)a.Hp && (unsigned)wx < (unsigned)a.Wp;
         }
         r_am[ph][sl] = 0x09090909u;                                           // code 9 never matches a tap: weight 0 below
-        r_dp[ph][sl] = (f32x4){0.f, 0.f, 0.f, 0.f}; r_pl[ph][sl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        r_dp[ph][sl] = (f32x4){0.f, 0.f, 0.f, 0.f}; r_pl[ph][sl] = (f32x4){1.f, 1.f, 1.f, 1.f};
         if (ok) {
           const long long o = q.wbase + it_goff[ph][sl];
           r_am[ph][sl] = *(const unsigned*)(a.amax + o);
           r_dp[ph][sl] = *(const f32x4*)(a.dy + o);
-          r_pl[ph][sl] = *(const f32x4*)(a.pooled + o);
+          // the fused forward's codes already carry the ReLU mask (15 = pooled value not > 0): `pooled` is optional and only
+          // read when given (uniform branch)
+          if (has_pl) r_pl[ph][sl] = *(const f32x4*)(a.pooled + o);
         }
       }
   };
 
-  int tile = blockIdx.x;
+  int tile = sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);     // neighbouring tiles (shared halo lines) through one XCD's L2
   if (tile < a.nblocks) {
     Tile cur = tile_at(tile);
     dma_in(cur, 0);
@@ -781,7 +908,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_pooled_kernel(StemWgradArgs a)
             const unsigned tix = code < 9u ? code : 0u;                        // out-of-image item: any valid table slot ...
             const int rel = relT[cls_off / 4 + tix];
             float w = mskT[cls_off / 4 + tix];
-            float v = pl[e] > 0.f ? dp[e] : 0.f;                               // ... its dp is 0
+            float v = (pl[e] > 0.f && code < 9u) ? dp[e] : 0.f;                // ... its dp is 0; code 15 = ReLU mask 0
             float* dst = (float*)(base + rel) + e;
             *dst += v * w;
           }
@@ -894,7 +1021,7 @@ extern "C" int sqd_stem_wgrad(const float* dy, const float* img, float* slab, fl
 extern "C" int sqd_stem_wgrad_pooled(const float* dpool, const float* pooled, const unsigned char* argmax, const float* img,
                                      float* slab, float* dw, float* db, int B, int Hin, int Win, int N, int ksize, int S,
                                      void* stream) {
-  SQD_CHECK_ARG(dpool && pooled && argmax && img && slab && dw && B > 0 && Hin > 0 && Win > 0 && S > 0 && S <= 65535);
+  SQD_CHECK_ARG(dpool && argmax && img && slab && dw && B > 0 && Hin > 0 && Win > 0 && S > 0 && S <= 65535);
   SQD_CHECK_ARG(((uintptr_t)dpool & 15) == 0 && ((uintptr_t)pooled & 15) == 0 && ((uintptr_t)argmax & 3) == 0);
   StemWgradArgs a;
   a.dy = dpool; a.img = img; a.slab = slab; a.pooled = pooled; a.amax = argmax; a.B = B; a.Hin = Hin; a.Win = Win; a.N = N;

@@ -151,6 +151,10 @@ class SqueezeDetBase(nn.Module):
         self.fuse_pool_squeeze = False
         self._pack_table_keepalive = None
         self._forced_drop_mask = None       # tests: NCHW mask (already scaled by 1/(1-p)) instead of RNG
+        import os
+        self.wgrad_side_stream = os.environ.get('SQD_WGRAD_SIDE_STREAM', '0')[:1] == '1'     # backward: weight gradients on a second stream
+        self._wgrad_stream = None
+        self.fuse_squeeze_bwd = os.environ.get('SQD_FUSE_SQUEEZE_BWD', '1')[:1] != '0'     # backward: squeeze wgrad + dgrad in one launch
         self.init_weights()
 
     # ---- reference: init_weights, src/model/squeezedet.py:89-97 ----

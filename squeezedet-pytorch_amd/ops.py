@@ -277,8 +277,10 @@ def stem_pool(image, weight, bias, argmax=None):
     return out
 
 
-def maxpool(x, out=None, argmax=None):
-    """MaxPool2d(3, 2, ceil_mode=True) on NHWC; ``argmax`` (uint8, same shape as out) is filled if given."""
+def maxpool(x, out=None, argmax=None, relu_codes=False):
+    """MaxPool2d(3, 2, ceil_mode=True) on NHWC; ``argmax`` (uint8, same shape as out) is filled if given.  ``relu_codes=True``
+    (x is a ReLU output, a backward follows): the codes also carry x's ReLU mask (15 = pooled value not > 0), so
+    ``maxpool_bwd`` runs without ``relu_src``."""
     _check_nhwc(x, 'x')
     B, H, W, C = x.shape
     if H < 3 or W < 3 or C % 4:
@@ -291,7 +293,12 @@ def maxpool(x, out=None, argmax=None):
     if argmax is not None and (tuple(argmax.shape) != (B, Ho, Wo, C) or argmax.dtype != torch.uint8):
         raise ValueError('maxpool: bad argmax tensor')
     br = _Bracket('maxpool_fwd', f'pool C{C} {H}x{W}', 0.0, 4.0 * B * C * (H * W + Ho * Wo)) if timing._timer is not None else None
-    rc = nat.lib().sqd_maxpool3x3s2_ceil_fwd(nat.ptr(x), nat.ptr(out), nat.ptr(argmax), B, H, W, C, nat.stream_handle(x.device))
+    if relu_codes:
+        if argmax is None:
+            raise ValueError('maxpool: relu_codes needs an argmax tensor')
+        rc = nat.lib().sqd_maxpool3x3s2_ceil_fwd_relu(nat.ptr(x), nat.ptr(out), nat.ptr(argmax), B, H, W, C, nat.stream_handle(x.device))
+    else:
+        rc = nat.lib().sqd_maxpool3x3s2_ceil_fwd(nat.ptr(x), nat.ptr(out), nat.ptr(argmax), B, H, W, C, nat.stream_handle(x.device))
     nat.check(rc, 'sqd_maxpool3x3s2_ceil_fwd')
     if br is not None:
         br.done()
@@ -308,7 +315,7 @@ def maxpool_bwd(dy, argmax, in_hw, out=None, relu_src=None):
         out = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
     if relu_src is not None and (tuple(relu_src.shape) != (B, H, W, C) or not relu_src.is_contiguous()):
         raise ValueError('maxpool_bwd: relu_src must match the pool input')
-    br = _Bracket('maxpool_bwd', f'poolbwd C{C} {H}x{W}', 0.0, 4.0 * B * C * (H * W * 2 + Ho * Wo * 1.25)) if timing._timer is not None else None
+    br = _Bracket('maxpool_bwd', f'poolbwd C{C} {H}x{W}', 0.0, 4.0 * B * C * (H * W * (2 if relu_src is not None else 1) + Ho * Wo * 1.25)) if timing._timer is not None else None
     rc = nat.lib().sqd_maxpool3x3s2_ceil_bwd(nat.ptr(dy), nat.ptr(argmax), nat.ptr(out), nat.ptr(relu_src), B, H, W, C,
                                              nat.stream_handle(dy.device))
     if br is not None:
@@ -456,6 +463,38 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
     return None if deferred else (dw, db)
 
 
+def squeeze_bwd_ok(N, C):
+    """Whether ``squeeze_bwd`` can run a (C -> N) 1x1 layer: all N out-channels in one group."""
+    return N % 4 == 0 and C % 4 == 0 and N <= 96
+
+
+def squeeze_bwd(dy, x, weight, slab, dx, relu_mask):
+    """A Fire squeeze's backward in ONE launch: the weight / bias gradient slabs (as ``conv_wgrad(..., slab=...)`` writes them; ``slab``
+    from a ``WgradBatch`` entry flagged fused) and the data gradient dx = dy . W, zeroed where ``relu_mask`` and x <= 0.  dy [B,H,W,N]
+    (already masked), x / dx [B,H,W,C], weight: the layer's OIHW [N,C,1,1] parameter."""
+    _check_nhwc(dy, 'dy'); _check_nhwc(x, 'x'); _check_nhwc(dx, 'dx')
+    B, H, W, N = dy.shape
+    C = x.shape[3]
+    if tuple(x.shape[:3]) != (B, H, W) or tuple(dx.shape) != tuple(x.shape):
+        raise ValueError('squeeze_bwd: dy, x and dx disagree on B,H,W / C')
+    if tuple(weight.shape) != (N, C, 1, 1) or weight.dtype != torch.float32 or not weight.is_cuda or not weight.is_contiguous():
+        raise ValueError(f'squeeze_bwd: weight must be a contiguous fp32 CUDA [N,C,1,1] tensor, got {tuple(weight.shape)}')
+    if not squeeze_bwd_ok(N, C):
+        raise ValueError(f'squeeze_bwd: unsupported layer C={C} N={N}')
+    S, stride = wgrad_split(N, C, 1, B, H, W, fused_dgrad=True)
+    if slab.numel() != S * stride or not slab.is_contiguous() or slab.dtype != torch.float32:
+        raise ValueError('squeeze_bwd: slab workspace does not match this layer')
+    npix = B * H * W
+    br = _Bracket('squeeze_bwd', f'sqbwd C{C} N{N} {H}x{W}', 4.0 * npix * N * C,
+                  4.0 * (npix * (2 * C + N) + N * C + 2 * S * stride)) if timing._timer is not None else None
+    rc = nat.lib().sqd_squeeze_bwd(nat.ptr(dy), nat.ptr(x), nat.ptr(weight.detach()), nat.ptr(slab), nat.ptr(dx), B, H, W, N, N, 0, C, C, 0,
+                                   C, 0, int(bool(relu_mask)), S, nat.stream_handle(dy.device))
+    nat.check(rc, 'sqd_squeeze_bwd')
+    if br is not None:
+        br.done()
+    return dx
+
+
 def _check_stem_out(dw, db, N, ksize):
     if tuple(dw.shape) != (N, 3, ksize, ksize) or tuple(db.shape) != (N,) or not dw.is_contiguous() or not db.is_contiguous() \
             or dw.dtype != torch.float32 or db.dtype != torch.float32:
@@ -489,11 +528,14 @@ def stem_wgrad(dy, image, N, ksize, out=None):
 
 
 def stem_wgrad_pooled(dpool, pooled, argmax, image, N, ksize, out=None):
-    """Stem (dW, db) when the forward ran fused (stem_pool with argmax): ReLU + max-pool backward folded in."""
-    _check_nhwc(dpool, 'dpool'); _check_nhwc(pooled, 'pooled')
+    """Stem (dW, db) when the forward ran fused (stem_pool with argmax): ReLU + max-pool backward folded in.  ``pooled`` may be
+    None: the forward's arg-max codes carry the ReLU mask (15 = pooled value 0)."""
+    _check_nhwc(dpool, 'dpool')
+    if pooled is not None:
+        _check_nhwc(pooled, 'pooled')
     B, Hp, Wp, n = dpool.shape
-    if n != N or tuple(pooled.shape) != (B, Hp, Wp, N) or tuple(argmax.shape) != (B, Hp, Wp, N) or argmax.dtype != torch.uint8 \
-            or not argmax.is_contiguous():
+    if n != N or (pooled is not None and tuple(pooled.shape) != (B, Hp, Wp, N)) or tuple(argmax.shape) != (B, Hp, Wp, N) \
+            or argmax.dtype != torch.uint8 or not argmax.is_contiguous():
         raise ValueError('stem_wgrad_pooled: dpool / pooled / argmax geometry mismatch')
     if image.dim() != 4 or image.shape[0] != B or image.shape[1] != 3 or not image.is_contiguous():
         raise ValueError('stem_wgrad_pooled: bad image')
@@ -509,7 +551,7 @@ def stem_wgrad_pooled(dpool, pooled, argmax, image, N, ksize, out=None):
                                           torch.empty(N, device=dpool.device, dtype=torch.float32))
     _check_stem_out(dw, db, N, ksize)
     br = _Bracket(f'stem_wgrad_pooled<{ksize}>', f'stem wgrad (pooled) {H}x{W}', 2.0 * B * Ho * Wo * N * K,
-                  4.0 * (B * Hp * Wp * N * 2.25 + B * 3 * H * W)) if timing._timer is not None else None
+                  4.0 * (B * Hp * Wp * N * (2.25 if pooled is not None else 1.25) + B * 3 * H * W)) if timing._timer is not None else None
     rc = nat.lib().sqd_stem_wgrad_pooled(nat.ptr(dpool), nat.ptr(pooled), nat.ptr(argmax), nat.ptr(image), nat.ptr(slab), nat.ptr(dw),
                                          nat.ptr(db), B, H, W, N, ksize, S, nat.stream_handle(dpool.device))
     nat.check(rc, 'sqd_stem_wgrad_pooled')

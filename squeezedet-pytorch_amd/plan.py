@@ -104,12 +104,13 @@ def _wgrad(batch, H, W, N, C, taps):
 
 
 def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
-                         use_winograd=True, data_parallel_stages=False):
+                         use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True):
     """Launches of one training iteration's forward (activations saved, no inference-only fusion: ``autograd.py`` gates
     the bridges and fused expands on ``not save``), multi-task loss forward / backward and the backbone backward, as
     (kernel name, shape tag) in launch order.  The optimizer launch and torch's own elementwise kernels (dropout mask,
     ``loss.mean()``) are not KernelTimer-bracketed and not listed.  ``data_parallel_stages``: with a gradient exchange
-    attached the slab reduction runs once per backward stage instead of once at the end."""
+    attached the slab reduction runs once per backward stage instead of once at the end.  ``fuse_squeeze_bwd`` =
+    ``SqueezeDetBase.fuse_squeeze_bwd``."""
     layers = layer_table(arch)
     ks = layers[0][3]
     H, W = ops.stem_out_size(input_size[0], input_size[1], ks)
@@ -163,8 +164,11 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
         plan.append(_wgrad(batch, Hi, Wi, e3, s, 9))
         plan.append(_conv1x1(batch, Hi, Wi, e1, s))                                   # expand1x1 data gradient
         plan.append(_conv3x3(batch, Hi, Wi, e3, s, use_winograd))                     # expand3x3 data gradient (accumulates)
-        plan.append(_wgrad(batch, Hi, Wi, s, cin, 1))
-        plan.append(_conv1x1(batch, Hi, Wi, s, cin))                                  # squeeze data gradient
+        if fuse_squeeze_bwd and ops.squeeze_bwd_ok(s, cin):
+            plan.append(('squeeze_bwd', f'sqbwd C{cin} N{s} {Hi}x{Wi}'))              # squeeze weight + data gradient, one launch
+        else:
+            plan.append(_wgrad(batch, Hi, Wi, s, cin, 1))
+            plan.append(_conv1x1(batch, Hi, Wi, s, cin))                              # squeeze data gradient
         rows_total += 3
     Hs, Ws = input_size
     if fused_stem:

@@ -237,15 +237,18 @@ class WgradBatch:
     def __init__(self, entries, device):
         rows, self.slabs, off, blk = [], {}, 0, 0
         self.row_blocks = [0]                  # first workgroup of every record (+ the total at the end)
-        for key, N, C, taps, B, H, W, dw_off, db_off in entries:
-            S, stride = wgrad_split(N, C, taps, B, H, W)
+        self.fused = {}
+        for key, N, C, taps, B, H, W, dw_off, db_off, *flags in entries:
+            fused = bool(flags and flags[0])       # the layer's slabs come from ops.squeeze_bwd (its own split)
+            self.fused[key] = fused
+            S, stride = wgrad_split(N, C, taps, B, H, W, fused_dgrad=fused)
             rows.append([off, dw_off, db_off, S, stride, N, C, taps, blk])
             self.slabs[key] = (off, S * stride)
             off += S * stride
             blk += -(-stride // _WGR_OUT)
             self.row_blocks.append(blk)
         self.total_blocks = blk
-        self.row_of = {key: i for i, (key, *_rest) in enumerate(entries)}
+        self.row_of = {e[0]: i for i, e in enumerate(entries)}
         self.workspace = torch.empty(off, device=device, dtype=torch.float32)
         self.table = torch.tensor(rows, dtype=torch.int64).to(device)
         self.nrows = len(rows)

@@ -285,6 +285,7 @@ def pool_out_size(h, w):
 _TARGET_WGS = 1536          # workgroups a 3x3 weight-gradient launch aims for (measured sweep 768 / 1536 / 3072)
 
 
+_TARGET_WGS_SQBWD = 512     # fused squeeze backward (ops.squeeze_bwd): two ~60 KB workgroups per CU, one resident round
 _TARGET_WGS_1X1 = 512       # 1x1: fewer, longer pixel streams (less slab traffic per MFMA; round 2, inside the training step: 512 6.26 ms, 1024 6.29, 384 6.40)
 
 
@@ -306,8 +307,14 @@ def _wino_wgrad_tc(N, C):
     return 1 if (N % 64 or C % 32 == 16 or C < 32) else 2
 
 
-def wgrad_split(N, C, taps, B, H, W, wino=None):
+def _wgrad_wide():
+    import os
+    return os.environ.get('SQD_WGRAD_WIDE', '1')[:1] != '0'
+
+
+def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False):
     """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab.
+    ``fused_dgrad``: the layer runs ``ops.squeeze_bwd`` (weight + data gradient in one launch: all N in one group, 64-channel in-tiles).
     S comes from the workgroup targets below unless the measured table has a row 'G:taps:N:C:npix' (tools/tune_insitu.py --mode
     train: the split of each layer tried inside the training step)."""
     tuned = _tuning().get(f'G:{taps}:{N}:{C}:{B * H * W}')
@@ -319,6 +326,17 @@ def wgrad_split(N, C, taps, B, H, W, wino=None):
         if tuned is not None and tuned >= 1:
             S = max(1, min(ngroups, int(tuned)))
         return S, N * taps * C + N
+    if fused_dgrad:
+        if taps != 1 or N > 96:
+            raise ValueError('fused squeeze backward: 1x1 layers with N <= 96')
+        nblocks = -(-(B * H * W) // 32)
+        groups = -(-C // 64)
+        import os
+        target = int(os.environ.get('SQD_SQBWD_WGS', _TARGET_WGS_SQBWD))      # (env: A/B sweeps)
+        S = max(1, min(nblocks, target // groups, 1024))
+        if tuned is not None and tuned >= 1:
+            S = max(1, min(nblocks, int(tuned), 1024))
+        return S, N * C + N
     tn = 4 if N >= 64 else -(-N // 16)
     if taps == 9:
         if 64 < N <= 80:
@@ -332,6 +350,11 @@ def wgrad_split(N, C, taps, B, H, W, wino=None):
         nblocks = B * -(-H // 4) * -(-W // 16)
     else:
         tc = 4 if C >= 64 else -(-C // 16)
+        if _wgrad_wide():                       # (mirrors csrc/wgrad.hip sqd_conv_wgrad: 128-channel in-tiles, N = 96 as one 6-tile group)
+            if 64 < N <= 96:
+                tn = 6
+            if C >= 256:
+                tc = 8
         nblocks = -(-(B * H * W) // 128)
     groups = -(-N // (tn * 16)) * -(-C // (tc * 16))
     S = max(1, min(nblocks, (_TARGET_WGS if taps == 9 else _TARGET_WGS_1X1) // groups, 256))

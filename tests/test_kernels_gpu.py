@@ -119,6 +119,33 @@ def test_maxpool_fwd_bwd(C, H, W):
     assert (dx.cpu() - _nhwc(x.grad)).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize("C,H,W", [(64, 32, 48), (128, 17, 23), (8, 4, 4), (128, 96, 312)])
+def test_maxpool_relu_codes_carry_the_mask(C, H, W):
+    """Training path: the pool input is a ReLU output.  ``maxpool(relu_codes=True)`` writes code 15 where the pooled value is not
+    > 0; ``maxpool_bwd`` on those codes WITHOUT a mask tensor equals the old path (plain codes + relu_src re-read) bit for bit,
+    and equals autograd through relu -> max_pool2d."""
+    ops = _ops()
+    pre = _rand(2, C, H, W, seed=16).requires_grad_(True)
+    ref = F.max_pool2d(F.relu(pre), 3, 2, ceil_mode=True)
+    dy = _rand(*ref.shape, seed=17)
+    ref.backward(dy)
+    xg = _nhwc(F.relu(pre.detach())).cuda()
+    shape = _nhwc(ref.detach()).shape
+    am_plain = torch.empty(*shape, dtype=torch.uint8, device='cuda')
+    am_relu = torch.empty(*shape, dtype=torch.uint8, device='cuda')
+    y0 = ops.maxpool(xg, argmax=am_plain)
+    y1 = ops.maxpool(xg, argmax=am_relu, relu_codes=True)
+    assert torch.equal(y0, y1) and torch.equal(y0.cpu(), _nhwc(ref.detach()))
+    zero = y0 <= 0
+    assert bool((am_relu[zero] == 15).all()) and torch.equal(am_relu[~zero], am_plain[~zero]) and int(am_plain.max()) <= 8
+    assert bool(zero.any())                                   # the case is exercised
+    dyg = _nhwc(dy).cuda()
+    old = ops.maxpool_bwd(dyg, am_plain, (H, W), relu_src=xg)
+    new = ops.maxpool_bwd(dyg, am_relu, (H, W))
+    assert torch.equal(old, new)
+    assert (new.cpu() - _nhwc(pre.grad)).abs().max().item() <= 1e-6
+
+
 @pytest.mark.parametrize("k,N,H,W", [(3, 64, 64, 96), (3, 64, 50, 70), (3, 64, 37, 45), (7, 96, 64, 96), (7, 96, 30, 50)])
 def test_fused_stem_pool(k, N, H, W):
     ops = _ops()
@@ -131,12 +158,13 @@ def test_fused_stem_pool(k, N, H, W):
     y = ops.stem_pool(x.cuda(), w.cuda(), b.cuda(), argmax=am)
     assert tuple(y.shape) == tuple(_nhwc(ref).shape)
     assert (y.cpu() - _nhwc(ref)).abs().max().item() <= _tol(ref)
-    # argmax consistent with the separate kernels (same window code 0..8)
+    # argmax consistent with the separate kernels (same window code 0..8, 15 where the pooled value is 0: the ReLU mask)
     y2 = ops.stem_conv_relu(x.cuda(), w.cuda(), b.cuda())
     am2 = torch.empty_like(am)
-    p2 = ops.maxpool(y2, argmax=am2)
+    p2 = ops.maxpool(y2, argmax=am2, relu_codes=True)
     assert torch.equal(p2, y)
     assert (am == am2).float().mean().item() > 0.999
+    assert bool((am[y <= 0] == 15).all()) and int(am[y > 0].max()) <= 8
     # inference instantiation (no argmax, v_max3 pooling): same bits
     assert torch.equal(ops.stem_pool(x.cuda(), w.cuda(), b.cuda()), y)
 
@@ -152,7 +180,7 @@ def test_fused_stem_pool_kitti_size_both_paths_agree():
     assert torch.equal(y_inf, y_tr)
     ref = F.max_pool2d(F.relu(F.conv2d(x[:1].cpu(), w.cpu(), b.cpu(), stride=2, padding=1)), 3, 2, ceil_mode=True)
     assert (y_inf[:1].cpu() - _nhwc(ref)).abs().max().item() <= _tol(ref)
-    assert int(am.max()) <= 8
+    assert int(am[y_tr > 0].max()) <= 8 and bool((am[y_tr <= 0] == 15).all())
 
 
 @pytest.mark.parametrize("C,E,H,W", [(16, 64, 40, 70), (32, 128, 24, 78), (48, 192, 13, 29), (96, 384, 24, 78), (64, 256, 9, 17)])

@@ -236,6 +236,9 @@ def test_stem_wgrad_pooled(k, N, H, W):
     assert (db.cpu() - b.grad).abs().max().item() <= 2e-4 * max(1.0, float(b.grad.abs().max()))
     dw2, db2 = ops.stem_wgrad_pooled(_nhwc(dy).cuda(), pooled, am, x.cuda(), N, k)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)          # deterministic
+    # the arg-max codes carry the ReLU mask (15 = pooled value 0): without the pooled tensor the result is the same, bit for bit
+    dw3, db3 = ops.stem_wgrad_pooled(_nhwc(dy).cuda(), None, am, x.cuda(), N, k)
+    assert torch.equal(dw, dw3) and torch.equal(db, db3)
 
 
 def test_trainer_epochs_dense_and_sparse_annotations():
@@ -403,3 +406,65 @@ def test_trainer_with_steplr_and_fused_optimizer():
     assert fo._table_key != key0
     for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
         assert torch.allclose(p, q, rtol=2e-5, atol=1e-7), n
+
+
+@pytest.mark.parametrize("C,N,B,H,W,mask", [(64, 16, 2, 24, 39, False), (128, 16, 2, 17, 23, True), (256, 32, 2, 12, 20, True),
+                                            (384, 48, 3, 7, 13, True), (512, 64, 2, 9, 11, True), (768, 96, 2, 24, 78, True),
+                                            (48, 96, 1, 5, 7, True), (512, 96, 20, 24, 78, True)])
+def test_squeeze_bwd_one_launch(C, N, B, H, W, mask):
+    """ops.squeeze_bwd (a Fire squeeze's weight gradient slabs + data gradient + the previous Fire's ReLU mask in one launch) vs
+    autograd of relu -> conv1x1 on the CPU, and vs the two separate kernels it replaces: the slabs are bitwise those of
+    conv_wgrad's tiling when the tilings coincide, the data gradient equals the conv kernel's to fp32 rounding; odd pixel
+    counts (partial last block), channel counts off the 64-channel tile, mask on and off."""
+    from squeezedet_pytorch_amd import ops
+    pre = _rand(B, C, H, W, seed=41).requires_grad_(True)
+    xin = F.relu(pre) if mask else pre
+    w = _rand(N, C, 1, 1, seed=42, scale=(2.0 / C) ** 0.5).requires_grad_(True)
+    b = _rand(N, seed=43, scale=0.1).requires_grad_(True)
+    y = F.conv2d(xin, w, b)
+    dy = _rand(*y.shape, seed=44)
+    y.backward(dy)
+    x_nhwc = _nhwc(xin.detach()).cuda()
+    dy_nhwc = _nhwc(dy).cuda()
+    S, stride = ops.wgrad_split(N, C, 1, B, H, W, fused_dgrad=True)
+    slab = torch.full((S * stride,), float('nan'), device='cuda')
+    dx = torch.full_like(x_nhwc, float('nan'))
+    ops.squeeze_bwd(dy_nhwc, x_nhwc, w.detach().cuda().contiguous(), slab, dx, relu_mask=mask)
+    torch.cuda.synchronize()
+    red = slab.view(S, stride).double().sum(0).cpu()
+    assert not torch.isnan(red).any() and not torch.isnan(dx).any()
+    dw = red[:N * C].view(N, C, 1, 1)
+    db = red[N * C:]
+    scale_w = max(1.0, float(w.grad.abs().max()))
+    assert (dw - w.grad.double()).abs().max().item() <= 2e-4 * scale_w
+    assert (db - b.grad.double()).abs().max().item() <= 2e-4 * max(1.0, float(b.grad.abs().max()))
+    want_dx = _nhwc(pre.grad)                       # through the ReLU when mask: dpre = dx * (pre > 0)
+    assert (dx.cpu() - want_dx).abs().max().item() <= 2e-5 * max(1.0, float(want_dx.abs().max()))
+    # the separate kernels it replaces
+    plan = ops.ConvPlan(w.detach().cuda(), None, ops.choose_cfg(1, N, C, B * H * W), dgrad=True)
+    dx2 = torch.empty_like(x_nhwc)
+    ops.conv(dy_nhwc, 0, plan, dx2, 0, ymask=x_nhwc if mask else None)
+    assert (dx - dx2).abs().max().item() <= 1e-5 * max(1.0, float(want_dx.abs().max()))
+    # run-to-run reproducible
+    slab2 = torch.empty_like(slab); dx3 = torch.empty_like(dx)
+    ops.squeeze_bwd(dy_nhwc, x_nhwc, w.detach().cuda().contiguous(), slab2, dx3, relu_mask=mask)
+    assert torch.equal(slab, slab2) and torch.equal(dx, dx3)
+
+
+def test_backward_with_and_without_fused_squeeze_bwd_agree():
+    """Whole backward, SqueezeDetBase.fuse_squeeze_bwd on vs off: same gradients to fp32 rounding (the weight-gradient split
+    differs, so not bitwise), flat-buffer layout intact either way."""
+    size = (64, 96)
+    cfg, m, sd = _train_model('squeezedet', size)
+    x = synthetic.make_images(2, size, seed=3).cuda()
+    gt = synthetic.make_gt(2, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3).cuda()
+    grads = {}
+    for flag in (True, False):
+        m.base.fuse_squeeze_bwd = flag
+        m.zero_grad()
+        loss, _ = m({'image': x, 'gt': gt})
+        loss.mean().backward()
+        grads[flag] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert (a - b).abs().max().item() <= 2e-5 * max(float(b.abs().max()), 1e-3), n
