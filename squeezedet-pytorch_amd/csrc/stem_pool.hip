@@ -517,10 +517,16 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
   // blockIdx.y = (b, oy): no 64-bit divisions per element.  Clipped border windows (ceil mode) clamp their tap offsets
   // to the last valid row / column for the value; the argmax only ever considers in-range taps.
   const int cv = C >> 2, Wp = (Wo + 1) >> 1;
-  const int t = blockIdx.x * 256 + threadIdx.x;            // index inside the output row: oxp * cv + c4
+  // XCD-contiguous block order: output rows oy and oy + 1 share an input row, and the plain (x, y) order dealt vertically
+  // adjacent blocks to different XCDs, so each L2 fetched the shared row for itself (428 MB of fabric traffic per launch against
+  // 287 MB algorithmic in the training step, profiles/traffic.json of round 3)
+  const int gxn = (int)gridDim.x, nblk = gxn * (int)gridDim.y;
+  const int lin = sqd_xcd_contiguous((int)blockIdx.y * gxn + (int)blockIdx.x, nblk);
+  const int by = lin / gxn, bx = lin - by * gxn;
+  const int t = bx * 256 + threadIdx.x;                    // index inside the output row: oxp * cv + c4
   if (t >= Wp * cv) return;
   const int oxp = t / cv, c4 = t - oxp * cv;
-  const int oy = blockIdx.y % Ho, b = blockIdx.y / Ho;
+  const int oy = by % Ho, b = by / Ho;
   const int ox0 = 2 * oxp, ix0 = 4 * oxp;
   const float* row = x + ((long long)b * H + 2 * oy) * W * C + (long long)ix0 * C + 4 * c4;
   const int ny = (2 * oy + 3 <= H) ? 3 : H - 2 * oy;                               // rows of the (clipped) windows
@@ -594,43 +600,63 @@ extern "C" int sqd_maxpool3x3s2_ceil_fwd_relu(const float* x, float* y, unsigned
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ amax,
                                                           float* __restrict__ dx, const float* __restrict__ relu_src,
                                                           int B, int H, int W, int C, int Ho, int Wo) {
-  const int cv = C >> 2;
-  const long long total = (long long)B * H * W * cv;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % cv); long long p = idx / cv;
-    const int ix = (int)(p % W); p /= W;
-    const int iy = (int)(p % H); const int b = (int)(p / H);
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // windows oy with 2*oy <= iy <= 2*oy+2  ->  oy in [ceil((iy-2)/2), floor(iy/2)]
-    const int oy_lo = iy >= 2 ? (iy - 1) / 2 : 0, oy_hi = min(iy / 2, Ho - 1);
-    const int ox_lo = ix >= 2 ? (ix - 1) / 2 : 0, ox_hi = min(ix / 2, Wo - 1);
-    for (int oy = oy_lo; oy <= oy_hi; ++oy)
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        const int t = (iy - 2 * oy) * 3 + (ix - 2 * ox);
-        const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + 4 * c4;
-        const uint32_t am = *(const uint32_t*)(amax + o);
-        const f32x4 g = *(const f32x4*)(dy + o);
-        if ((int)(am & 255) == t) acc.x += g.x;
-        if ((int)((am >> 8) & 255) == t) acc.y += g.y;
-        if ((int)((am >> 16) & 255) == t) acc.z += g.z;
-        if ((int)(am >> 24) == t) acc.w += g.w;
-      }
-    const long long xo = (((long long)b * H + iy) * W + ix) * C + 4 * c4;
+  // One thread = a 2x2 quad of input pixels (rows 2r, 2r+1; columns 2q, 2q+1) x 4 channels.  The quad is covered by exactly the
+  // four windows (r-1..r, q-1..q): 4 (code word, dy) loads feed 4 outputs, where a thread per pixel issued 9 for the same four
+  // (the kernel is bound by those gather loads, not by its stores).  blockIdx.y = (b, r), blockIdx.x covers q * cv + c4:
+  // 32-bit index arithmetic only.  Blocks are renumbered XCD-contiguously: vertically adjacent quads share two windows.
+  const int cv = C >> 2, Wq = (W + 1) >> 1, Hq = (H + 1) >> 1;
+  const int gxn = (int)gridDim.x, nblk = gxn * (int)gridDim.y;
+  const int lin = sqd_xcd_contiguous((int)blockIdx.y * gxn + (int)blockIdx.x, nblk);
+  const int by = lin / gxn, bx = lin - by * gxn;
+  const int t = bx * 256 + (int)threadIdx.x;
+  if (t >= Wq * cv) return;
+  const int q = t / cv, c4 = t - q * cv;
+  const int r = by % Hq, b = by / Hq;
+  // window (oy, ox) contributes to pixel (iy, ix) at tap (iy - 2 oy) * 3 + (ix - 2 ox)
+  f32x4 o00 = (f32x4){0.f, 0.f, 0.f, 0.f}, o01 = o00, o10 = o00, o11 = o00;
+  auto add = [](f32x4& acc, uint32_t am, const f32x4& g, int tap) {
+    if ((int)(am & 255) == tap) acc.x += g.x;
+    if ((int)((am >> 8) & 255) == tap) acc.y += g.y;
+    if ((int)((am >> 16) & 255) == tap) acc.z += g.z;
+    if ((int)(am >> 24) == tap) acc.w += g.w;
+  };
+  // same order of additions per output as the one-pixel gather (oy ascending, then ox ascending): bitwise the same results
+#pragma unroll
+  for (int dr = -1; dr <= 0; ++dr)
+#pragma unroll
+    for (int dq = -1; dq <= 0; ++dq) {
+      const int oy = r + dr, ox = q + dq;
+      if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+      const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + 4 * c4;
+      const uint32_t am = *(const uint32_t*)(amax + o);
+      const f32x4 g = *(const f32x4*)(dy + o);
+      // taps of this window that fall on the quad: rows 2r - 2oy = -2dr (+0, +1), columns -2dq (+0, +1)
+      const int ty = -2 * dr, tx = -2 * dq;
+      add(o00, am, g, ty * 3 + tx);
+      if (tx + 1 < 3) add(o01, am, g, ty * 3 + tx + 1);
+      if (ty + 1 < 3) add(o10, am, g, (ty + 1) * 3 + tx);
+      if (ty + 1 < 3 && tx + 1 < 3) add(o11, am, g, (ty + 1) * 3 + tx + 1);
+    }
+  const int iy = 2 * r, ix = 2 * q;
+  auto put = [&](f32x4 acc, int y, int x) {
+    if (y >= H || x >= W) return;
+    const long long xo = (((long long)b * H + y) * W + x) * C + 4 * c4;
     if (relu_src) {      // the pooled tensor was a ReLU output: fold its backward mask into this store
       const f32x4 m = *(const f32x4*)(relu_src + xo);
       acc.x = m.x > 0.f ? acc.x : 0.f; acc.y = m.y > 0.f ? acc.y : 0.f; acc.z = m.z > 0.f ? acc.z : 0.f; acc.w = m.w > 0.f ? acc.w : 0.f;
     }
     *(f32x4*)(dx + xo) = acc;
-  }
+  };
+  put(o00, iy, ix); put(o01, iy, ix + 1); put(o10, iy + 1, ix); put(o11, iy + 1, ix + 1);
 }
 
 extern "C" int sqd_maxpool3x3s2_ceil_bwd(const float* dy, const unsigned char* argmax, float* dx, const float* relu_src,
                                          int B, int H, int W, int C, void* stream) {
   SQD_CHECK_ARG(dy && argmax && dx && B > 0 && H >= 3 && W >= 3 && C > 0 && (C & 3) == 0);
+  SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)argmax & 3) == 0 && ((uintptr_t)relu_src & 15) == 0);
   const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
-  const long long total = (long long)B * H * W * (C >> 2);
-  const int blocks = (int)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, relu_src, B, H, W, C, Ho, Wo);
+  SQD_CHECK_ARG((long long)B * ((H + 1) / 2) <= 65535 && (long long)W * (C >> 2) < (1ll << 30));
+  const dim3 grid((unsigned)sqd_cdiv(((W + 1) / 2) * (C >> 2), 256), (unsigned)(B * ((H + 1) / 2)));
+  hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, relu_src, B, H, W, C, Ho, Wo);
   return sqd_launch_status();
 }
