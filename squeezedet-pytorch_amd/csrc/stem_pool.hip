@@ -10,6 +10,7 @@
 // A = weights, operand B = pixels, so a lane ends with 4 consecutive output channels of one pixel
 // and stores 16 bytes (the stem output is the largest tensor of the network: 30.7 MB per image).
 #include "sqd_common.h"
+#include <type_traits>
 
 struct StemArgs {
   const float* x;     // [B][3][Hin][Win]
@@ -295,6 +296,14 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : ((WM == 8 && KS
     }
   }
 
+  // (WREG) byte address of every k-step's B operand inside input buffer 0: patch pixel base + im2col offset of k = 4s + g
+  const char* bofs[WREG ? MT : 1][WREG ? KSTEPS : 1];
+  if (WREG) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) bofs[i][s] = (const char*)(inB + pbase[i] + kreg[s]);
+  }
   const bool is_prod = (WM != 8) || wave_s < 4;       // uniform
   const bool is_pool = (WM != 8) || wave_s >= 4;
   // XCD-contiguous walk: horizontally adjacent tiles share two of the three 128-byte lines every 140-byte patch row touches and
@@ -327,9 +336,34 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : ((WM == 8 && KS
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (WREG) {
+      // 3x3 stem: the im2col addresses of all k-steps are per-lane constants (bofs, computed once before the tile loop); the
+      // input buffer is a compile-time offset inside each of the two copies of this phase, so every operand read is
+      // ds_read_b32 base + immediate, all of them are issued before the first MFMA, and the phase holds NO vector ALU
+      // instruction (it had an add + add3 per k-step and waited for each read in turn; every VALU instruction delays the
+      // matrix pipe, DESIGN.md cost model)
+      auto mfma_phase = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        float bf[KSTEPS][MT];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const float v = *(const float*)(bofs[i][s] + BUF * INSLOTS * 4);
+            bf[s][i] = (4 * s + 3 < K) ? v : ((4 * s + g < K) ? v : 0.f);     // padded k of the last step: weights are 0 there too
+          }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(wreg[s][j], bf[s][i], acc[i][j]);
+      };
+      if (buf) mfma_phase(std::integral_constant<int, 1>{}); else mfma_phase(std::integral_constant<int, 0>{});
+    } else {
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-      const int koff = WREG ? kreg[s] : koffL[4 * s + g];
+      const int koff = koffL[4 * s + g];
       float bf[MT], af[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -337,11 +371,12 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : ((WM == 8 && KS
         else bf[i] = (4 * s + g < K) ? inT[pbase[i] + koff] : 0.f;        // padded k of the last step: weights are 0 there too
       }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) af[j] = WREG ? wreg[s][j] : wT[(j * 16 + lr) * KW + 4 * s + g];
+      for (int j = 0; j < NT; ++j) af[j] = wT[(j * 16 + lr) * KW + 4 * s + g];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(af[j], bf[i], acc[i][j]);
+    }
     }
     // bias + ReLU -> LDS; positions outside the conv feature map become 0 (neutral for max of ReLU outputs)
     const bool conv_inner = cy0 + CH <= a.Ho && cx0 + CW <= a.Wo;       // uniform
@@ -360,6 +395,7 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : ((WM == 8 && KS
           asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
                        : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
           if (!conv_inner) {                                            // uniform: only border tiles mask per lane
+            asm volatile("" ::: "memory");
             if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         } else {
@@ -368,6 +404,8 @@ __global__ __launch_bounds__(WM * 64, (WM == 4 && KS == 3) ? 3 : ((WM == 8 && KS
           // pixels (every VALU instruction delays the matrix pipe); positions outside the conv map are -inf here
           v = acc[i][j];
           if (!conv_inner) {
+            asm volatile("" ::: "memory");                                // keep the border path a real scalar branch: as a select
+                                                                          // it cost 16 v_cndmask per tile on EVERY tile
             if (!inside) v = (f32x4){-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
           }
         }
