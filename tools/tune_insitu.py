@@ -86,8 +86,8 @@ def main():
         wgrad_keys = {}                              # 'G:taps:N:C:npix' -> split the heuristic (or the table) gives today
         real_split = ops.wgrad_split
 
-        def rec_split(N, C, taps, Bq, H, W, wino=None):
-            S, stride = real_split(N, C, taps, Bq, H, W, wino)
+        def rec_split(N, C, taps, Bq, H, W, wino=None, **kw):
+            S, stride = real_split(N, C, taps, Bq, H, W, wino, **kw)
             wgrad_keys.setdefault(f'G:{taps}:{N}:{C}:{Bq * H * W}', S)
             return S, stride
         ops.choose_cfg, ops.choose_wino_cfg, ops.wgrad_split = rec_choose, rec_wino, rec_split
