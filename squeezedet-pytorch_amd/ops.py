@@ -373,6 +373,24 @@ def _det_buffers(B, K, device, A=None):
     return bufs
 
 
+def det_buffers_packed(B, K, device, A=None):
+    """The same five result tensors as views of ONE allocation (16-byte aligned sections), so that a whole batch's compact
+    detections leave the GPU with a single device-to-host copy.  -> (bufs as ``_det_buffers``, flat uint8 tensor)."""
+    sizes = [(B, torch.int32), (B * K, torch.int64), (B * K, torch.float32), (B * K * 4, torch.float32), (B * K, torch.int32)]
+    shapes = [(B,), (B, K), (B, K), (B, K, 4), (B, K)]
+    offs, off = [], 0
+    for n, dt in sizes:
+        off = -(-off // 16) * 16
+        offs.append(off)
+        off += n * torch.empty(0, dtype=dt).element_size()
+    flat = torch.zeros(-(-off // 16) * 16, device=device, dtype=torch.uint8)
+    bufs = tuple(flat[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt).view(shp)
+                 for o, (n, dt), shp in zip(offs, sizes, shapes))
+    if A is not None:
+        bufs = bufs + (_det_workspace(B, A, device),)
+    return bufs, flat
+
+
 def _det_workspace(B, A, device):
     """Placeholder for the ABI's ``keys_ws`` argument (the one-launch detect kernel keeps its keys in LDS)."""
     return torch.zeros(4, device=device, dtype=torch.int32)

@@ -415,3 +415,21 @@ def test_filter_nms_boundary_gpu():
         assert idx[0, :n].cpu().tolist() == want, (thr, idx[0, :n].cpu().tolist())
         d = oracle.filter_detections(ids[0], sc[0], bx[0], 64, thr, 0.3)
         assert list(d['anchor_idx']) == want
+
+
+def test_detect_into_packed_result_buffer():
+    """ops.det_buffers_packed: the five result tensors as views of ONE allocation (what bench.py's end-to-end leg copies back with
+    a single D2H): the fused detect kernel writes the same results into them as into separately allocated tensors."""
+    from squeezedet_pytorch_amd import ops
+    cfg = sqd.make_cfg()
+    pred = _decode_pred().cuda()
+    anc = torch.from_numpy(cfg.anchors).float().cuda()
+    plain = ops.detect(pred, anc, cfg.input_size, cfg.num_classes, cfg.keep_top_k, cfg.nms_thresh, cfg.score_thresh)
+    bufs, flat = ops.det_buffers_packed(pred.shape[0], cfg.keep_top_k, pred.device, cfg.num_anchors)
+    packed = ops.detect(pred, anc, cfg.input_size, cfg.num_classes, cfg.keep_top_k, cfg.nms_thresh, cfg.score_thresh, out=bufs)
+    assert int(plain[0].sum()) > 0
+    for a, b in zip(plain, packed):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    host = flat.cpu()                                            # one copy carries everything
+    assert torch.equal(host[:4 * pred.shape[0]].view(torch.int32), plain[0].cpu()) and flat.numel() % 16 == 0
+    assert all(t.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for t in bufs[:5])
