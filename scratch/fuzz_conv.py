@@ -102,6 +102,41 @@ while time.time() - t0 < budget:
         if not (e3 <= 1e-4 * sc and e4 <= 1e-4 * max(1.0, bg.grad.abs().max().item())):
             print('WGRAD MISMATCH', dict(taps=taps, B=B, H=H, W=W, C=C, N=N, e3=e3, e4=e4, sc=sc)); sys.exit(1)
         n_ok += 1
+# Fused squeeze backward (sqd_squeeze_bwd: weight-gradient slabs + data gradient + ReLU mask in one launch) and the pool whose
+# arg-max codes carry the ReLU mask: random shapes (partial pixel blocks, channel counts off the 64-channel tile)
+ts = time.time()
+nsq = 0
+while time.time() - ts < max(2.0, 0.1 * budget):
+    B = int(rs.randint(1, 4)); H = int(rs.choice([1, 3, 5, 8, 13, 24, 31])); W = int(rs.choice([1, 3, 7, 16, 17, 33, 47, 78]))
+    C = int(rs.choice([4, 16, 48, 64, 68, 128, 200, 256, 384])); N = int(rs.choice([4, 16, 24, 32, 48, 64, 72, 96]))
+    mask = bool(rs.randint(0, 2))
+    pre = torch.randn(B, C, H, W, requires_grad=True)
+    xin = torch.relu(pre) if mask else pre
+    w = (torch.randn(N, C, 1, 1) * (1.0 / C) ** 0.5).requires_grad_(True); b = (torch.randn(N) * 0.1).requires_grad_(True)
+    dy = torch.randn(B, N, H, W)
+    F.conv2d(xin, w, b).backward(dy)
+    S, stride = ops.wgrad_split(N, C, 1, B, H, W, fused_dgrad=True)
+    slab = torch.full((S * stride,), float('nan')).cuda(); dx = torch.full((B, H, W, C), float('nan')).cuda()
+    ops.squeeze_bwd(nhwc(dy).cuda(), nhwc(xin.detach()).cuda(), w.detach().cuda().contiguous(), slab, dx, relu_mask=mask)
+    red = slab.view(S, stride).double().sum(0).cpu()
+    e1 = (red[:N * C].view(N, C, 1, 1) - w.grad.double()).abs().max().item(); e2 = (red[N * C:] - b.grad.double()).abs().max().item()
+    e3 = (dx.cpu() - nhwc(pre.grad)).abs().max().item()
+    if not (e1 <= 1e-4 * max(1.0, w.grad.abs().max().item()) and e2 <= 1e-4 * max(1.0, b.grad.abs().max().item())
+            and e3 <= 2e-5 * max(1.0, pre.grad.abs().max().item()) + 1e-5):
+        print('SQUEEZE_BWD MISMATCH', dict(B=B, H=H, W=W, C=C, N=N, mask=mask, e1=e1, e2=e2, e3=e3)); sys.exit(1)
+    n_ok += 1; nsq += 1
+    if H >= 3 and W >= 3 and C % 4 == 0:
+        prep = torch.randn(B, C, H, W, requires_grad=True)
+        pooled = F.max_pool2d(torch.relu(prep), 3, 2, ceil_mode=True)
+        dyp = torch.randn(*pooled.shape); pooled.backward(dyp)
+        xg = nhwc(torch.relu(prep.detach())).cuda()
+        am = torch.empty(*nhwc(pooled.detach()).shape, dtype=torch.uint8).cuda()
+        yg = ops.maxpool(xg, argmax=am, relu_codes=True)
+        dxp = ops.maxpool_bwd(nhwc(dyp).cuda(), am, (H, W))
+        if not (torch.equal(yg.cpu(), nhwc(pooled.detach())) and (dxp.cpu() - nhwc(prep.grad)).abs().max().item() <= 1e-6):
+            print('POOL RELU-CODES MISMATCH', dict(B=B, H=H, W=W, C=C)); sys.exit(1)
+        n_ok += 1
+print(f'  .. {nsq} fused squeeze-backward cases ok', flush=True)
 # Fire bridges (one launch for expand pair + next squeeze, optionally through the max pool): random small-C Fire shapes
 tb = time.time()
 nb = 0
