@@ -62,7 +62,8 @@ int sqd_conv_wgrad(const float* dy, const float* x, float* slab, float* dw, floa
  * as triggered by loss.backward(), src/engine/trainer.py:47): the weight / bias gradient slabs of sqd_conv_wgrad (taps = 1,
  * partial slabs only: reduce with sqd_wgrad_reduce_batched) and the data gradient
  * dx[p][dx_coff + c] = sum_n dy[p][dy_coff + n] * w[n][c], zeroed where relu_mask != 0 and x[p][x_coff + c] <= 0 (x = the
- * squeeze's forward input when that is a ReLU output).  w_oihw: the layer's own [N][C][1][1] parameter.  N <= 96.
+ * squeeze's forward input when that is a ReLU output).  w_oihw: the layer's own [N][C][1][1] parameter.  N <= 128.  Also serves
+ * Fire.expand1x1 (dy = the expand1x1 window of the Fire output's gradient, x = the squeeze output, relu_mask = 0).
  * S pixel-splits as in sqd_conv_wgrad with 64-channel in-tiles: slab = S * (N*C + N) floats. */
 int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_oihw, float* slab, float* dx, int B, int H, int W,
                     int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int dx_pitch, int dx_coff,

@@ -33,7 +33,7 @@ def _wgrad_layout(base, saved, B, H, W):
             continue
         _, cin, s, e1, e3 = layers[i]
         shp = saved[f'fire{i}'][2].shape
-        add(f'features.{i}.expand1x1', e1, s, 1, shp)
+        add(f'features.{i}.expand1x1', e1, s, 1, shp, fused=bool(getattr(base, 'fuse_squeeze_bwd', False)) and ops.squeeze_bwd_ok(e1, s))
         add(f'features.{i}.expand3x3', e3, s, 9, shp)
         add(f'features.{i}.squeeze', s, cin, 1, shp, fused=bool(getattr(base, 'fuse_squeeze_bwd', False)) and ops.squeeze_bwd_ok(s, cin))
     return entries, slots, off
@@ -134,12 +134,20 @@ def run_backbone_backward(base, saved, dpred):
         Bq, Hq, Wq, _ = out.shape
         npix = Bq * Hq * Wq
         pre = f'features.{i}.'
-        def expand_wgrads(dA=dA, sq=sq, e1=e1, e3=e3, s=s, pre=pre):
-            ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
+        fused_e1 = bool(wb.fused.get(pre + 'expand1x1'))
+
+        def expand_wgrads(dA=dA, sq=sq, e1=e1, e3=e3, s=s, pre=pre, fused_e1=fused_e1):
+            if not fused_e1:
+                ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
             ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
         on_side(expand_wgrads, dA, sq)
         dSq = torch.empty_like(sq)
-        ops.conv(dA, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, e1, s, npix), 'dgrad'), dSq, 0)
+        if fused_e1:
+            # narrow expand1x1 (N <= 128: the first four Fires): weight-gradient slabs and the data gradient from ONE pass over the
+            # expand1x1 half of dA; the expand3x3 data gradient below accumulates onto it and applies the squeeze's ReLU mask
+            ops.squeeze_bwd(dA, sq, fire.expand1x1.weight, wb.slab(pre + 'expand1x1'), dSq, relu_mask=False, dy_coff=0, N=e1)
+        else:
+            ops.conv(dA, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, e1, s, npix), 'dgrad'), dSq, 0)
         base.dgrad3x3(f'{i}.expand3x3', fire.expand3x3, dA, e1, dSq, accumulate=True, ymask=sq)
         dIn = torch.empty_like(x_in)
         prev_is_fire = layers[i - 1][0] == 'fire'

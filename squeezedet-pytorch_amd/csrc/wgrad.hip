@@ -13,6 +13,7 @@
 // tiles whose pitch is = 16 (mod 32) floats so the two k-groups of a 32-lane half hit disjoint banks.
 // The bias gradient rides along as extra tiles with B = 1.
 #include "sqd_common.h"
+#include <type_traits>
 
 #ifndef SQD_WG9_TH
 #define SQD_WG9_TH 4
@@ -206,6 +207,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   typedef unsigned int wg_u32x4_t __attribute__((ext_vector_type(4)));
   __amdgpu_buffer_rsrc_t dxres;
   if (DG) dxres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dx + a.dx_coff + c0), 0, 0x7ffffff0, 0x00020000);
+  // block-invariant per-lane byte offsets of the data-gradient phase: dy row pieces (per 16-channel block j), transposed-weight row
+  // piece, x mask piece, store offset (out of range when the channel does not exist), pixel inside the block, tile exists
+  constexpr int DGN = DG ? DG_ST : 1;
+  int dg_d[DGN][DG ? TN : 1], dg_w[DGN], dg_m[DGN], dg_v[DGN], dg_px[DGN];
+  bool dg_live[DGN];
+  if constexpr (DG) {
+#pragma unroll
+    for (int it = 0; it < DG_ST; ++it) {
+      const int t = wave_s + 4 * it;
+      dg_live[it] = t < (PB / 16) * TC;
+      const int tt = dg_live[it] ? t : 0;
+      const int pt = tt / TC, ct = tt - pt * TC;
+      const int px = pt * 16 + lr;
+      const int swd = SWN ? ((px & 1) << 2) : 0, swx = SWC ? ((px & 1) << 2) : 0;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) dg_d[it][j] = (px * RN + ((4 * j + kq) ^ swd)) * 16;
+      dg_w[it] = ((ct * 16 + lr) * WP + 4 * kq) * 4;
+      dg_m[it] = (px * RC + ((4 * ct + kq) ^ swx)) * 16;
+      const int c = ct * 16 + 4 * kq;
+      dg_px[it] = dg_live[it] ? px : PB;                        // (a tile that does not exist never stores)
+      dg_v[it] = (c0 + c < a.C) ? (px * a.dx_pitch + c) * 4 : (int)0x80000000;
+    }
+  }
   int pb = blockIdx.x, buf = 0;
   bool first_block = true;
   if (pb < a.nblocks) dma_block(pb, 0);
@@ -286,39 +310,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
     if constexpr (DG) {
       // ---- data gradient of this pixel block for this workgroup's in-channels ----
-      constexpr int PT = PB / 16, NTILE = PT * TC;
-      static_assert(DG_ST == (NTILE + 3) / 4, "store count per wave and block");
+      // every per-lane LDS / store offset is block-invariant (dg_*, computed once before the loop); the input buffer is a
+      // compile-time offset inside each of the two copies of the phase, so the phase is reads at base + immediate, MFMAs, the
+      // mask selects and one store per tile
       const long long p0 = (long long)pb * PB;
       const unsigned soff = (unsigned)(p0 * a.dx_pitch * 4);    // (tensor < 4 GiB: checked by the launcher)
+      const int px_left = (int)((a.total_px - p0 < (long long)PB) ? (a.total_px - p0) : (long long)PB);   // valid pixels of this block
+      auto dgrad_phase = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
 #pragma unroll
-      for (int it = 0; it < DG_ST; ++it) {
-        const int t = wave_s + 4 * it;                        // (wave-uniform)
-        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int voff = (int)0x80000000;                           // out of range: the store is dropped
-        if (t < NTILE) {
-          const int pt = t / TC, ct = t - pt * TC;
-          const int px = pt * 16 + lr;
-          const int swd = SWN ? ((px & 1) << 2) : 0, swx = SWC ? ((px & 1) << 2) : 0;
-          const float* const drow = dyT + px * (RN * 4);
-          const float* const wrow = wtT + (ct * 16 + lr) * WP + 4 * kq;
+        for (int it = 0; it < DG_ST; ++it) {
+          f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (dg_live[it]) {                                    // (wave-uniform)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const f32x4 bq = *(const f32x4*)(drow + (((4 * j + kq) ^ swd) << 2));      // dy[px][16 j + 4 kq .. + 3]
-            const f32x4 aq = *(const f32x4*)(wrow + 16 * j);                             // w[16 j + 4 kq .. + 3][c]
-            o = mfma16(aq.x, bq.x, o); o = mfma16(aq.y, bq.y, o); o = mfma16(aq.z, bq.z, o); o = mfma16(aq.w, bq.w, o);
+            for (int j = 0; j < TN; ++j) {
+              const f32x4 bq = *(const f32x4*)((const char*)dyB + dg_d[it][j] + BUF * DSLOTS * 16);    // dy[px][16 j + 4 kq .. + 3]
+              const f32x4 aq = *(const f32x4*)((const char*)wtT + dg_w[it] + j * 64);                  // w[16 j + 4 kq .. + 3][c]
+              o = mfma16(aq.x, bq.x, o); o = mfma16(aq.y, bq.y, o); o = mfma16(aq.z, bq.z, o); o = mfma16(aq.w, bq.w, o);
+            }
+            if (a.dx_mask) {
+              const f32x4 m = *(const f32x4*)((const char*)xB + dg_m[it] + BUF * XSLOTS * 16);
+              o.x = m.x > 0.f ? o.x : 0.f; o.y = m.y > 0.f ? o.y : 0.f; o.z = m.z > 0.f ? o.z : 0.f; o.w = m.w > 0.f ? o.w : 0.f;
+            }
           }
-          if (a.dx_mask) {
-            const f32x4 m = *(const f32x4*)(xT + px * (RC * 4) + (((4 * ct + kq) ^ swx) << 2));
-            o.x = m.x > 0.f ? o.x : 0.f; o.y = m.y > 0.f ? o.y : 0.f; o.z = m.z > 0.f ? o.z : 0.f; o.w = m.w > 0.f ? o.w : 0.f;
-          }
-          const int c = ct * 16 + 4 * kq;
-          if (p0 + px < a.total_px && c0 + c < a.C) voff = (px * a.dx_pitch + c) * 4;
+          const int voff = (dg_px[it] < px_left) ? dg_v[it] : (int)0x80000000;      // out of range: the store is dropped
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wg_u32x4_t, o), dxres, voff, (int)soff, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1" ::: "memory");                 // (MUBUF store with an SGPR soffset: write-after-read hazard, see conv_wino.hip)
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wg_u32x4_t, o), dxres, voff, (int)soff, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 1" ::: "memory");                 // (MUBUF store with an SGPR soffset: write-after-read hazard, see conv_wino.hip)
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      if (buf) dgrad_phase(std::integral_constant<int, 1>{}); else dgrad_phase(std::integral_constant<int, 0>{});
     }
     buf ^= 1;
   }
@@ -483,7 +505,9 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
 // as triggered by loss.backward(), src/engine/trainer.py:47): the weight / bias gradient slabs exactly as sqd_conv_wgrad writes
 // them (taps = 1, dw == NULL convention: the caller reduces the slabs) AND the data gradient
 //   dx[p][dx_coff + c] = (x[p][x_coff + c] > 0 or !relu_mask) ? sum_n dy[p][dy_coff + n] * w[n][c] : 0
-// for every pixel.  w: the squeeze weight itself, OIHW [N][C][1][1] (no packed copy).  N <= 96 (one out-channel group).
+// for every pixel.  w: the layer's weight itself, OIHW [N][C][1][1] (no packed copy).  N <= 128 (one out-channel group).  The same
+// launch serves a Fire's expand1x1 where its width allows (dy = the e1 window of the Fire's output gradient, x = the squeeze
+// output, relu_mask = 0: the expand3x3 data gradient that accumulates onto dx applies the mask).
 // S as in sqd_conv_wgrad; the slab split uses 64-channel in-tiles (host: tiles.wgrad_split(..., fused_dgrad=True)).
 extern "C" int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_oihw, float* slab, float* dx, int B, int H, int W,
                                int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int dx_pitch, int dx_coff,
@@ -495,7 +519,7 @@ extern "C" int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_o
   SQD_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0);
   SQD_CHECK_ARG((long long)B * H * W * dx_pitch * 4 < (1ll << 32) - (1ll << 24));       // 32-bit SGPR byte offset of a pixel block
   SQD_CHECK_ARG((long long)32 * dx_pitch * 4 < (1ll << 30));                             // per-lane byte offsets inside a block
-  if (N > 96) return SQD_ERR_UNSUPPORTED;
+  if (N > 128) return SQD_ERR_UNSUPPORTED;
   WgradArgs a;
   a.dy = dy; a.x = x; a.slab = slab; a.B = B; a.H = H; a.W = W;
   a.N = N; a.dy_pitch = dy_pitch; a.dy_coff = dy_coff; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
@@ -503,7 +527,7 @@ extern "C" int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_o
   a.slab_stride = (long long)N * C + N;
   a.w = w_oihw; a.dx = dx; a.dx_pitch = dx_pitch; a.dx_coff = dx_coff; a.dx_mask = relu_mask;
   hipStream_t s = (hipStream_t)stream;
-  const int tn = N > 64 ? 6 : sqd_cdiv(N, 16);
+  const int tn = N > 96 ? 8 : (N > 64 ? 6 : sqd_cdiv(N, 16));
   const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
   int rc = SQD_ERR_UNSUPPORTED;
 #define SQD_SB_CASE(TNv, TCv) if (tn == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, 2, true>(a, S, s);
@@ -512,6 +536,7 @@ extern "C" int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_o
   SQD_SB_CASE(3, 1) SQD_SB_CASE(3, 2) SQD_SB_CASE(3, 3) SQD_SB_CASE(3, 4)
   SQD_SB_CASE(4, 1) SQD_SB_CASE(4, 2) SQD_SB_CASE(4, 3) SQD_SB_CASE(4, 4)
   SQD_SB_CASE(6, 1) SQD_SB_CASE(6, 2) SQD_SB_CASE(6, 3) SQD_SB_CASE(6, 4)
+  SQD_SB_CASE(8, 1) SQD_SB_CASE(8, 2) SQD_SB_CASE(8, 3) SQD_SB_CASE(8, 4)
 #undef SQD_SB_CASE
   return rc;
 }

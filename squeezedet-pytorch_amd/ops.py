@@ -483,15 +483,20 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
 
 def squeeze_bwd_ok(N, C):
     """Whether ``squeeze_bwd`` can run a (C -> N) 1x1 layer: all N out-channels in one group."""
-    return N % 4 == 0 and C % 4 == 0 and N <= 96
+    return N % 4 == 0 and C % 4 == 0 and N <= 128
 
 
-def squeeze_bwd(dy, x, weight, slab, dx, relu_mask):
-    """A Fire squeeze's backward in ONE launch: the weight / bias gradient slabs (as ``conv_wgrad(..., slab=...)`` writes them; ``slab``
-    from a ``WgradBatch`` entry flagged fused) and the data gradient dx = dy . W, zeroed where ``relu_mask`` and x <= 0.  dy [B,H,W,N]
-    (already masked), x / dx [B,H,W,C], weight: the layer's OIHW [N,C,1,1] parameter."""
+def squeeze_bwd(dy, x, weight, slab, dx, relu_mask, dy_coff=0, N=None):
+    """A 1x1 layer's backward in ONE launch: the weight / bias gradient slabs (as ``conv_wgrad(..., slab=...)`` writes them; ``slab``
+    from a ``WgradBatch`` entry flagged fused) and the data gradient dx = dy . W, zeroed where ``relu_mask`` and x <= 0.  dy [B,H,W,.]
+    (already masked; channel window ``[dy_coff, dy_coff + N)``, default all of it), x / dx [B,H,W,C], weight: the layer's OIHW
+    [N,C,1,1] parameter.  Fire.squeeze (relu_mask = the previous layer is a Fire) and, where N <= 128, Fire.expand1x1 (dy = the
+    expand1x1 window of the Fire output's gradient, x = the squeeze output, relu_mask False)."""
     _check_nhwc(dy, 'dy'); _check_nhwc(x, 'x'); _check_nhwc(dx, 'dx')
-    B, H, W, N = dy.shape
+    B, H, W, dyp = dy.shape
+    N = dyp - dy_coff if N is None else int(N)
+    if dy_coff < 0 or dy_coff % 4 or dy_coff + N > dyp:
+        raise ValueError('squeeze_bwd: dy channel window out of range')
     C = x.shape[3]
     if tuple(x.shape[:3]) != (B, H, W) or tuple(dx.shape) != tuple(x.shape):
         raise ValueError('squeeze_bwd: dy, x and dx disagree on B,H,W / C')
@@ -505,7 +510,7 @@ def squeeze_bwd(dy, x, weight, slab, dx, relu_mask):
     npix = B * H * W
     br = _Bracket('squeeze_bwd', f'sqbwd C{C} N{N} {H}x{W}', 4.0 * npix * N * C,
                   4.0 * (npix * (2 * C + N) + N * C + 2 * S * stride)) if timing._timer is not None else None
-    rc = nat.lib().sqd_squeeze_bwd(nat.ptr(dy), nat.ptr(x), nat.ptr(weight.detach()), nat.ptr(slab), nat.ptr(dx), B, H, W, N, N, 0, C, C, 0,
+    rc = nat.lib().sqd_squeeze_bwd(nat.ptr(dy), nat.ptr(x), nat.ptr(weight.detach()), nat.ptr(slab), nat.ptr(dx), B, H, W, N, dyp, dy_coff, C, C, 0,
                                    C, 0, int(bool(relu_mask)), S, nat.stream_handle(dy.device))
     nat.check(rc, 'sqd_squeeze_bwd')
     if br is not None:

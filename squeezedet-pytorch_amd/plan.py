@@ -160,9 +160,14 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
             plan.append(('maxpool_bwd', f'poolbwd C{Ci} {Hi}x{Wi}'))
             continue
         _, cin, s, e1, e3 = l
-        plan.append(_wgrad(batch, Hi, Wi, e1, s, 1))
+        fused_e1 = fuse_squeeze_bwd and ops.squeeze_bwd_ok(e1, s)
+        if not fused_e1:
+            plan.append(_wgrad(batch, Hi, Wi, e1, s, 1))
         plan.append(_wgrad(batch, Hi, Wi, e3, s, 9))
-        plan.append(_conv1x1(batch, Hi, Wi, e1, s))                                   # expand1x1 data gradient
+        if fused_e1:
+            plan.append(('squeeze_bwd', f'sqbwd C{s} N{e1} {Hi}x{Wi}'))                # expand1x1 weight + data gradient, one launch
+        else:
+            plan.append(_conv1x1(batch, Hi, Wi, e1, s))                               # expand1x1 data gradient
         plan.append(_conv3x3(batch, Hi, Wi, e3, s, use_winograd))                     # expand3x3 data gradient (accumulates)
         if fuse_squeeze_bwd and ops.squeeze_bwd_ok(s, cin):
             plan.append(('squeeze_bwd', f'sqbwd C{cin} N{s} {Hi}x{Wi}'))              # squeeze weight + data gradient, one launch

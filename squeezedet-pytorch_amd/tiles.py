@@ -327,8 +327,8 @@ def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False):
             S = max(1, min(ngroups, int(tuned)))
         return S, N * taps * C + N
     if fused_dgrad:
-        if taps != 1 or N > 96:
-            raise ValueError('fused squeeze backward: 1x1 layers with N <= 96')
+        if taps != 1 or N > 128:
+            raise ValueError('fused 1x1 backward: 1x1 layers with N <= 128')
         nblocks = -(-(B * H * W) // 32)
         groups = -(-C // 64)
         import os

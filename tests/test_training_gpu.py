@@ -468,3 +468,26 @@ def test_backward_with_and_without_fused_squeeze_bwd_agree():
     for n in grads[True]:
         a, b = grads[True][n], grads[False][n]
         assert (a - b).abs().max().item() <= 2e-5 * max(float(b.abs().max()), 1e-3), n
+
+
+@pytest.mark.parametrize("s,e1,B,H,W", [(16, 64, 2, 24, 39), (32, 128, 2, 13, 21), (16, 128, 1, 7, 9)])
+def test_fused_1x1_backward_serves_expand1x1(s, e1, B, H, W):
+    """The same launch as a Fire's expand1x1 backward (N = e1 <= 128): dy = the expand1x1 WINDOW of the Fire output's gradient
+    (pitch 2 e1), x = the squeeze output, no mask here (the expand3x3 data gradient accumulates onto dx and masks)."""
+    from squeezedet_pytorch_amd import ops
+    sq = _rand(B, s, H, W, seed=51).requires_grad_(True)
+    w = _rand(e1, s, 1, 1, seed=52, scale=(2.0 / s) ** 0.5).requires_grad_(True)
+    b = _rand(e1, seed=53, scale=0.1).requires_grad_(True)
+    y = F.conv2d(sq, w, b)
+    dy = _rand(*y.shape, seed=54)
+    y.backward(dy)
+    dA = torch.randn(B, H, W, 2 * e1, device='cuda')              # [expand1x1 | expand3x3] halves of the Fire output's gradient
+    dA[..., :e1] = _nhwc(dy).cuda()
+    S, stride = ops.wgrad_split(e1, s, 1, B, H, W, fused_dgrad=True)
+    slab = torch.full((S * stride,), float('nan'), device='cuda')
+    dx = torch.full((B, H, W, s), float('nan'), device='cuda')
+    ops.squeeze_bwd(dA, _nhwc(sq.detach()).cuda(), w.detach().cuda().contiguous(), slab, dx, relu_mask=False, dy_coff=0, N=e1)
+    red = slab.view(S, stride).double().sum(0).cpu()
+    assert (red[:e1 * s].view(e1, s, 1, 1) - w.grad.double()).abs().max().item() <= 2e-4 * max(1.0, float(w.grad.abs().max()))
+    assert (red[e1 * s:] - b.grad.double()).abs().max().item() <= 2e-4 * max(1.0, float(b.grad.abs().max()))
+    assert (dx.cpu() - _nhwc(sq.grad)).abs().max().item() <= 2e-5 * max(1.0, float(sq.grad.abs().max()))
