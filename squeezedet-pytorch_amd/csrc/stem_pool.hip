@@ -11,6 +11,7 @@
 // and stores 16 bytes (the stem output is the largest tensor of the network: 30.7 MB per image).
 #include "sqd_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 struct StemArgs {
   const float* x;     // [B][3][Hin][Win]
@@ -516,6 +517,275 @@ static int launch_stem_pool(StemPoolArgs a, hipStream_t s) {
   return a.amax ? launch_stem_pool_t<KS, PAD, NT, true, WM>(a, s) : launch_stem_pool_t<KS, PAD, NT, false, WM>(a, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-autonomous fused stem (round 3, the 3x3 / 64-channel stem of src/model/squeezedet.py:34-36 at inference): same
+// arithmetic as stem_pool_kernel<3,1,4,false,8> -- a k-ordered fp32 MFMA chain from 0, max over the window, THEN bias and
+// ReLU -- so the two kernels agree bit for bit, but no workgroup-level cooperation at all:
+//   * a WAVE owns a pooled tile of PH rows x 7 columns = a conv patch of (2 PH + 1) rows x 15 columns: one MFMA column
+//     block (16 conv columns, the 16th unused) per conv row, 4 channel blocks -> 4 (2 PH + 1) accumulators;
+//   * its NCHW input patch ((4 PH + 3) rows x 36 floats x 3 planes, 16-byte slots: the patch starts 4 floats left of the
+//     first tap so that every row segment is 16-byte aligned in a 4-float-aligned image row) arrives by buffer-resource
+//     LDS-DMA in a wave-private double buffer, retired by a counted s_waitcnt vmcnt; slots outside the image carry an
+//     out-of-range offset and are zero-filled by the hardware (the convolution's padding);
+//   * im2col = the LDS read address of the B operand (per-lane base + immediates), weights in registers;
+//   * the 3x3 / stride-2 pool runs in REGISTERS: vertical max = v_max3 across the accumulators of three conv rows (same
+//     lane), horizontal max = two v_max_f32 with DPP row_shl:1 / row_shl:2 operands (lane = conv column), bias + ReLU on
+//     the pooled values, one 16-byte store per (pooled row, channel block) from the 7 x 4 lanes that hold a pooled pixel.
+// The workgroup kernel above spends 7700 cycles per tile of which 1792 issue MFMAs: two workgroup barriers per tile and
+// the conv-patch round trip through LDS into the pool; here nothing waits for another wave.
+// Needs Win % 4 == 0 and a 16-byte aligned image (else the launcher keeps the workgroup kernel).
+// ---------------------------------------------------------------------------------------------
+struct StemWaveArgs {
+  const float* x; const float* w; const float* bias; float* y;
+  int B, Hin, Win, Ho, Wo, Hp, Wp;
+  int tiles_x, tiles_y, ntiles;
+  unsigned tiles_x_m, tiles_y_m;
+};
+
+// CB = 1: one 16-column block per conv row, lane = conv column, 7 pooled columns per tile (lanes 0, 2, .., 12 end with a pooled
+// pixel).  CB = 2: TWO column blocks per conv row, split by column PARITY -- block E holds conv columns 2m, block O columns 2m + 1
+// (im2col is only an LDS read address, so the split is free) -- so that lane m's window is E[m], O[m], E[m + 1]: one plain max,
+// one DPP max, and 15 of 16 lanes end with a pooled pixel (2.3x fewer vector instructions per pooled pixel than CB = 1; every
+// vector instruction delays the SIMD's matrix pipe).
+template <int PH, int CB>
+__global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int PW = CB == 1 ? 7 : 15, CH = 2 * PH + 1, IH = 2 * CH + 1;
+  constexpr int SL = CB == 1 ? 9 : 17, RP = 4 * SL;                                  // 16-byte slots / floats per patch row
+  constexpr int NSLOT = 3 * IH * SL, N_IT = (NSLOT + 63) / 64, BUFF = N_IT * 64 * 4; // floats per buffer
+  constexpr int K = 27, KSTEPS = 7, NT = 4, N = 64;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int NST = PH * NT;                                                       // stores per tile (always issued)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const bufW = smem + wave_s * (2 * BUFF + N);  // [2][BUFF] patch images + the wave's own copy of the bias
+  float* const biasW = bufW + 2 * BUFF;
+  typedef __attribute__((address_space(3))) const char* lds_cptr_t;   // 32-bit LDS addresses (a generic pointer costs two registers)
+
+  // ---- per-lane constants ----
+  int d_off[N_IT];                                     // byte offset of the lane's 16-byte slot from the patch origin
+#pragma unroll
+  for (int it = 0; it < N_IT; ++it) {
+    const int slot = it * 64 + lane;
+    const bool real = slot < NSLOT;
+    const int ci = slot / (IH * SL), rem = slot - ci * (IH * SL), row = rem / SL, k4 = rem - row * SL;
+    d_off[it] = real ? ((ci * a.Hin + row) * a.Win + 4 * k4) * 4 : (int)OOB;
+  }
+  float wreg[KSTEPS][NT];
+  lds_cptr_t bp[KSTEPS];                               // B operand of k-step s, conv row 0, (even) column block, buffer 0
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const int kk = 4 * s + g;
+    const int k = kk < K ? kk : 0;                     // the padded k multiplies a real (finite) tap with a zero weight
+    const int ci = k / 9, r9 = k - ci * 9, dy = r9 / 3, dx = r9 - dy * 3;
+    bp[s] = (lds_cptr_t)(bufW + (ci * IH + dy) * RP + 2 * CB * c + dx + 3);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wreg[s][j] = kk < K ? a.w[(j * 16 + c) * K + kk] : 0.f;
+  }
+  biasW[lane] = a.bias ? a.bias[lane] : 0.f;           // read back by this wave only (epilogue): no barrier
+  const f32x4* const biasL = (const f32x4*)(biasW + 4 * g);
+  // the patch origin (input row 4 PH ty - 1, column 4 PW tx - 4) is never negative relative to this base
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - (a.Win + 4)), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0x7ffffff0, 0x00020000);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  auto store16 = [&](f32x4 v, int voff, int soff) {    // (MUBUF store + SGPR soffset write-after-read hazard: see conv_wino.hip)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yres, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // lanes that end up with a pooled pixel: conv columns 0, 2, .., 12 (CB = 1) / pooled columns 0..14 (CB = 2)
+  const bool out_lane = CB == 1 ? ((c & 1) == 0 && c < 2 * PW) : (c < PW);
+  const int pcol = CB == 1 ? (c >> 1) : c;
+  const int o_voff = out_lane ? (pcol * N + 4 * g) * 4 : (int)OOB;
+
+  struct Tile { int ty, tx, inner; unsigned soff, osoff; };
+  auto tile_at = [&](int t) {
+    Tile q;
+    const int t1 = a.tiles_x_m ? (int)__umulhi((unsigned)t, a.tiles_x_m) : t;
+    q.tx = t - t1 * a.tiles_x;
+    const int b = a.tiles_y_m ? (int)__umulhi((unsigned)t1, a.tiles_y_m) : t1;
+    q.ty = t1 - b * a.tiles_y;
+    const int iy0 = 4 * PH * q.ty - 1, ix0 = 4 * PW * q.tx - 4;
+    q.soff = (unsigned)(((b * 3 * a.Hin + 4 * PH * q.ty) * a.Win + 4 * PW * q.tx) * 4);
+    q.inner = iy0 >= 0 && iy0 + IH <= a.Hin && ix0 >= 0 && ix0 + RP <= a.Win;
+    q.osoff = (unsigned)((((b * a.Hp + q.ty * PH) * a.Wp + q.tx * PW) * N) * 4);
+    return q;
+  };
+  auto dma_in = [&](const Tile q, int buf) {
+    const int iy0 = 4 * PH * q.ty - 1, ix0 = 4 * PW * q.tx - 4;
+#pragma unroll
+    for (int it = 0; it < N_IT; ++it) {
+      int off = d_off[it];
+      if (!q.inner) {                                  // uniform: border tile (the slot's row / column are recomputed here only)
+        const int slot = it * 64 + lane;
+        const int ci = slot / (IH * SL), rem = slot - ci * (IH * SL), row = rem / SL, k4 = rem - row * SL;
+        const bool ok = slot < NSLOT && (unsigned)(iy0 + row) < (unsigned)a.Hin && (unsigned)(ix0 + 4 * k4) < (unsigned)a.Win;
+        off = ok ? off : (int)OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (stem_lds_ptr_t)(bufW + buf * BUFF + it * 256), 16, off, (int)q.soff, 0, 0);
+    }
+  };
+
+  // tile walk: the four waves of a workgroup take four neighbouring tiles, the workgroups of one XCD a contiguous run
+  const int tstride = (int)gridDim.x * 4;
+  int tile = sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * 4 + wave_s;
+  if (tile >= a.ntiles) return;                        // (no barrier anywhere in this kernel)
+  Tile cur = tile_at(tile);
+  dma_in(cur, 0);
+  int buf = 0;
+  bool first = true;
+  for (;;) {
+    const int ntile = tile + tstride;
+    const bool has_next = ntile < a.ntiles;
+    const Tile nxt = tile_at(has_next ? ntile : tile);
+    // this tile's patch has landed: everything but the previous tile's NST stores (issued after the patch request) is done
+    __builtin_amdgcn_sched_barrier(0);
+    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    first = false;
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) dma_in(nxt, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- conv patch on the matrix cores: conv row r = CB 16-column blocks x 4 channel blocks ----
+    f32x4 acc[CH][CB][NT];
+    auto mfma_phase = [&](auto bufc) {
+      constexpr int BO = decltype(bufc)::value * BUFF * 4;
+      float bf[2][CB][KSTEPS];
+      auto load_row = [&](int r) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int s = 0; s < KSTEPS; ++s) bf[r & 1][cb][s] = *(__attribute__((address_space(3))) const float*)(bp[s] + BO + r * (2 * RP * 4) + cb * 8);
+      };
+      load_row(0);
+#pragma unroll
+      for (int r = 0; r < CH; ++r) {
+        if (r + 1 < CH) load_row(r + 1);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[r][cb][j] = mfma16(wreg[s][j], bf[r & 1][cb][s], s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[r][cb][j]);
+      }
+    };
+    if (buf) mfma_phase(std::integral_constant<int, 1>{}); else mfma_phase(std::integral_constant<int, 0>{});
+
+    // ---- conv positions outside the feature map are -inf for the pool (border tiles only) ----
+    const int cy0 = 2 * PH * cur.ty, cx0 = 2 * PW * cur.tx;
+    const int py0 = PH * cur.ty, px0 = PW * cur.tx;
+    int voff = o_voff;
+    if (!(cy0 + CH <= a.Ho && cx0 + 16 * CB <= a.Wo && px0 + PW <= a.Wp)) {      // uniform
+      const float ninf = -__builtin_inff();
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const bool col_out = cx0 + (CB == 1 ? c : 2 * c + cb) >= a.Wo;
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+          const bool out = col_out || cy0 + r >= a.Ho;
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            if (out) acc[r][cb][j] = (f32x4){ninf, ninf, ninf, ninf};
+        }
+      }
+      voff = (out_lane && px0 + pcol < a.Wp) ? o_voff : (int)OOB;
+    }
+    // ---- pool in registers, bias + ReLU behind it, stores (always issued: rows / lanes without a pixel go out of range) ----
+    auto vmax3 = [&](const f32x4 r0, const f32x4 r1, const f32x4 r2) {
+      f32x4 v;
+      asm volatile("v_max3_f32 %0, %4, %8, %12\n\tv_max3_f32 %1, %5, %9, %13\n\tv_max3_f32 %2, %6, %10, %14\n\tv_max3_f32 %3, %7, %11, %15"
+                   : "=&v"(v.x), "=&v"(v.y), "=&v"(v.z), "=&v"(v.w)
+                   : "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w),
+                     "v"(r2.x), "v"(r2.y), "v"(r2.z), "v"(r2.w));
+      return v;
+    };
+#pragma unroll
+    for (int i = 0; i < PH; ++i) {
+      const int vrow = (py0 + i < a.Hp) ? voff : (int)OOB;
+      const int soff = (int)(cur.osoff + (unsigned)(i * a.Wp * N * 4));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 h;
+        // (row_shl:n reads lane + n of the 16-lane row; lanes past its end read 0 and only feed lanes that hold no pooled pixel.
+        //  s_nop 1: a DPP operand may not be read in the two wait states behind the VALU write of that register.)
+        if constexpr (CB == 1) {
+          const f32x4 v = vmax3(acc[2 * i][0][j], acc[2 * i + 1][0][j], acc[2 * i + 2][0][j]);
+          asm volatile("s_nop 1\n\t"
+                       "v_max_f32_dpp %0, %4, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %1, %5, %5 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %2, %6, %6 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %3, %7, %7 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %0, %4, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %1, %5, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %2, %6, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %3, %7, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                       : "=&v"(h.x), "=&v"(h.y), "=&v"(h.z), "=&v"(h.w)
+                       : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        } else {
+          const f32x4 ve = vmax3(acc[2 * i][0][j], acc[2 * i + 1][0][j], acc[2 * i + 2][0][j]);
+          const f32x4 vo = vmax3(acc[2 * i][CB - 1][j], acc[2 * i + 1][CB - 1][j], acc[2 * i + 2][CB - 1][j]);
+          asm volatile("v_max_f32 %0, %4, %8\n\tv_max_f32 %1, %5, %9\n\tv_max_f32 %2, %6, %10\n\tv_max_f32 %3, %7, %11\n\t"
+                       "v_max_f32_dpp %0, %4, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %1, %5, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %2, %6, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                       "v_max_f32_dpp %3, %7, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                       : "=&v"(h.x), "=&v"(h.y), "=&v"(h.z), "=&v"(h.w)
+                       : "v"(ve.x), "v"(ve.y), "v"(ve.z), "v"(ve.w), "v"(vo.x), "v"(vo.y), "v"(vo.z), "v"(vo.w));
+        }
+        h += biasL[j * 4];
+        asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
+                     : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w));
+        store16(h, vrow + j * 64, soff);
+      }
+    }
+    if (!has_next) break;
+    tile = ntile; cur = nxt; buf ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+template <int PH, int CB>
+static int launch_stem_wave(StemWaveArgs a, hipStream_t s) {
+  constexpr int PW = CB == 1 ? 7 : 15, CH = 2 * PH + 1, IH = 2 * CH + 1, SL = CB == 1 ? 9 : 17;
+  constexpr int NSLOT = 3 * IH * SL, N_IT = (NSLOT + 63) / 64;
+  constexpr size_t lds = (size_t)4 * (2 * N_IT * 64 * 16 + 64 * 4);
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  a.tiles_x = sqd_cdiv(a.Wp, PW); a.tiles_y = sqd_cdiv(a.Hp, PH);
+  a.ntiles = a.B * a.tiles_x * a.tiles_y;
+  a.tiles_x_m = a.tiles_x > 1 ? (unsigned)(((1ull << 32) + a.tiles_x - 1) / a.tiles_x) : 0u;
+  a.tiles_y_m = a.tiles_y > 1 ? (unsigned)(((1ull << 32) + a.tiles_y - 1) / a.tiles_y) : 0u;
+  auto kern = stem_wave_kernel<PH, CB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SQD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  int dev = 0, cus = 256; hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const int wtiles = sqd_cdiv(a.ntiles, 4);                      // workgroup-sized runs of 4 tiles
+  const int per_wg = sqd_cdiv(wtiles, 2 * cus);
+  const int gx = sqd_cdiv(wtiles, per_wg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, s, a);
+  return sqd_launch_status();
+}
+
+// Which kernel runs the inference-mode 3x3 stem: 2 = stem_wave_kernel<2, 2> (default; in the bs=20 step 110.9 us against 154.6 us for
+// the workgroup kernel, gpurun_out/r03z), 3 / 4 = stem_wave_kernel<PH, 1> (117.4 / 113.5 us), 0 = the workgroup kernel
+// stem_pool_kernel.  SQD_STEM_WAVE in the environment overrides it (read per call: the parity tests switch it at run time).
+static int stem_wave_variant() {
+  const char* e = getenv("SQD_STEM_WAVE");
+  return e ? atoi(e) : 2;
+}
+
 // x NCHW [B,3,Hin,Win] -> y NHWC [B,Hp,Wp,N] = MaxPool(3,2,ceil)(ReLU(conv(x))); argmax may be NULL.
 extern "C" int sqd_stem_conv_relu_pool_fwd(const float* x, const float* w, const float* bias, float* y,
                                            unsigned char* argmax, int B, int Hin, int Win, int N, int ksize,
@@ -529,6 +799,13 @@ extern "C" int sqd_stem_conv_relu_pool_fwd(const float* x, const float* w, const
   SQD_CHECK_ARG(a.Ho >= 3 && a.Wo >= 3);
   a.Hp = (a.Ho - 3 + 1) / 2 + 1; a.Wp = (a.Wo - 3 + 1) / 2 + 1;
   hipStream_t s = (hipStream_t)stream;
+  const int variant = stem_wave_variant();
+  if (ksize == 3 && N == 64 && !argmax && variant && (Win & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
+      (long long)B * 3 * Hin * Win * 4 < (1ll << 31) && (long long)B * a.Hp * a.Wp * N * 4 < (1ll << 31)) {
+    StemWaveArgs wa;
+    wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.B = B; wa.Hin = Hin; wa.Win = Win; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Hp = a.Hp; wa.Wp = a.Wp;
+    return variant == 4 ? launch_stem_wave<4, 1>(wa, s) : (variant == 3 ? launch_stem_wave<3, 1>(wa, s) : launch_stem_wave<2, 2>(wa, s));
+  }
   if (ksize == 3 && N == 64) return launch_stem_pool<3, 1, 4>(a, s);
   if (ksize == 7 && N == 96) return launch_stem_pool<7, 3, 6>(a, s);
   return SQD_ERR_UNSUPPORTED;

@@ -169,6 +169,26 @@ def test_fused_stem_pool(k, N, H, W):
     assert torch.equal(ops.stem_pool(x.cuda(), w.cuda(), b.cuda()), y)
 
 
+@pytest.mark.parametrize("variant", ["2", "3", "4"])
+@pytest.mark.parametrize("H,W", [(64, 96), (50, 68), (37, 44), (12, 16), (9, 8), (130, 250 * 4)])
+def test_stem_wave_kernels(variant, H, W, monkeypatch):
+    """The wave-autonomous inference stem (stem_wave_kernel<PH, CB>, selected by SQD_STEM_WAVE) == features[0..2] of the reference
+    (src/model/squeezedet.py:34-36) and, bit for bit, the workgroup kernel it replaces: widths that are a multiple of 4 (its 16-byte
+    row DMA), maps smaller than one tile, borders on all four sides, partial last tiles."""
+    ops = _ops()
+    x = _rand(2, 3, H, W, seed=24)
+    w = _rand(64, 3, 3, 3, seed=25, scale=(2.0 / 27) ** 0.5)
+    b = _rand(64, seed=26, scale=0.1)
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w, b, stride=2, padding=1)), 3, 2, ceil_mode=True)
+    monkeypatch.setenv('SQD_STEM_WAVE', '0')
+    y_old = ops.stem_pool(x.cuda(), w.cuda(), b.cuda())
+    monkeypatch.setenv('SQD_STEM_WAVE', variant)
+    y = ops.stem_pool(x.cuda(), w.cuda(), b.cuda())
+    assert tuple(y.shape) == tuple(_nhwc(ref).shape)
+    assert (y.cpu() - _nhwc(ref)).abs().max().item() <= _tol(ref)
+    assert torch.equal(y, y_old)
+
+
 def test_fused_stem_pool_kitti_size_both_paths_agree():
     ops = _ops()
     x = _rand(3, 3, 384, 1248, seed=31).cuda()
