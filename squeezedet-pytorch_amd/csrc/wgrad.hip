@@ -13,6 +13,7 @@
 // tiles whose pitch is = 16 (mod 32) floats so the two k-groups of a 32-lane half hit disjoint banks.
 // The bias gradient rides along as extra tiles with B = 1.
 #include "sqd_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #ifndef SQD_WG9_TH
@@ -604,14 +605,7 @@ extern "C" int sqd_wgrad_reduce_batched_range(const void* descs_dev, int n, int 
 // Stem weight gradient: dW0[n][ci][ky][kx] = sum_p dY[p][n] * img[ci][2*py+ky-pad][2*px+kx-pad]
 // (no data gradient: the image needs none).  Same split-K slab scheme; slab layout [n][K] + [N].
 // ---------------------------------------------------------------------------------------------
-struct StemWgradArgs {
-  const float* dy; const float* img; float* slab;
-  const float* pooled; const unsigned char* amax;    // POOLED variant: dy is dPool [B][Hp][Wp][N]
-  int Hp, Wp;
-  int B, Hin, Win, Ho, Wo, N;
-  int tiles_x, tiles_y, nblocks;
-  long long slab_stride;
-};
+#include "stem_wgrad.h"
 
 // POOLED = true folds the backward of the fused ReLU + MaxPool(3,2,ceil) into the dY staging: the gradient of a
 // conv output is the sum of dPool over the (at most 4) windows whose argmax it is, masked by pooled > 0 (the
@@ -1021,6 +1015,14 @@ static int stem_wgrad_common(StemWgradArgs a, int ksize, int S, float* dw, float
   a.Ho = (a.Hin + 2 * pad - ksize) / 2 + 1; a.Wo = (a.Win + 2 * pad - ksize) / 2 + 1;
   a.Hp = (a.Ho - 3 + 1) / 2 + 1; a.Wp = (a.Wo - 3 + 1) / 2 + 1;
   int rc = SQD_ERR_UNSUPPORTED;
+  // the gather kernel (SQD_STEM_WGRAD_GATHER=0 in the environment keeps the dense kernel: A/B and the parity tests)
+  const char* env_g = getenv("SQD_STEM_WGRAD_GATHER");
+  if (pooled && ksize == 3 && a.N == 64 && !(env_g && env_g[0] == '0') && (a.Win & 3) == 0 && ((uintptr_t)a.img & 15) == 0 &&
+      (long long)a.B * 3 * a.Hin * a.Win * 4 < (1ll << 31) && (long long)a.B * a.Hp * a.Wp * a.N * 4 < (1ll << 31)) {
+    const int g = launch_stem_wgrad_gather(a, S, s);
+    if (g < 0) return SQD_ERR_LAUNCH;
+    S = g; rc = SQD_OK;
+  } else
   if (ksize == 3 && a.N == 64) rc = pooled ? launch_stem_wgrad_pooled<3, 1, 4>(a, S, s) : launch_stem_wgrad<3, 1, 4, false>(a, S, s);
   else if (ksize == 7 && a.N == 96) rc = pooled ? launch_stem_wgrad_pooled<7, 3, 6>(a, S, s) : launch_stem_wgrad<7, 3, 6, false>(a, S, s);
   if (rc != SQD_OK) return rc;
