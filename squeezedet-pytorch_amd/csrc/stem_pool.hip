@@ -536,7 +536,7 @@ static int launch_stem_pool(StemPoolArgs a, hipStream_t s) {
 // Needs Win % 4 == 0 and a 16-byte aligned image (else the launcher keeps the workgroup kernel).
 // ---------------------------------------------------------------------------------------------
 struct StemWaveArgs {
-  const float* x; const float* w; const float* bias; float* y;
+  const float* x; const float* w; const float* bias; float* y; uint8_t* amax;
   int B, Hin, Win, Ho, Wo, Hp, Wp;
   int tiles_x, tiles_y, ntiles;
   unsigned tiles_x_m, tiles_y_m;
@@ -547,7 +547,13 @@ struct StemWaveArgs {
 // (im2col is only an LDS read address, so the split is free) -- so that lane m's window is E[m], O[m], E[m + 1]: one plain max,
 // one DPP max, and 15 of 16 lanes end with a pooled pixel (2.3x fewer vector instructions per pooled pixel than CB = 1; every
 // vector instruction delays the SIMD's matrix pipe).
-template <int PH, int CB>
+// ARGMAX (training forward, CB = 2 only): additionally writes the uint8 code of the FIRST window position (row-major) holding the
+// pooled value, or 15 where the pooled value is not > 0 -- the codes of stem_pool_kernel<.., ARGMAX = true> / maxpool_fwd_kernel<true,
+// true>.  Positions are compared AFTER the bias add (rounding can create ties that the raw sums do not have); the ReLU needs no
+// compare of its own (a window whose maximum is <= 0 is code 15 whatever its arg-max).  Column E / O of the window: first row holding
+// the column maximum by two compares, candidates 3 dy + dx of the three columns (the third arrives by DPP from lane + 1) merged by
+// one v_min3.
+template <int PH, int CB, bool ARGMAX = false>
 __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PW = CB == 1 ? 7 : 15, CH = 2 * PH + 1, IH = 2 * CH + 1;
@@ -555,7 +561,8 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
   constexpr int NSLOT = 3 * IH * SL, N_IT = (NSLOT + 63) / 64, BUFF = N_IT * 64 * 4; // floats per buffer
   constexpr int K = 27, KSTEPS = 7, NT = 4, N = 64;
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int NST = PH * NT;                                                       // stores per tile (always issued)
+  constexpr int NST = PH * NT * (ARGMAX ? 2 : 1);                                    // stores per tile (always issued)
+  static_assert(!ARGMAX || CB == 2, "the arg-max epilogue is written for the parity-split layout");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
@@ -589,6 +596,9 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
   // the patch origin (input row 4 PH ty - 1, column 4 PW tx - 4) is never negative relative to this base
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - (a.Win + 4)), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0x7ffffff0, 0x00020000);
+  // codes: one byte per element; idle lanes carry 2^29 (a quarter of the fp32 streams' idle offset), past this resource's range
+  const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(ARGMAX ? (void*)a.amax : (void*)a.y), 0,
+                                                                        ARGMAX ? a.B * a.Hp * a.Wp * N : 0x7ffffff0, 0x00020000);
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   auto store16 = [&](f32x4 v, int voff, int soff) {    // (MUBUF store + SGPR soffset write-after-read hazard: see conv_wino.hip)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yres, voff, soff, 0);
@@ -696,6 +706,15 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
       voff = (out_lane && px0 + pcol < a.Wp) ? o_voff : (int)OOB;
     }
     // ---- pool in registers, bias + ReLU behind it, stores (always issued: rows / lanes without a pixel go out of range) ----
+    if constexpr (ARGMAX) {
+      // bias first: the arg-max is taken over the values the reference's pool sees (fl(conv + bias); the ReLU cannot reorder them)
+#pragma unroll
+      for (int r = 0; r < CH; ++r)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[r][cb][j] += biasL[j * 4];
+    }
     auto vmax3 = [&](const f32x4 r0, const f32x4 r1, const f32x4 r2) {
       f32x4 v;
       asm volatile("v_max3_f32 %0, %4, %8, %12\n\tv_max3_f32 %1, %5, %9, %13\n\tv_max3_f32 %2, %6, %10, %14\n\tv_max3_f32 %3, %7, %11, %15"
@@ -713,6 +732,43 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
         f32x4 h;
         // (row_shl:n reads lane + n of the 16-lane row; lanes past its end read 0 and only feed lanes that hold no pooled pixel.
         //  s_nop 1: a DPP operand may not be read in the two wait states behind the VALU write of that register.)
+        if constexpr (ARGMAX) {
+          const f32x4 e0 = acc[2 * i][0][j], e1 = acc[2 * i + 1][0][j], e2 = acc[2 * i + 2][0][j];
+          const f32x4 o0 = acc[2 * i][1][j], o1 = acc[2 * i + 1][1][j], o2 = acc[2 * i + 2][1][j];
+          const f32x4 ce = vmax3(e0, e1, e2), co = vmax3(o0, o1, o2);
+          unsigned codes = 0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const unsigned ke = e0[t] == ce[t] ? 0u : (e1[t] == ce[t] ? 3u : 6u);          // 3 dy of the first row holding the column maximum
+            const unsigned ko = o0[t] == co[t] ? 1u : (o1[t] == co[t] ? 4u : 7u);
+            // lane + 1's column maximum and its row code, as ISA: with __builtin_amdgcn_update_dpp the compiler (ROCm 7.2) kept ONE
+            // shifted copy of element 0's maximum and reused it for elements 1..3 of the quad (wrong pooled values in 3 of 4
+            // channels; found by the bit-equality check against the workgroup kernel)
+            float ce2; unsigned ke2;
+            asm volatile("s_nop 1\n\t"
+                         "v_mov_b32_dpp %0, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_mov_b32_dpp %1, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                         : "=&v"(ce2), "=&v"(ke2) : "v"(ce[t]), "v"(ke));
+            ke2 += 2u;
+            const float m = __builtin_fmaxf(__builtin_fmaxf(ce[t], co[t]), ce2);
+            const unsigned k0 = ce[t] == m ? ke : 9u, k1 = co[t] == m ? ko : 9u, k2 = ce2 == m ? ke2 : 9u;
+            unsigned code = k0 < k1 ? k0 : k1;
+            code = code < k2 ? code : k2;
+            code = m > 0.f ? code : 15u;
+            codes |= code << (8 * t);
+            h[t] = m;
+            __builtin_amdgcn_sched_barrier(0);       // one element at a time: interleaving the four chains costs ~30 registers (spills)
+          }
+          asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
+                       : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w));
+          store16(h, vrow + j * 64, soff);
+          // (vrow >> 2: byte offset of the lane's four codes; an idle lane's 2^31 becomes 2^29, past the code resource's range)
+          __builtin_amdgcn_raw_buffer_store_b32(codes, ares, (int)((unsigned)vrow >> 2) + j * 16, (int)((unsigned)soff >> 2), 0);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
         if constexpr (CB == 1) {
           const f32x4 v = vmax3(acc[2 * i][0][j], acc[2 * i + 1][0][j], acc[2 * i + 2][0][j]);
           asm volatile("s_nop 1\n\t"
@@ -750,17 +806,18 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
 #endif
 }
 
-template <int PH, int CB>
+template <int PH, int CB, bool ARGMAX = false>
 static int launch_stem_wave(StemWaveArgs a, hipStream_t s) {
   constexpr int PW = CB == 1 ? 7 : 15, CH = 2 * PH + 1, IH = 2 * CH + 1, SL = CB == 1 ? 9 : 17;
   constexpr int NSLOT = 3 * IH * SL, N_IT = (NSLOT + 63) / 64;
   constexpr size_t lds = (size_t)4 * (2 * N_IT * 64 * 16 + 64 * 4);
-  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  constexpr int OCC = 2;                                          // workgroups per CU (= waves per SIMD) the kernel is built for
+  static_assert(OCC * lds <= 160 * 1024, "OCC workgroups per CU");
   a.tiles_x = sqd_cdiv(a.Wp, PW); a.tiles_y = sqd_cdiv(a.Hp, PH);
   a.ntiles = a.B * a.tiles_x * a.tiles_y;
   a.tiles_x_m = a.tiles_x > 1 ? (unsigned)(((1ull << 32) + a.tiles_x - 1) / a.tiles_x) : 0u;
   a.tiles_y_m = a.tiles_y > 1 ? (unsigned)(((1ull << 32) + a.tiles_y - 1) / a.tiles_y) : 0u;
-  auto kern = stem_wave_kernel<PH, CB>;
+  auto kern = stem_wave_kernel<PH, CB, ARGMAX>;
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 64 * 1024 &&
@@ -772,7 +829,7 @@ static int launch_stem_wave(StemWaveArgs a, hipStream_t s) {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     cus = prop.multiProcessorCount;
   const int wtiles = sqd_cdiv(a.ntiles, 4);                      // workgroup-sized runs of 4 tiles
-  const int per_wg = sqd_cdiv(wtiles, 2 * cus);
+  const int per_wg = sqd_cdiv(wtiles, OCC * cus);
   const int gx = sqd_cdiv(wtiles, per_wg);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, s, a);
   return sqd_launch_status();
@@ -800,10 +857,13 @@ extern "C" int sqd_stem_conv_relu_pool_fwd(const float* x, const float* w, const
   a.Hp = (a.Ho - 3 + 1) / 2 + 1; a.Wp = (a.Wo - 3 + 1) / 2 + 1;
   hipStream_t s = (hipStream_t)stream;
   const int variant = stem_wave_variant();
-  if (ksize == 3 && N == 64 && !argmax && variant && (Win & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
+  if (ksize == 3 && N == 64 && variant && (Win & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
       (long long)B * 3 * Hin * Win * 4 < (1ll << 31) && (long long)B * a.Hp * a.Wp * N * 4 < (1ll << 31)) {
     StemWaveArgs wa;
-    wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.B = B; wa.Hin = Hin; wa.Win = Win; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Hp = a.Hp; wa.Wp = a.Wp;
+    wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.amax = argmax; wa.B = B; wa.Hin = Hin; wa.Win = Win; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Hp = a.Hp; wa.Wp = a.Wp;
+    // training forward: one pooled row per tile -- with two (variant 5) the arg-max epilogue's temporaries spill 42 registers, and
+    // every reload queues behind the next patch's DMA in vmcnt order
+    if (argmax) return variant == 5 ? launch_stem_wave<2, 2, true>(wa, s) : launch_stem_wave<1, 2, true>(wa, s);
     return variant == 4 ? launch_stem_wave<4, 1>(wa, s) : (variant == 3 ? launch_stem_wave<3, 1>(wa, s) : launch_stem_wave<2, 2>(wa, s));
   }
   if (ksize == 3 && N == 64) return launch_stem_pool<3, 1, 4>(a, s);
