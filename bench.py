@@ -517,12 +517,27 @@ def main():
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         ms = elapsed / args.steps * 1e3
+        # the upload alone (same pinned buffer, same copy stream, nothing else running): is the leg bound by the host link?
+        torch.cuda.synchronize()
+        ncopy = max(4, min(args.steps, 20))
+        with torch.cuda.stream(copy_stream):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(copy_stream)
+            for i in range(ncopy):
+                slots[i & 1]['src'].copy_(slots[i & 1]['host'], non_blocking=True)
+            e1.record(copy_stream)
+        torch.cuda.synchronize()
+        h2d_alone_ms = e0.elapsed_time(e1) / ncopy
         # sanity: the last batch's results arrived on the host and agree with the device buffers
         last = slots[(args.steps - 1) & 1]
         ok = bool(torch.equal(last['res'], last['flat'].cpu())) and int(last['out'][0].sum()) > 0
         return {'value': round(B * joined * args.steps / elapsed, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4),
                 'h2d_bytes_per_step': total, 'd2h_bytes_per_step': d2h_bytes,
-                'pcie_h2d_gbs_implied': round(total / (ms / 1e3) / 1e9, 2), 'timed_with': how, 'results_on_host_ok': ok,
+                'pcie_h2d_gbs_implied': round(total / (ms / 1e3) / 1e9, 2),
+                'h2d_alone': {'ms_per_batch': round(h2d_alone_ms, 4), 'gbs': round(total / (h2d_alone_ms / 1e3) / 1e9, 2),
+                              'note': 'the same pinned uint8 batch uploaded back to back with nothing else running: the floor the '
+                                      'host link sets for ms_per_step of this leg'},
+                'timed_with': how, 'results_on_host_ok': ok,
                 'what': f'per batch: pinned uint8 {B}x{H0}x{W0}x3 -> H2D (copy stream) -> preprocess_kernel -> backbone -> fused detect -> '
                         f'D2H of (count, class_ids, scores, boxes, anchor_idx) as ONE copy into pinned memory on a third stream; two slots, '
                         f'upload of batch i+1 overlaps compute of batch i; excludes disk read and JPEG decode; NOT part of `value`'}

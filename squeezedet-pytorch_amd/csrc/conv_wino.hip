@@ -42,6 +42,18 @@
 #define SQD_WINO_U_FIRST 0        /* 1: the next stage's U slice is requested right behind the stage barrier (its buffer is free from
                                      there on), ahead of the input transform; only the patch refill waits for the transform's reads */
 #endif
+#ifndef SQD_WINO_PIXMAJOR
+#define SQD_WINO_PIXMAJOR 0       /* the raw patch image of a wave: 0 = [k-quad][pixel][4 floats]; 1 = [pixel][k-quad][4 floats], i.e. adjacent
+                                     lanes of a DMA instruction fetch the two adjacent 16-byte pieces of one pixel (a 32-byte run of one
+                                     cache line per lane pair instead of every lane on a line of its own).  Round 3 A/B of the whole step
+                                     (gpurun_out/r03z/bench_pix*.json): 1 is 5 % SLOWER on conv_wino<2,4> (0.545 vs 0.520 ms) and the
+                                     U-stationary <2,4>, 1 % faster on <1,4> / <2,8> -- the patch fetch is not bound by lines touched */
+#endif
+#if SQD_WINO_PIXMAJOR
+#define SQD_WINO_PXS 8            /* floats per pixel of the raw image */
+#else
+#define SQD_WINO_PXS 4
+#endif
 #ifndef SQD_WINO_DMA_EARLY
 #define SQD_WINO_DMA_EARLY 0      /* 1: issue the whole next stage at the first MFMA step -- measured 5-8 % slower than spreading it */
 #endif
@@ -129,7 +141,11 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
 #pragma unroll
   for (int it = 0; it < RAW_IT; ++it) {
     const int slot = it * 64 + lane;
+#if SQD_WINO_PIXMAJOR
+    const int kq = slot & 1, pix = slot >> 1;
+#else
     const int kq = slot / RP, pix = slot - kq * RP;
+#endif
     const bool real = kq < 2 && pix < 108;
     const int r = pix / 18, c = pix - r * 18;
     r_key[it] = real ? (r << 8 | c) : -1;
@@ -217,7 +233,11 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
   // are consumed by the lane that computed them and never leave its registers (the patch reads are 2-way bank
   // conflicted in this order: 16 ds_read_b64 per chunk, cheap next to a V round trip through LDS)
   const int tt = lr, cp = g;
+#if SQD_WINO_PIXMAJOR
+  const float* const rawL = rawW + (((2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 8 + 2 * cp);
+#else
   const float* const rawL = rawW + (((cp >> 1) * RP + (2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 4 + 2 * (cp & 1));
+#endif
   // U image per 16 channels: [8 position pairs][4 channel pairs][16 n][pos parity][2 channels] (k-quad-major: conflict-free)
   const float* const uR0 = UB + g * 64 + lr * 4;
   // the former V image now parks a finished tile's outputs until the next barrier: [4 px][NT][64 lanes] f32x4
@@ -307,8 +327,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
         f32x2 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * 4), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * 4);
-          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * 4), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * 4);
+          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * SQD_WINO_PXS), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * SQD_WINO_PXS);
+          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * SQD_WINO_PXS), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * SQD_WINO_PXS);
           t[0][j] = d0 - d2; t[1][j] = d1 + d2; t[2][j] = d2 - d1; t[3][j] = d1 - d3;
         }
 #pragma unroll
@@ -489,7 +509,11 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
 #pragma unroll
   for (int it = 0; it < RAW_IT; ++it) {
     const int slot = it * 64 + lane;
+#if SQD_WINO_PIXMAJOR
+    const int kq = slot & 1, pix = slot >> 1;
+#else
     const int kq = slot / RP, pix = slot - kq * RP;
+#endif
     const bool real = kq < 2 && pix < 108;
     const int r = pix / 18, c = pix - r * 18;
     r_key[it] = real ? (r << 8 | c) : -1;
@@ -593,7 +617,11 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
   };
   const float relu_lo = a.relu ? 0.f : -__builtin_inff();
   const int tt = lr, cp = g;
+#if SQD_WINO_PIXMAJOR
+  const int rawL_off = (((2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 8 + 2 * cp);
+#else
   const int rawL_off = (((cp >> 1) * RP + (2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 4 + 2 * (cp & 1));
+#endif
   const float* const uR0 = UB + g * 64 + lr * 4;
   const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
   const bool plain_epi = !acc_i && !has_mul && !has_mask;
@@ -668,8 +696,8 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
       if constexpr (E1) {
         // only the four inner positions are needed: rows 1, 2 x columns 1, 2 of the tile's 4x4 patch
         const float* const rawL = rawW + rb * WV * 256 * 4 + rawL_off;
-        const f32x2 d11 = *(const f32x2*)(rawL + (1 * 18 + 1) * 4), d12 = *(const f32x2*)(rawL + (1 * 18 + 2) * 4);
-        const f32x2 d21 = *(const f32x2*)(rawL + (2 * 18 + 1) * 4), d22 = *(const f32x2*)(rawL + (2 * 18 + 2) * 4);
+        const f32x2 d11 = *(const f32x2*)(rawL + (1 * 18 + 1) * SQD_WINO_PXS), d12 = *(const f32x2*)(rawL + (1 * 18 + 2) * SQD_WINO_PXS);
+        const f32x2 d21 = *(const f32x2*)(rawL + (2 * 18 + 1) * SQD_WINO_PXS), d22 = *(const f32x2*)(rawL + (2 * 18 + 2) * SQD_WINO_PXS);
         const f32x2 t11 = d11 + d21, t12 = d12 + d22, t21 = d21 - d11, t22 = d22 - d12;      // column transform rows 1, 2
         vv[5] = t11 + t12; vv[6] = t12 - t11; vv[9] = t21 + t22; vv[10] = t22 - t21;
       } else {
@@ -677,8 +705,8 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
         f32x2 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * 4), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * 4);
-          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * 4), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * 4);
+          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * SQD_WINO_PXS), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * SQD_WINO_PXS);
+          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * SQD_WINO_PXS), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * SQD_WINO_PXS);
           t[0][j] = d0 - d2; t[1][j] = d1 + d2; t[2][j] = d2 - d1; t[3][j] = d1 - d3;
         }
 #pragma unroll
