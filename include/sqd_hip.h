@@ -116,6 +116,13 @@ int sqd_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* bia
 int sqd_stem_conv_relu_pool_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
                                 unsigned char* argmax, int B, int Hin, int Win, int N, int ksize, void* stream);
 
+/* features[0..2] AND the first Fire's squeeze (src/model/squeezedet.py:34-37 with :17-18: Fire.squeeze + squeeze_activation) in one
+ * launch, inference only: y NHWC [B][Hp][Wp][nsq] = ReLU(conv1x1(MaxPool(ReLU(conv(x))))); the pooled 64-channel tensor is never
+ * written.  w_sq: the squeeze's OIHW weight [nsq][N][1][1], b_sq its bias.  Supported: ksize 3, N 64, nsq 16, Win % 4 == 0, x
+ * 16-byte aligned; anything else returns SQD_ERR_UNSUPPORTED and the caller keeps the two launches. */
+int sqd_stem_pool_squeeze_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* w_sq, const float* b_sq,
+                              float* y_nhwc, int B, int Hin, int Win, int N, int ksize, int nsq, void* stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True) (src/model/squeezedet.py:36,39,42), NHWC.
  * argmax (uint8, same shape as y, may be NULL) records the window position 0..8 for the backward. */
 int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C,

@@ -30,6 +30,9 @@ def short_name(k):
     if m: return "conv_wgrad_wino"
     m = re.match(r"conv_wgrad_kernel<(\d+), \d+, \d+, \d+(, (true|false))?>", short)
     if m: return "squeeze_bwd" if m.group(3) == "true" else f"conv_wgrad<{m.group(1)}>"
+    m = re.match(r"stem_wave_kernel<\d+, \d+, (true|false), (\d+)>", short)           # the wave-autonomous 3x3 stem (round 3): same bench name as the
+    if m: return "stem_pool_sq<3>" if m.group(2) != "0" else "stem_pool<3>"           # workgroup kernel; SQ > 0 = with the first Fire's squeeze
+    if short.startswith("stem_wgrad_gather_kernel<"): return "stem_wgrad_pooled<3>"     # ... and so does the gather form of its weight gradient
     m = re.match(r"stem_wgrad_pooled_kernel<(\d+),", short)
     if m: return f"stem_wgrad_pooled<{m.group(1)}>"
     if short.startswith("wgrad_reduce_batched_kernel"): return "wgrad_reduce_batched"

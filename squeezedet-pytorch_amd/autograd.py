@@ -38,7 +38,17 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
         # argmax; the backward folds ReLU + pool into the stem weight-gradient kernel (ops.stem_wgrad_pooled)
         Hs, Ws = ops.stem_out_size(image.shape[2], image.shape[3], stem.kernel_size[0])
         am = torch.empty(B, *ops.pool_out_size(Hs, Ws), stem.out_channels, device=image.device, dtype=torch.uint8) if save else None
-        a = ops.stem_pool(image, stem.weight, stem.bias, argmax=am)
+        nxt = layers[3] if len(layers) > 3 else None
+        if (not save and base.fuse_stem_squeeze and nxt is not None and nxt[0] == 'fire'
+                and ops.stem_pool_squeeze_ok(image.shape, stem.weight.shape, nxt[2])):
+            # inference: the first Fire's squeeze rides in the stem launch; the pooled 64-channel tensor (its only consumer) is
+            # never written
+            fsq = feats[3].squeeze
+            stem_sq = ops.stem_pool_squeeze(image, stem.weight, stem.bias, fsq.weight, fsq.bias)
+            a = None
+        else:
+            stem_sq = None
+            a = ops.stem_pool(image, stem.weight, stem.bias, argmax=am)
         first = 3
         if save:
             saved['stem_pool'] = (am, a)
@@ -51,6 +61,8 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
     drop_applied = False
     unpooled = None                            # inference: a pool whose output only feeds the next squeeze is folded into it
     bridged = None                             # inference: the next Fire's squeeze output, produced by the previous Fire's launch
+    if layers[2][0] == 'pool' and stem_sq is not None:
+        bridged = stem_sq                      # ... or by the stem's
     for i in range(first, len(layers)):
         l = layers[i]
         if l[0] == 'pool':

@@ -537,6 +537,7 @@ static int launch_stem_pool(StemPoolArgs a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 struct StemWaveArgs {
   const float* x; const float* w; const float* bias; float* y; uint8_t* amax;
+  const float* wsq; const float* bsq;       // SQ variant: the next Fire's squeeze (1x1, 64 -> SQ channels, OIHW + bias); y is ITS output
   int B, Hin, Win, Ho, Wo, Hp, Wp;
   int tiles_x, tiles_y, ntiles;
   unsigned tiles_x_m, tiles_y_m;
@@ -553,7 +554,13 @@ struct StemWaveArgs {
 // compare of its own (a window whose maximum is <= 0 is code 15 whatever its arg-max).  Column E / O of the window: first row holding
 // the column maximum by two compares, candidates 3 dy + dx of the three columns (the third arrives by DPP from lane + 1) merged by
 // one v_min3.
-template <int PH, int CB, bool ARGMAX = false>
+// SQ > 0 (inference, CB = 2): the first Fire's squeeze (1x1 conv 64 -> SQ = 16 channels + bias + ReLU, src/model/squeezedet.py:17-18)
+// is applied to the pooled pixels before they leave the registers, and ONLY its output is written (y: NHWC [B][Hp][Wp][SQ]): a
+// pooled lane holds channels 16j + 4g + t of its pixel = the B operand (k = g, column = pixel) of v_mfma_f32_16x16x4_f32 for input
+// channel 16j + 4g + t, so the squeeze is 16 MFMAs per pooled row against squeeze weights pre-arranged as A operands in LDS
+// (sqA[j][lane] = W[n = lane & 15][16j + 4 (lane >> 4) + 0..3]) -- the Fire bridges' trick (wino_bridge.h).  The 153 MB pooled tensor is
+// neither written nor read back by a separate squeeze launch.
+template <int PH, int CB, bool ARGMAX = false, int SQ = 0>
 __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PW = CB == 1 ? 7 : 15, CH = 2 * PH + 1, IH = 2 * CH + 1;
@@ -561,14 +568,26 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
   constexpr int NSLOT = 3 * IH * SL, N_IT = (NSLOT + 63) / 64, BUFF = N_IT * 64 * 4; // floats per buffer
   constexpr int K = 27, KSTEPS = 7, NT = 4, N = 64;
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int NST = PH * NT * (ARGMAX ? 2 : 1);                                    // stores per tile (always issued)
+  constexpr int NST = SQ ? PH : PH * NT * (ARGMAX ? 2 : 1);                          // stores per tile (always issued)
   static_assert(!ARGMAX || CB == 2, "the arg-max epilogue is written for the parity-split layout");
+  static_assert(SQ == 0 || (SQ == 16 && CB == 2 && !ARGMAX), "fused squeeze: 16 channels, parity-split layout, inference");
+  constexpr int NO = SQ ? SQ : N;                                                    // channels per pixel of the tensor this kernel writes
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* const bufW = smem + wave_s * (2 * BUFF + N);  // [2][BUFF] patch images + the wave's own copy of the bias
   float* const biasW = bufW + 2 * BUFF;
+  float* const sqA = smem + 4 * (2 * BUFF + N);        // (SQ) [4 channel blocks][64 lanes] f32x4 A operands + [SQ] squeeze bias: one copy per workgroup
+  if constexpr (SQ > 0) {
+    {
+      const int j = tid >> 6;                          // 256 threads = 4 blocks x 64 lanes
+      const int n = lane & 15, ch = 16 * j + 4 * (lane >> 4);
+      *(f32x4*)(sqA + tid * 4) = *(const f32x4*)(a.wsq + n * N + ch);      // OIHW 1x1: W[n][ch .. ch + 3] contiguous
+    }
+    if (tid < SQ) sqA[1024 + tid] = a.bsq ? a.bsq[tid] : 0.f;
+    __syncthreads();                                   // the only workgroup barrier (before any wave may leave)
+  }
   typedef __attribute__((address_space(3))) const char* lds_cptr_t;   // 32-bit LDS addresses (a generic pointer costs two registers)
 
   // ---- per-lane constants ----
@@ -609,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
   // lanes that end up with a pooled pixel: conv columns 0, 2, .., 12 (CB = 1) / pooled columns 0..14 (CB = 2)
   const bool out_lane = CB == 1 ? ((c & 1) == 0 && c < 2 * PW) : (c < PW);
   const int pcol = CB == 1 ? (c >> 1) : c;
-  const int o_voff = out_lane ? (pcol * N + 4 * g) * 4 : (int)OOB;
+  const int o_voff = out_lane ? (pcol * NO + 4 * g) * 4 : (int)OOB;
 
   struct Tile { int ty, tx, inner; unsigned soff, osoff; };
   auto tile_at = [&](int t) {
@@ -621,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
     const int iy0 = 4 * PH * q.ty - 1, ix0 = 4 * PW * q.tx - 4;
     q.soff = (unsigned)(((b * 3 * a.Hin + 4 * PH * q.ty) * a.Win + 4 * PW * q.tx) * 4);
     q.inner = iy0 >= 0 && iy0 + IH <= a.Hin && ix0 >= 0 && ix0 + RP <= a.Win;
-    q.osoff = (unsigned)((((b * a.Hp + q.ty * PH) * a.Wp + q.tx * PW) * N) * 4);
+    q.osoff = (unsigned)((((b * a.Hp + q.ty * PH) * a.Wp + q.tx * PW) * NO) * 4);
     return q;
   };
   auto dma_in = [&](const Tile q, int buf) {
@@ -726,7 +745,8 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
 #pragma unroll
     for (int i = 0; i < PH; ++i) {
       const int vrow = (py0 + i < a.Hp) ? voff : (int)OOB;
-      const int soff = (int)(cur.osoff + (unsigned)(i * a.Wp * N * 4));
+      const int soff = (int)(cur.osoff + (unsigned)(i * a.Wp * NO * 4));
+      f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f};          // (SQ) the pooled row's squeeze output: rows 4g .. 4g + 3 of pixel column c
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         f32x4 h;
@@ -796,7 +816,19 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
         h += biasL[j * 4];
         asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
                      : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w));
-        store16(h, vrow + j * 64, soff);
+        if constexpr (SQ > 0) {
+          const f32x4 aw = *(const f32x4*)(sqA + (j * 64 + lane) * 4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) sacc = mfma16(aw[t], h[t], sacc);
+        } else {
+          store16(h, vrow + j * 64, soff);
+        }
+      }
+      if constexpr (SQ > 0) {
+        sacc += *(const f32x4*)(sqA + 1024 + 4 * g);
+        asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
+                     : "+v"(sacc.x), "+v"(sacc.y), "+v"(sacc.z), "+v"(sacc.w));
+        store16(sacc, vrow, soff);
       }
     }
     if (!has_next) break;
@@ -806,18 +838,18 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
 #endif
 }
 
-template <int PH, int CB, bool ARGMAX = false>
+template <int PH, int CB, bool ARGMAX = false, int SQ = 0>
 static int launch_stem_wave(StemWaveArgs a, hipStream_t s) {
   constexpr int PW = CB == 1 ? 7 : 15, CH = 2 * PH + 1, IH = 2 * CH + 1, SL = CB == 1 ? 9 : 17;
   constexpr int NSLOT = 3 * IH * SL, N_IT = (NSLOT + 63) / 64;
-  constexpr size_t lds = (size_t)4 * (2 * N_IT * 64 * 16 + 64 * 4);
+  constexpr size_t lds = (size_t)4 * (2 * N_IT * 64 * 16 + 64 * 4) + (SQ ? (1024 + 16) * 4 : 0);
   constexpr int OCC = 2;                                          // workgroups per CU (= waves per SIMD) the kernel is built for
   static_assert(OCC * lds <= 160 * 1024, "OCC workgroups per CU");
   a.tiles_x = sqd_cdiv(a.Wp, PW); a.tiles_y = sqd_cdiv(a.Hp, PH);
   a.ntiles = a.B * a.tiles_x * a.tiles_y;
   a.tiles_x_m = a.tiles_x > 1 ? (unsigned)(((1ull << 32) + a.tiles_x - 1) / a.tiles_x) : 0u;
   a.tiles_y_m = a.tiles_y > 1 ? (unsigned)(((1ull << 32) + a.tiles_y - 1) / a.tiles_y) : 0u;
-  auto kern = stem_wave_kernel<PH, CB, ARGMAX>;
+  auto kern = stem_wave_kernel<PH, CB, ARGMAX, SQ>;
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 64 * 1024 &&
@@ -860,7 +892,7 @@ extern "C" int sqd_stem_conv_relu_pool_fwd(const float* x, const float* w, const
   if (ksize == 3 && N == 64 && variant && (Win & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
       (long long)B * 3 * Hin * Win * 4 < (1ll << 31) && (long long)B * a.Hp * a.Wp * N * 4 < (1ll << 31)) {
     StemWaveArgs wa;
-    wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.amax = argmax; wa.B = B; wa.Hin = Hin; wa.Win = Win; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Hp = a.Hp; wa.Wp = a.Wp;
+    wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.amax = argmax; wa.wsq = nullptr; wa.bsq = nullptr; wa.B = B; wa.Hin = Hin; wa.Win = Win; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Hp = a.Hp; wa.Wp = a.Wp;
     // training forward: one pooled row per tile -- with two (variant 5) the arg-max epilogue's temporaries spill 42 registers, and
     // every reload queues behind the next patch's DMA in vmcnt order
     if (argmax) return variant == 5 ? launch_stem_wave<2, 2, true>(wa, s) : launch_stem_wave<1, 2, true>(wa, s);
@@ -869,6 +901,23 @@ extern "C" int sqd_stem_conv_relu_pool_fwd(const float* x, const float* w, const
   if (ksize == 3 && N == 64) return launch_stem_pool<3, 1, 4>(a, s);
   if (ksize == 7 && N == 96) return launch_stem_pool<7, 3, 6>(a, s);
   return SQD_ERR_UNSUPPORTED;
+}
+
+// features[0..2] + the first Fire's squeeze in one launch (inference): x NCHW [B,3,Hin,Win] -> y NHWC [B,Hp,Wp,nsq] =
+// ReLU(squeeze(MaxPool(3,2,ceil)(ReLU(conv(x))))).  Only the 3x3 / 64-channel stem with a 16-channel squeeze, Win % 4 == 0 and a
+// 16-byte aligned image (SQD_ERR_UNSUPPORTED otherwise: the caller keeps the two launches).
+extern "C" int sqd_stem_pool_squeeze_fwd(const float* x, const float* w, const float* bias, const float* wsq, const float* bsq,
+                                         float* y, int B, int Hin, int Win, int N, int ksize, int nsq, void* stream) {
+  SQD_CHECK_ARG(x && w && wsq && y && B > 0 && Hin > 0 && Win > 0);
+  SQD_CHECK_ARG(((uintptr_t)y & 15) == 0 && ((uintptr_t)wsq & 15) == 0);
+  if (!(ksize == 3 && N == 64 && nsq == 16 && (Win & 3) == 0 && ((uintptr_t)x & 15) == 0)) return SQD_ERR_UNSUPPORTED;
+  StemWaveArgs wa;
+  wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.amax = nullptr; wa.wsq = wsq; wa.bsq = bsq; wa.B = B; wa.Hin = Hin; wa.Win = Win;
+  wa.Ho = (Hin + 2 - 3) / 2 + 1; wa.Wo = (Win + 2 - 3) / 2 + 1;
+  SQD_CHECK_ARG(wa.Ho >= 3 && wa.Wo >= 3);
+  wa.Hp = (wa.Ho - 3 + 1) / 2 + 1; wa.Wp = (wa.Wo - 3 + 1) / 2 + 1;
+  if ((long long)B * 3 * Hin * Win * 4 >= (1ll << 31) || (long long)B * wa.Hp * wa.Wp * N * 4 >= (1ll << 31)) return SQD_ERR_UNSUPPORTED;
+  return launch_stem_wave<2, 2, false, 16>(wa, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -149,6 +149,7 @@ class SqueezeDetBase(nn.Module):
         # inference forward: pool 2 / 3 folded into the following squeeze (ops.pool_squeeze).  Off by default: measured equal
         # to the two separate kernels (0.174 vs 0.18 ms) -- both are bound by the 9x L2 read amplification of the window gather
         self.fuse_pool_squeeze = False
+        self.fuse_stem_squeeze = True             # inference forward: the first Fire's squeeze inside the stem launch (ops.stem_pool_squeeze)
         self._pack_table_keepalive = None
         self._forced_drop_mask = None       # tests: NCHW mask (already scaled by 1/(1-p)) instead of RNG
         import os

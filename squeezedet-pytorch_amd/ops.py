@@ -277,6 +277,40 @@ def stem_pool(image, weight, bias, argmax=None):
     return out
 
 
+def stem_pool_squeeze_ok(image_shape, stem_weight_shape, squeeze_width):
+    """True where ops.stem_pool_squeeze has a kernel: the 3x3 / 64-channel stem, a 16-channel squeeze, image width a multiple of 4."""
+    N, ci, k, k2 = stem_weight_shape
+    return (k, N, squeeze_width) == (3, 64, 16) and image_shape[3] % 4 == 0 and image_shape[2] >= 5 and image_shape[3] >= 5
+
+
+def stem_pool_squeeze(image, weight, bias, sq_weight, sq_bias):
+    """Inference: conv(3->64,3,s2)+ReLU+MaxPool(3,2,ceil) AND the first Fire's squeeze (1x1, 64->16, +ReLU) in one launch:
+    NCHW image -> NHWC squeeze output [B,Hp,Wp,16]; the pooled tensor is never written (src/model/squeezedet.py:34-37, :17-18)."""
+    if image.dim() != 4 or image.shape[1] != 3 or image.dtype != torch.float32 or not image.is_cuda:
+        raise ValueError(f'stem_pool_squeeze: image must be fp32 CUDA NCHW with 3 channels, got {tuple(image.shape)}')
+    image = image.contiguous()
+    N, ci, k, k2 = weight.shape
+    nsq = sq_weight.shape[0]
+    if ci != 3 or k != k2 or tuple(sq_weight.shape[1:]) != (N, 1, 1) or not stem_pool_squeeze_ok(image.shape, weight.shape, nsq):
+        raise ValueError(f'stem_pool_squeeze: unsupported geometry {tuple(image.shape)} / {tuple(weight.shape)} / {tuple(sq_weight.shape)}')
+    B, _, H, W = image.shape
+    Ho, Wo = stem_out_size(H, W, k)
+    Hp, Wp = pool_out_size(Ho, Wo)
+    out = torch.empty(B, Hp, Wp, nsq, device=image.device, dtype=torch.float32)
+    w = weight.detach().contiguous()
+    b = None if bias is None else bias.detach().contiguous()
+    ws = sq_weight.detach().contiguous()
+    bs = None if sq_bias is None else sq_bias.detach().contiguous()
+    br = _Bracket(f'stem_pool_sq<{k}>', f'stem+pool+squeeze {H}x{W} S{nsq}', 2.0 * B * (Ho * Wo * N * 3 * k * k + Hp * Wp * N * nsq),
+                  4.0 * (B * 3 * H * W + B * Hp * Wp * nsq)) if timing._timer is not None else None
+    rc = nat.lib().sqd_stem_pool_squeeze_fwd(nat.ptr(image), nat.ptr(w), nat.ptr(b), nat.ptr(ws), nat.ptr(bs), nat.ptr(out), B, H, W, N, k,
+                                             nsq, nat.stream_handle(image.device))
+    nat.check(rc, 'sqd_stem_pool_squeeze_fwd')
+    if br is not None:
+        br.done()
+    return out
+
+
 def maxpool(x, out=None, argmax=None, relu_codes=False):
     """MaxPool2d(3, 2, ceil_mode=True) on NHWC; ``argmax`` (uint8, same shape as out) is filled if given.  ``relu_codes=True``
     (x is a ReLU output, a backward follows): the codes also carry x's ReLU mask (15 = pooled value not > 0), so

@@ -31,22 +31,28 @@ def _conv1x1(batch, H, W, Cin, N):
 
 def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
                           use_winograd=True, fuse_expand=True, fuse_fire_bridge=True, fuse_expand_wino=True,
-                          fuse_pool_squeeze=False):
-    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order.  The five switches are
+                          fuse_pool_squeeze=False, fuse_stem_squeeze=True):
+    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order.  The six switches are
     ``SqueezeDetBase``'s attributes of the same names, one to one."""
     layers = layer_table(arch)
     H, W = ops.stem_out_size(input_size[0], input_size[1], layers[0][3])
     C = layers[0][2]
     plan = []
     first = 2
+    bridged = False
     if layers[2][0] == 'pool':
-        plan.append((f'stem_pool<{layers[0][3]}>', f'stem+pool {input_size[0]}x{input_size[1]}'))
+        nxt = layers[3] if len(layers) > 3 else None
+        if (fuse_stem_squeeze and nxt is not None and nxt[0] == 'fire'
+                and ops.stem_pool_squeeze_ok((batch, 3, input_size[0], input_size[1]), (layers[0][2], 3, layers[0][3], layers[0][3]), nxt[2])):
+            plan.append((f'stem_pool_sq<{layers[0][3]}>', f'stem+pool+squeeze {input_size[0]}x{input_size[1]} S{nxt[2]}'))
+            bridged = True
+        else:
+            plan.append((f'stem_pool<{layers[0][3]}>', f'stem+pool {input_size[0]}x{input_size[1]}'))
         H, W = ops.pool_out_size(H, W)
         first = 3
     else:
         plan.append((f'stem_conv<{layers[0][3]}>', f'stem {input_size[0]}x{input_size[1]}'))
 
-    bridged = False
     unpooled = None                        # (H, W) of the un-pooled map when the pool is folded into the next squeeze
     for i in range(first, len(layers)):
         l = layers[i]

@@ -352,6 +352,37 @@ def test_golden_forward_through_one_launch_winograd_fire(golden_dir, monkeypatch
     assert used['n'] >= 30
 
 
+def test_golden_forward_with_and_without_stem_squeeze(golden_dir):
+    """The reference-generated goldens through the stem launch that also runs the first Fire's squeeze (default at inference,
+    ``fuse_stem_squeeze``) and through the two separate launches: same 1e-4 bound, and the two paths agree to summation-order noise."""
+    from squeezedet_pytorch_amd import timing
+    g = np.load(os.path.join(golden_dir, "backbone_small.npz"))
+    preds = {}
+    for flag in (True, False):
+        cfg, m, sd = _model('squeezedet', (64, 96))
+        m.base.fuse_stem_squeeze = flag
+        x = synthetic.make_images(2, (64, 96), seed=3)
+        kt = timing.KernelTimer()
+        timing.set_timer(kt)
+        try:
+            with torch.no_grad():
+                preds[flag] = m.base(x.cuda())
+        finally:
+            timing.set_timer(None)
+        torch.cuda.synchronize()
+        names = [r[0] for r in kt.records]
+        assert ('stem_pool_sq<3>' in names) == flag and ('stem_pool<3>' in names) == (not flag)
+        np.testing.assert_allclose(preds[flag].cpu().numpy(), g["squeezedet_pred"], atol=TOL, rtol=0)
+    assert (preds[True] - preds[False]).abs().max().item() <= 2e-5
+    gk = np.load(os.path.join(golden_dir, "kitti_full.npz"))
+    cfg, m, sd = _model('squeezedet', (384, 1248))
+    assert m.base.fuse_stem_squeeze
+    x1 = synthetic.make_images(1, (384, 1248), seed=0)
+    with torch.no_grad():
+        pred1 = m.base(x1.cuda())
+    np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
+
+
 def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
     """The reference-generated goldens with every Fire -> Fire pair the bridge launches can take (expand pair + the next Fire's
     squeeze in one kernel, squeeze width <= 32: fire3 -> fire4 and fire6 -> fire7 of SqueezeDet; and through the max pool,

@@ -189,6 +189,30 @@ def test_stem_wave_kernels(variant, H, W, monkeypatch):
     assert torch.equal(y, y_old)
 
 
+@pytest.mark.parametrize("H,W", [(64, 96), (50, 68), (37, 44), (12, 16), (9, 8), (384, 1248)])
+def test_stem_pool_squeeze_one_launch(H, W):
+    """features[0..2] + the first Fire's squeeze in one launch (ops.stem_pool_squeeze, inference) == the reference's modules in fp32
+    (src/model/squeezedet.py:34-37, :17-18) and == the two launches it replaces within summation-order noise."""
+    ops = _ops()
+    B = 1 if H == 384 else 2
+    x = _rand(B, 3, H, W, seed=27)
+    w = _rand(64, 3, 3, 3, seed=28, scale=(2.0 / 27) ** 0.5); b = _rand(64, seed=29, scale=0.1)
+    ws = _rand(16, 64, 1, 1, seed=30, scale=(2.0 / 64) ** 0.5); bs = _rand(16, seed=31, scale=0.1)
+    pooled = F.max_pool2d(F.relu(F.conv2d(x, w, b, stride=2, padding=1)), 3, 2, ceil_mode=True)
+    ref = _nhwc(F.relu(F.conv2d(pooled, ws, bs)))
+    assert ops.stem_pool_squeeze_ok(x.shape, w.shape, 16)
+    y = ops.stem_pool_squeeze(x.cuda(), w.cuda(), b.cuda(), ws.cuda(), bs.cuda())
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert (y.cpu() - ref).abs().max().item() <= _tol(ref)
+    two = torch.empty_like(y)
+    p = ops.stem_pool(x.cuda(), w.cuda(), b.cuda())
+    ops.conv(p, 0, ops.ConvPlan(ws.cuda(), bs.cuda(), ops.choose_cfg(1, 64, 16, p.shape[0] * p.shape[1] * p.shape[2])), two, 0, relu=True)
+    assert (y - two).abs().max().item() <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(y, ops.stem_pool_squeeze(x.cuda(), w.cuda(), b.cuda(), ws.cuda(), bs.cuda()))       # run-to-run
+    # widths the 16-byte row DMA cannot take are refused on the host (the model then keeps the two launches)
+    assert not ops.stem_pool_squeeze_ok((2, 3, 50, 70), w.shape, 16) and not ops.stem_pool_squeeze_ok(x.shape, w.shape, 32)
+
+
 def test_fused_stem_pool_kitti_size_both_paths_agree():
     ops = _ops()
     x = _rand(3, 3, 384, 1248, seed=31).cuda()

@@ -28,14 +28,16 @@ def test_launch_plan_totals():
     from squeezedet_pytorch_amd import plan
     p = plan.inference_launch_plan('squeezedet', 20, (384, 1248))
     names = [n for n, _ in p]
-    assert names[0] == 'stem_pool<3>' and names[-1] == 'detect'
+    assert names[0] == 'stem_pool_sq<3>' and names[-1] == 'detect'          # the first Fire's squeeze rides in the stem launch
     # fire3's and fire4's expand pairs run inside the two bridge launches (with fire4's / fire6's squeeze, and the first pool)
     assert names.count('fire_bridge') == 1 and names.count('fire_pool_bridge') == 1 and names.count('maxpool_fwd') == 1
     assert sum(1 for n in names if n.startswith('conv_wino')) == 9             # 8 expand3x3 + ConvDet, all Winograd at bs=20
-    assert len(p) == 1 + 1 + 2 + 24 + 1 + 1             # stem+pool, pool, bridges, 8 squeeze + 8 expand1x1 + 8 expand3x3, ConvDet, detect
+    assert len(p) == 1 + 1 + 2 + 23 + 1 + 1             # stem+pool+squeeze, pool, bridges, 7 squeeze + 8 expand1x1 + 8 expand3x3, ConvDet, detect
+    r = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_stem_squeeze=False)
+    assert r[0][0] == 'stem_pool<3>' and len(r) == len(p) + 1
     # without the bridges: the plain launch set
     q = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_fire_bridge=False)
-    assert len(q) == 1 + 2 + 30 + 1 + 1 and sum(1 for n, _ in q if n.startswith('conv_wino')) == 11
+    assert len(q) == 1 + 2 + 29 + 1 + 1 and sum(1 for n, _ in q if n.startswith('conv_wino')) == 11
 
 
 def test_launch_plan_bridges_follow_the_table_rows():
