@@ -123,6 +123,16 @@ int sqd_stem_conv_relu_pool_fwd(const float* x_nchw, const float* w_oihw, const 
 int sqd_stem_pool_squeeze_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* w_sq, const float* b_sq,
                               float* y_nhwc, int B, int Hin, int Win, int N, int ksize, int nsq, void* stream);
 
+/* Fire.squeeze + squeeze_activation + Fire.expand1x1 + expand1x1_activation (src/model/squeezedet.py:17-19) in ONE launch: the
+ * squeeze tile feeds the expand1x1 from registers.  y_sq[..., sq_coff : +Nsq] = the squeeze output (read by the expand3x3 launch and
+ * by the backward), y_out[..., out_coff : +E1] = the expand1x1 half of the Fire's concat.  Both weight sets packed as by
+ * sqd_pack_conv_weight with kc = 32 (Npad = rows of the packing).  Nsq in {16, 32, 48, 64, 96}, E1 % 32 == 0, C > 32; anything else
+ * returns SQD_ERR_UNSUPPORTED.  wg_cap as in sqd_conv_fwd (cfg_id / 1000). */
+int sqd_fire_squeeze_expand1x1_fwd(const float* x, const float* wsq_packed, const float* bsq, float* y_sq,
+                                   const float* we1_packed, const float* be1, float* y_out, int B, int H, int W, int C,
+                                   int x_pitch, int x_coff, int Nsq, int Nsq_pad, int sq_pitch, int sq_coff, int E1,
+                                   int E1_pad, int out_pitch, int out_coff, int wg_cap, void* stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True) (src/model/squeezedet.py:36,39,42), NHWC.
  * argmax (uint8, same shape as y, may be NULL) records the window position 0..8 for the backward. */
 int sqd_maxpool3x3s2_ceil_fwd(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C,

@@ -92,21 +92,42 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                 Bq, H, W, C = a.shape
             assert C == cin, f'layer {i}: expected {cin} channels, got {C}'
             npix = Bq * H * W
+            fusable = not save and not (drop_mask is not None and i == len(layers) - 1)
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            nxt2 = layers[i + 2] if i + 2 < len(layers) else None
+            # which launch takes this Fire's expand pair (pure table look-ups; decided before the squeeze because the squeeze may ride
+            # with the expand1x1)
+            zseg = ycfg = xcfg = fcfg = None
+            if (fusable and nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire' and base.fuse_fire_bridge
+                    and base.use_winograd):
+                zseg = ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix)
+            if zseg is None and fusable and nxt is not None and nxt[0] == 'fire' and base.fuse_fire_bridge and base.use_winograd:
+                ycfg = ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix)
+            if zseg is None and ycfg is None:
+                xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fusable and base.fuse_expand_wino and base.use_winograd) else None
+                fcfg = ops.choose_fused_cfg(s, e1, npix) if (fusable and xcfg is None and base.fuse_expand and e1 == e3) else None
+            ym = drop_mask if (drop_mask is not None and i == len(layers) - 1) else None
+            # squeeze + expand1x1 in ONE launch (the squeeze tile feeds the expand1x1 from registers; forward of inference AND training)
+            # wherever the two would otherwise be separate plain launches
+            chain = (bridged is None and unpooled is None and zseg is None and ycfg is None and xcfg is None and fcfg is None and ym is None
+                     and base.fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1))
+            out = None
             if bridged is not None:
                 sq, bridged = bridged, None
             else:
                 sq = torch.empty(Bq, H, W, s, device=a.device, dtype=torch.float32)
-                if unpooled is not None:
+                if chain:
+                    out = torch.empty(Bq, H, W, e1 + e3, device=sq.device, dtype=torch.float32)
+                    csq, ce1 = ops.fire_sq_e1_cfgs(s)
+                    ops.fire_sq_e1(a, 0, base.plan(f'{i}.squeeze@chain', fire.squeeze, csq), base.plan(f'{i}.expand1x1@chain', fire.expand1x1, ce1),
+                                   sq, 0, out, 0)
+                elif unpooled is not None:
                     ops.pool_squeeze(unpooled, 0, cin, base.plan(f'{i}.squeeze@pool', fire.squeeze, ops.POOL_SQUEEZE_CFG), sq, 0)
                     unpooled = None
                 else:
                     ops.conv(a, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, cin, s, npix)), sq, 0, relu=True)
-            fusable = not save and not (drop_mask is not None and i == len(layers) - 1)
-            nxt = layers[i + 1] if i + 1 < len(layers) else None
-            nxt2 = layers[i + 2] if i + 2 < len(layers) else None
             if (fusable and nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire' and base.fuse_fire_bridge
                     and base.use_winograd):
-                zseg = ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix)
                 if zseg is not None:
                     # inference: expand pair + concat + the max pool + the squeeze of the Fire behind it in one launch
                     bridged = torch.empty(Bq, *ops.pool_out_size(H, W), nxt2[2], device=sq.device, dtype=torch.float32)
@@ -114,7 +135,6 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                     a = None
                     continue
             if fusable and nxt is not None and nxt[0] == 'fire' and base.fuse_fire_bridge and base.use_winograd:
-                ycfg = ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix)
                 if ycfg is not None:
                     # inference: this Fire's expand pair AND the next Fire's squeeze in one launch; the concatenated expand
                     # output (the next layer's only consumer is that squeeze) is never written
@@ -122,10 +142,11 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                     ops.fire_bridge(sq, 0, base.fire_bridge_plan(i, fire, feats[i + 1], ycfg), bridged, 0)
                     a = None
                     continue
-            out = torch.empty(Bq, H, W, e1 + e3, device=sq.device, dtype=torch.float32)
-            xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fusable and base.fuse_expand_wino and base.use_winograd) else None
-            fcfg = ops.choose_fused_cfg(s, e1, npix) if (fusable and xcfg is None and base.fuse_expand and e1 == e3) else None
-            if xcfg is not None:
+            if out is None:
+                out = torch.empty(Bq, H, W, e1 + e3, device=sq.device, dtype=torch.float32)
+            if chain:
+                base.conv3x3(f'{i}.expand3x3', fire.expand3x3, sq, 0, out, e1, relu=True)
+            elif xcfg is not None:
                 # inference: both expands in ONE Winograd launch (expand1x1 = the four inner transform positions, riding
                 # along as extra channel slices on the same staged squeeze tile)
                 ops.fire_wino(sq, 0, base.fire_wino_plan(i, fire, xcfg), out, 0, e1)
@@ -136,7 +157,6 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
             else:
                 # dropout in front of ConvDet (reference: squeezedet.py:81-82): relu(x) * m == relu(x * m) for the non-negative
                 # scaled keep mask, so it is the `ymul` epilogue of the last Fire's two expand kernels -- no extra pass
-                ym = drop_mask if (drop_mask is not None and i == len(layers) - 1) else None
                 ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, s, e1, npix)), out, 0, relu=True,
                          ymul=ym, ymul_coff=0)
                 base.conv3x3(f'{i}.expand3x3', fire.expand3x3, sq, 0, out, e1, relu=True, ymul=ym)

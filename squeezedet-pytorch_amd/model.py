@@ -153,6 +153,11 @@ class SqueezeDetBase(nn.Module):
         self._pack_table_keepalive = None
         self._forced_drop_mask = None       # tests: NCHW mask (already scaled by 1/(1-p)) instead of RNG
         import os
+        # forward (inference and training): squeeze + expand1x1 of a Fire in one launch (ops.fire_sq_e1) wherever they would be two plain
+        # launches.  OFF: measured slower in the step (inference 1.553 -> 1.607 ms, training 5.49 -> 5.57 ms; per Fire 100 vs 88 us at
+        # C512/768 -> 96 -> 384, 56 vs 52 at -> 64 -> 256, 37 vs 39 at -> 48 -> 192): a chain stage is 8 NT MFMAs per wave between two
+        # barriers, too short to hide its own weight fetch, and the chained form forces the one-slice squeeze tiling
+        self.fuse_sq_e1 = os.environ.get('SQD_FUSE_SQ_E1', '0')[:1] == '1'
         self.wgrad_side_stream = os.environ.get('SQD_WGRAD_SIDE_STREAM', '0')[:1] == '1'     # backward: weight gradients on a second stream
         self._wgrad_stream = None
         self.fuse_squeeze_bwd = os.environ.get('SQD_FUSE_SQUEEZE_BWD', '1')[:1] != '0'     # backward: squeeze wgrad + dgrad in one launch

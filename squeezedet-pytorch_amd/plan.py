@@ -31,8 +31,8 @@ def _conv1x1(batch, H, W, Cin, N):
 
 def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
                           use_winograd=True, fuse_expand=True, fuse_fire_bridge=True, fuse_expand_wino=True,
-                          fuse_pool_squeeze=False, fuse_stem_squeeze=True):
-    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order.  The six switches are
+                          fuse_pool_squeeze=False, fuse_stem_squeeze=True, fuse_sq_e1=False):
+    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order.  The seven switches are
     ``SqueezeDetBase``'s attributes of the same names, one to one."""
     layers = layer_table(arch)
     H, W = ops.stem_out_size(input_size[0], input_size[1], layers[0][3])
@@ -68,8 +68,22 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
             continue
         _, cin, s, e1, e3 = l
         npix = batch * H * W
+        nxt = layers[i + 1] if i + 1 < len(layers) else None
+        nxt2 = layers[i + 2] if i + 2 < len(layers) else None
+        zseg = ycfg = xcfg = fcfg = None
+        if nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire' and fuse_fire_bridge and use_winograd:
+            zseg = ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix)
+        if zseg is None and nxt is not None and nxt[0] == 'fire' and fuse_fire_bridge and use_winograd:
+            ycfg = ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix)
+        if zseg is None and ycfg is None:
+            xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fuse_expand_wino and use_winograd) else None
+            fcfg = ops.choose_fused_cfg(s, e1, npix) if (xcfg is None and fuse_expand and e1 == e3) else None
+        chain = (not bridged and unpooled is None and zseg is None and ycfg is None and xcfg is None and fcfg is None
+                 and fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1))
         if bridged:
             pass
+        elif chain:
+            plan.append((f'fire_sq_e1<{s // 16}>', f'sq+e1 C{cin} S{s} E{e1} {H}x{W}'))
         elif unpooled is not None:
             plan.append(('pool_squeeze', f'pool+squeeze C{cin} N{s} {unpooled[0]}x{unpooled[1]}'))
             unpooled = None
@@ -77,21 +91,17 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
             plan.append(_conv1x1(batch, H, W, cin, s))
         bridged = False
         C = e1 + e3
-        nxt = layers[i + 1] if i + 1 < len(layers) else None
-        nxt2 = layers[i + 2] if i + 2 < len(layers) else None
-        if nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire' and fuse_fire_bridge and use_winograd:
-            if ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix) is not None:
-                plan.append(('fire_pool_bridge', f'fire C{s} E{e1}+{e3} -> pool -> S{nxt2[2]} {H}x{W}'))
-                bridged = True
-                continue
-        if nxt is not None and nxt[0] == 'fire' and fuse_fire_bridge and use_winograd:
-            if ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix) is not None:
-                plan.append(('fire_bridge', f'fire C{s} E{e1}+{e3} -> S{nxt[2]} {H}x{W}'))
-                bridged = True
-                continue
-        xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fuse_expand_wino and use_winograd) else None
-        fcfg = ops.choose_fused_cfg(s, e1, npix) if (xcfg is None and fuse_expand and e1 == e3) else None
-        if xcfg is not None:
+        if zseg is not None:
+            plan.append(('fire_pool_bridge', f'fire C{s} E{e1}+{e3} -> pool -> S{nxt2[2]} {H}x{W}'))
+            bridged = True
+            continue
+        if ycfg is not None:
+            plan.append(('fire_bridge', f'fire C{s} E{e1}+{e3} -> S{nxt[2]} {H}x{W}'))
+            bridged = True
+            continue
+        if chain:
+            plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
+        elif xcfg is not None:
             plan.append((ops.fire_wino_kernel_name(xcfg), f'fire C{s} E{e1}+{e3} {H}x{W}'))
         elif fcfg is not None:
             plan.append((ops.cfg_kernel_name(fcfg).replace('conv_dma', 'fire_expand'), f'expand C{s} E{e1} {H}x{W}'))
@@ -110,7 +120,7 @@ def _wgrad(batch, H, W, N, C, taps):
 
 
 def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
-                         use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True):
+                         use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True, fuse_sq_e1=False):
     """Launches of one training iteration's forward (activations saved, no inference-only fusion: ``autograd.py`` gates
     the bridges and fused expands on ``not save``), multi-task loss forward / backward and the backbone backward, as
     (kernel name, shape tag) in launch order.  The optimizer launch and torch's own elementwise kernels (dropout mask,
@@ -139,8 +149,12 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
             H, W = ops.pool_out_size(H, W)
             continue
         _, cin, s, e1, e3 = l
-        plan.append(_conv1x1(batch, H, W, cin, s))
-        plan.append(_conv1x1(batch, H, W, s, e1))
+        # (the last Fire carries the dropout multiply in its expand epilogues: two plain launches)
+        if fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1) and i != len(layers) - 1:
+            plan.append((f'fire_sq_e1<{s // 16}>', f'sq+e1 C{cin} S{s} E{e1} {H}x{W}'))
+        else:
+            plan.append(_conv1x1(batch, H, W, cin, s))
+            plan.append(_conv1x1(batch, H, W, s, e1))
         plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
         C = e1 + e3
     ncd = anchors_per_grid * (num_classes + 5)

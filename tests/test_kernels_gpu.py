@@ -227,6 +227,40 @@ def test_fused_stem_pool_kitti_size_both_paths_agree():
     assert int(am[y_tr > 0].max()) <= 8 and bool((am[y_tr <= 0] == 15).all())
 
 
+@pytest.mark.parametrize("C,S,E1,B,H,W", [(64, 16, 64, 2, 12, 20), (128, 32, 128, 1, 9, 13), (256, 48, 192, 2, 7, 11), (384, 64, 256, 1, 6, 10),
+                                            (768, 96, 384, 1, 5, 9), (512, 96, 384, 2, 24, 78), (100, 48, 96, 1, 4, 5), (36, 16, 32, 1, 3, 3)])
+def test_fire_sq_e1_one_launch(C, S, E1, B, H, W):
+    """Fire.squeeze + ReLU + Fire.expand1x1 + ReLU in ONE launch (ops.fire_sq_e1: the squeeze tile feeds the expand1x1 from
+    registers; reference src/model/squeezedet.py:17-19) vs the fp32 CPU modules and vs the two launches it replaces: all five squeeze
+    widths, pixel counts that are not a multiple of the 64-pixel tile, a partial last K chunk, channel windows of wider buffers
+    (what lies outside stays untouched)."""
+    ops = _ops()
+    x = F.relu(_rand(B, C, H, W, seed=51))
+    ws = _rand(S, C, 1, 1, seed=52, scale=(2.0 / C) ** 0.5); bs = _rand(S, seed=53, scale=0.1)
+    we = _rand(E1, S, 1, 1, seed=54, scale=(2.0 / S) ** 0.5); be = _rand(E1, seed=55, scale=0.1)
+    sq_ref = F.relu(F.conv2d(x, ws, bs))
+    e1_ref = F.relu(F.conv2d(sq_ref, we, be))
+    assert ops.fire_sq_e1_ok(C, S, E1)
+    csq, ce1 = ops.fire_sq_e1_cfgs(S)
+    xg = torch.full((B, H, W, C + 8), 5.0, device='cuda'); xg[..., 4:4 + C] = _nhwc(x).cuda()
+    sq = torch.full((B, H, W, S + 4), 7.0, device='cuda')
+    out = torch.full((B, H, W, 2 * E1 + 8), 9.0, device='cuda')
+    p_sq, p_e1 = ops.ConvPlan(ws.cuda(), bs.cuda(), csq), ops.ConvPlan(we.cuda(), be.cuda(), ce1)
+    ops.fire_sq_e1(xg, 4, p_sq, p_e1, sq, 4, out, 8)
+    assert (sq[..., 4:].cpu() - _nhwc(sq_ref)).abs().max().item() <= _tol(sq_ref)
+    assert (out[..., 8:8 + E1].cpu() - _nhwc(e1_ref)).abs().max().item() <= _tol(e1_ref)
+    assert bool((sq[..., :4] == 7.0).all()) and bool((out[..., :8] == 9.0).all()) and bool((out[..., 8 + E1:] == 9.0).all())
+    # the two launches it replaces: the squeeze bit for bit (same kernel, same order), the expand1x1 within summation-order noise
+    sq2 = torch.empty(B, H, W, S, device='cuda'); out2 = torch.empty(B, H, W, E1, device='cuda')
+    ops.conv(xg, 4, p_sq, sq2, 0, relu=True)
+    ops.conv(sq2, 0, ops.ConvPlan(we.cuda(), be.cuda(), ops.choose_cfg(1, S, E1, B * H * W)), out2, 0, relu=True)
+    assert torch.equal(sq[..., 4:], sq2)
+    assert (out[..., 8:8 + E1] - out2).abs().max().item() <= 1e-5 * max(1.0, float(e1_ref.abs().max()))
+    again_sq, again_out = torch.empty_like(sq), torch.empty_like(out)
+    ops.fire_sq_e1(xg, 4, p_sq, p_e1, again_sq, 4, again_out, 8)
+    assert torch.equal(again_sq[..., 4:], sq[..., 4:]) and torch.equal(again_out[..., 8:8 + E1], out[..., 8:8 + E1])      # run-to-run
+
+
 @pytest.mark.parametrize("C,E,H,W", [(16, 64, 40, 70), (32, 128, 24, 78), (48, 192, 13, 29), (96, 384, 24, 78), (64, 256, 9, 17)])
 def test_fused_fire_expand_equals_separate_kernels(C, E, H, W):
     """fire_expand (one launch) == expand1x1 + expand3x3 launches, bit for bit, for every usable tile configuration."""

@@ -35,6 +35,9 @@ def test_launch_plan_totals():
     assert len(p) == 1 + 1 + 2 + 23 + 1 + 1             # stem+pool+squeeze, pool, bridges, 7 squeeze + 8 expand1x1 + 8 expand3x3, ConvDet, detect
     r = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_stem_squeeze=False)
     assert r[0][0] == 'stem_pool<3>' and len(r) == len(p) + 1
+    # squeeze + expand1x1 as one launch (a tested switch, off: measured slower): 7 launch pairs merge
+    r = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_sq_e1=True)
+    assert len(r) == len(p) - 7 and sum(1 for n, _ in r if n.startswith('fire_sq_e1')) == 7
     # without the bridges: the plain launch set
     q = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_fire_bridge=False)
     assert len(q) == 1 + 2 + 29 + 1 + 1 and sum(1 for n, _ in q if n.startswith('conv_wino')) == 11
