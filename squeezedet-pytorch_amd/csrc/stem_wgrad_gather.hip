@@ -37,7 +37,10 @@ template <bool HAS_PL, int OCC>
 __global__ __launch_bounds__(256, OCC) void stem_wgrad_gather_kernel(StemWgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PH = 2, PW = 8, N = 64, K = 27;
-  constexpr int IH = 4 * PH + 3, SL = PW + 2, RP = 4 * SL;                           // patch rows, 16-byte slots / floats per row
+  // patch rows, 16-byte slots / floats per row.  One slot more than the 10 the taps need: with a 44-float pitch the three window rows
+  // of a pixel (2 RP dy floats apart) start 0 / 24 / 16 banks apart for the 4-byte reads (32 banks) and 0 / 24 / 48 for the 8-byte
+  // reads (64 banks) -- with 40 floats rows 0 and 2 met on the same banks (2-way conflicts of the 4-byte tap-0 reads)
+  constexpr int IH = 4 * PH + 3, SL = PW + 3, RP = 4 * SL;
   constexpr int NSLOT = 3 * IH * SL, N_IT = (NSLOT + 63) / 64, BUFF = N_IT * 64 * 4; // floats per buffer
   constexpr int NG = PH * PW / 2;                                                    // pixel groups (2 pixels) per tile
   constexpr unsigned OOB = 0x80000000u;
@@ -255,7 +258,7 @@ static int stem_wgrad_gather_slabs(const StemWgradArgs& a, int S, int occ) {
 
 // returns the number of slabs written (= workgroups), or a negative status
 int launch_stem_wgrad_gather(StemWgradArgs a, int S, hipStream_t s) {
-  constexpr int IH = 11, SL = 10, N_IT = (3 * IH * SL + 63) / 64;
+  constexpr int IH = 11, SL = 11, N_IT = (3 * IH * SL + 63) / 64;
   constexpr size_t lds_patch = (size_t)4 * 2 * N_IT * 64 * 16, lds_red = (size_t)4 * 56 * 32 * 4;
   constexpr size_t lds = lds_patch > lds_red ? lds_patch : lds_red;
   a.tiles_x = sqd_cdiv(a.Wp, 8); a.tiles_y = sqd_cdiv(a.Hp, 2);
