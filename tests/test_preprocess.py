@@ -22,6 +22,28 @@ def test_resize_identity_and_ramp_known_answers():
     assert np.allclose(oracle.resize_linear_f32(c, (11, 13)), 1.25)
 
 
+@pytest.mark.parametrize("src,dst", [((375, 1242), (384, 1248)), ((370, 1224), (384, 1248)), ((50, 61), (64, 96)), ((123, 77), (64, 96)),
+                                     ((800, 2000), (384, 1248)), ((9, 5), (17, 33))])
+def test_resize_agrees_with_an_independent_half_pixel_bilinear(src, dst):
+    """A second witness for the restated cv2.resize(INTER_LINEAR) (OpenCV itself is absent here: parity against cv2 stays unpinned):
+    torch's ``F.interpolate(mode='bilinear', align_corners=False, antialias=False)`` implements the same published rule -- source
+    coordinate (x + 0.5) * scale - 0.5, border clamp, no prefilter when shrinking -- independently of the oracle's code."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(3)
+    img = rs.uniform(-2.5, 2.5, src + (3,)).astype(np.float32)
+    # The witness runs in float64.  cv2 (and the oracle) round the source coordinate to float32 BEFORE splitting it into index and
+    # weight, so at x ~ 1242 the weight is only good to one float32 ulp of the coordinate (1.2e-4 pixel); on this white-noise image
+    # (neighbouring pixels differ by up to 5) that is up to ~6e-4 in the output.  A wrong rule (corner-aligned coordinates, a
+    # missing half-pixel offset, a prefilter) would differ by O(1).
+    want = F.interpolate(torch.from_numpy(img).double().permute(2, 0, 1)[None], size=dst, mode='bilinear', align_corners=False, antialias=False)
+    want = want[0].permute(1, 2, 0).numpy()
+    got = oracle.resize_linear_f32(img, dst)
+    np.testing.assert_allclose(got, want, atol=6e-4, rtol=0)
+    wrong = F.interpolate(torch.from_numpy(img).double().permute(2, 0, 1)[None], size=dst, mode='bilinear', align_corners=True)[0].permute(1, 2, 0).numpy()
+    if src != dst:
+        assert np.abs(got - wrong).max() > 0.05                           # (the comparison has teeth)
+
+
 def test_preprocess_image_layout_and_scales():
     img = np.random.RandomState(1).randint(0, 256, (375, 1242, 3), dtype=np.uint8)
     x, scales = oracle.preprocess_image(img, (384, 1248))
