@@ -1,6 +1,7 @@
 """``Detector`` with the reference's interface (src/engine/detector.py:14-122): ``detect(batch)``
 returns one dict per image (numpy arrays, boxes mapped back to original-image coordinates),
-``filter(det)`` filters one image's dense detections.
+``filter(det)`` filters one image's dense detections, ``detect_dataset(dataset)`` is the reference's inference driver
+(:52-85) on the GPU input pipeline, ``DataWrapper`` its annotation-free dataset view (:125-145).
 
 Where the reference loops over the batch in Python with >= 10 host syncs per image (boolean-mask
 indexing, ``torch.sum(..) == 0``, per-image ``.cpu()``), this runs ONE fused kernel for the whole
@@ -9,8 +10,12 @@ ONE device-to-host copy of the compact result.  Each result additionally carries
 """
 from __future__ import annotations
 
+import time
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
+import torch.utils.data
 
 from . import ops
 from .boxes import boxes_postprocess
@@ -90,6 +95,49 @@ class Detector(object):
                             'anchor_idx': idx[b, :n].astype(np.int64), 'image_meta': m})
         return results
 
+    def detect_dataset(self, dataset):
+        """The reference's inference driver (src/engine/detector.py:52-85: DataLoader over ``DataWrapper(dataset)`` -> ``detect`` per
+        batch -> timing lines -> list of per-image results), on the GPU input pipeline: ``dataset.load_image(i)`` -> raw image ->
+        uint8 upload -> ``preprocess_kernel`` -> backbone -> fused detect (``detect_images``); the images of batch i + 1 are loaded
+        by ``cfg.num_workers`` threads while batch i is on the GPU.  Images whose pixels are not uint8-representable (a dataset that
+        hands out pre-whitened floats) take the reference's own route instead: ``dataset.preprocess`` on the host, then ``detect``.
+        Same printed lines and the same result dicts (``image_meta['index']`` = dataset index) as the reference."""
+        cfg = self.cfg
+        n = len(dataset)
+        bs = max(1, int(getattr(cfg, 'batch_size', 1)))
+        every = max(1, int(getattr(cfg, 'print_interval', 10)))
+        batches = [list(range(i, min(i + bs, n))) for i in range(0, n, bs)]
+        t_start = time.time()
+        results = []
+        data_s = net_s = 0.0
+        with ThreadPoolExecutor(max_workers=max(1, int(getattr(cfg, 'num_workers', 1)))) as pool:
+            load = lambda idxs: list(pool.map(dataset.load_image, idxs))       # noqa: E731  [(image, image_id), ...]
+            pending = pool.submit(load, batches[0]) if batches else None
+            for it, idxs in enumerate(batches):
+                t0 = time.time()
+                loaded = pending.result()
+                pending = pool.submit(load, batches[it + 1]) if it + 1 < len(batches) else None
+                data_s = time.time() - t0
+                t0 = time.time()
+                raw = [np.asarray(im) for im, _ in loaded]
+                ids = [iid for _, iid in loaded]
+                as_u8 = [im if im.dtype == np.uint8 else im.astype(np.uint8) for im in raw]
+                if all(im.ndim == 3 and im.shape[2] == 3 and (im.dtype == np.uint8 or np.array_equal(u8, im)) for im, u8 in zip(raw, as_u8)):
+                    out = self.detect_images(as_u8, image_ids=ids)
+                    for r, i in zip(out, idxs):
+                        r['image_meta']['index'] = i
+                else:
+                    out = self.detect(_host_batch(dataset, raw, ids, idxs, cfg.device))
+                results.extend(out)
+                net_s = time.time() - t0
+                if it % every == 0:
+                    print('eval: [{0}/{1}] | data {2:.3f}s | net {3:.3f}s'.format(it, len(batches), data_s, net_s))
+        total = time.time() - t_start
+        tpi = total / max(n, 1)
+        print('Elapsed {:.2f}min ({:.1f}ms/image, {:.1f}frames/s)'.format(total / 60., tpi * 1000., 1. / max(tpi, 1e-12)))
+        print('-' * 80)
+        return results
+
     def filter(self, det):
         """One image's dense ``{'class_ids' [A], 'scores' [A], 'boxes' [A,4]}`` (GPU tensors) ->
         filtered dict of GPU tensors (plus ``anchor_idx``) or ``None``."""
@@ -100,3 +148,36 @@ class Detector(object):
         if n == 0:
             return None
         return {'class_ids': cls[0, :n], 'scores': sc[0, :n], 'boxes': bx[0, :n], 'anchor_idx': idx[0, :n].long()}
+
+
+def _host_batch(dataset, images, image_ids, indices, device):
+    """One ``detect`` batch built the reference's way (``DataWrapper.__getitem__`` + default collate, src/engine/detector.py:125-145):
+    ``dataset.preprocess`` on the host, images stacked CHW, every ``image_meta`` field stacked per key."""
+    items = [DataWrapper.item(dataset, im, iid, i) for im, iid, i in zip(images, image_ids, indices)]
+    meta = {}
+    for k in items[0]['image_meta']:
+        vals = [it['image_meta'][k] for it in items]
+        meta[k] = vals if isinstance(vals[0], str) else np.stack([np.asarray(v) for v in vals])
+    return {'image': torch.from_numpy(np.stack([it['image'] for it in items])).to(device), 'image_meta': meta}
+
+
+class DataWrapper(torch.utils.data.Dataset):
+    """A ``Dataset`` view that bypasses the annotations (src/engine/detector.py:125-145) for callers that drive ``detect`` with
+    their own ``DataLoader``: item = ``{'image': CHW float32 (the dataset's own ``preprocess``), 'image_meta': {...}}``."""
+
+    def __init__(self, dataset):
+        super().__init__()
+        self.dataset = dataset
+
+    @staticmethod
+    def item(dataset, image, image_id, index):
+        meta = {'index': index, 'image_id': image_id, 'orig_size': np.array(np.asarray(image).shape, dtype=np.int32)}
+        image, meta, _ = dataset.preprocess(image, meta)
+        return {'image': np.ascontiguousarray(np.asarray(image).transpose(2, 0, 1)), 'image_meta': meta}
+
+    def __getitem__(self, index):
+        image, image_id = self.dataset.load_image(index)
+        return self.item(self.dataset, image, image_id, index)
+
+    def __len__(self):
+        return len(self.dataset)

@@ -105,3 +105,77 @@ def test_detect_images_end_to_end():
         for i, bb in zip(r['anchor_idx'], r['boxes']):
             if int(i) in ref_boxes:
                 np.testing.assert_allclose(bb, ref_boxes[int(i)], atol=2e-2)
+
+
+class _FakeKitti:
+    """The three members ``Detector.detect_dataset`` / ``DataWrapper`` use of the reference's dataset classes
+    (src/datasets/kitti.py:47-55 ``load_image`` -> float32 RGB HWC + id; src/datasets/base.py:43-59 ``preprocess``)."""
+
+    def __init__(self, images, input_size, integral=True):
+        self.images, self.input_size, self.integral = images, input_size, integral
+
+    def __len__(self):
+        return len(self.images)
+
+    def load_image(self, index):
+        im = self.images[index].astype(np.float32)
+        return (im if self.integral else im + 0.25), f'{index:06d}'
+
+    def preprocess(self, image, image_meta, boxes=None):
+        x = (image - oracle.KITTI_RGB_MEAN.reshape(1, 1, 3)) / oracle.KITTI_RGB_STD.reshape(1, 1, 3)
+        scales = np.array([self.input_size[0] / image.shape[0], self.input_size[1] / image.shape[1]], dtype=np.float32)
+        image_meta = dict(image_meta, scales=scales)
+        return oracle.resize_linear_f32(x.astype(np.float32), self.input_size), image_meta, boxes
+
+
+def test_data_wrapper_item_layout():
+    from squeezedet_pytorch_amd.detector import DataWrapper
+    rs = np.random.RandomState(5)
+    ds = _FakeKitti([rs.randint(0, 256, (37, 53, 3), dtype=np.uint8), rs.randint(0, 256, (41, 60, 3), dtype=np.uint8)], (48, 64))
+    w = DataWrapper(ds)
+    assert len(w) == 2
+    it = w[1]
+    assert it['image'].shape == (3, 48, 64) and it['image'].dtype == np.float32
+    m = it['image_meta']
+    assert m['index'] == 1 and m['image_id'] == '000001' and m['orig_size'].tolist() == [41, 60, 3] and m['scales'].shape == (2,)
+
+
+@pytest.mark.gpu
+def test_detect_dataset_driver(capsys):
+    """``Detector.detect_dataset`` (src/engine/detector.py:52-85): batches of raw images through the GPU input pipeline == calling
+    ``detect_images`` batch by batch (ragged last batch, dataset indices in ``image_meta``), the reference's two kinds of log
+    lines, the empty dataset; a dataset whose pixels are not uint8-representable takes the host route (``dataset.preprocess`` +
+    ``detect``) and agrees with the GPU route up to the pre-processing difference of a quarter grey level."""
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd import synthetic
+    from squeezedet_pytorch_amd.detector import Detector
+    from squeezedet_pytorch_amd.model import SqueezeDet
+    cfg = sqd.make_cfg()
+    cfg.batch_size, cfg.num_workers, cfg.print_interval = 2, 2, 1
+    m = SqueezeDet(cfg); m.load_state_dict(synthetic.make_state_dict())
+    det = Detector(m, cfg)
+    rs = np.random.RandomState(3)
+    base = rs.standard_normal((5, 48, 156, 3)) * 60 + 100
+    sizes = [(375, 1242), (370, 1224), (375, 1242), (374, 1238), (376, 1241)]
+    images = [np.clip(np.kron(base[i], np.ones((8, 8, 1))), 0, 255).astype(np.uint8)[:h, :w] for i, (h, w) in enumerate(sizes)]
+    ds = _FakeKitti(images, cfg.input_size)
+    res = det.detect_dataset(ds)
+    out = capsys.readouterr().out
+    assert out.count('eval: [') == 3 and 'Elapsed' in out and 'frames/s' in out
+    assert len(res) == 5 and [r['image_meta']['index'] for r in res] == [0, 1, 2, 3, 4]
+    assert [r['image_meta']['image_id'] for r in res] == [f'{i:06d}' for i in range(5)]
+    want = det.detect_images(images[0:2]) + det.detect_images(images[2:4]) + det.detect_images(images[4:5])
+    assert sum('boxes' in r for r in want) >= 3
+    for r, w in zip(res, want):
+        assert ('boxes' in r) == ('boxes' in w)
+        if 'boxes' in r:
+            assert np.array_equal(r['anchor_idx'], w['anchor_idx']) and np.array_equal(r['boxes'], w['boxes']) and np.array_equal(r['scores'], w['scores'])
+        assert r['image_meta']['orig_size'].tolist() == w['image_meta']['orig_size'].tolist()
+    assert det.detect_dataset(_FakeKitti([], cfg.input_size)) == []
+    # host route: pixels + 0.25 are not uint8-representable
+    res_h = det.detect_dataset(_FakeKitti(images, cfg.input_size, integral=False))
+    assert len(res_h) == 5 and [r['image_meta']['index'] for r in res_h] == [0, 1, 2, 3, 4]
+    for r, w in zip(res_h, want):
+        if 'boxes' in r and 'boxes' in w:
+            common = set(r['anchor_idx'].tolist()) & set(w['anchor_idx'].tolist())
+            assert len(common) >= min(len(r['anchor_idx']), len(w['anchor_idx'])) - 3
