@@ -97,4 +97,5 @@ while time.time() - t0 < budget:
     if not (e1 <= t1 and e2 <= t2 and untouched):
         fail('fire_sq_e1', B=Bq, H=Hq, W=Wq, C=C, S=S, E1=E1, xo=xo, so=so, oo=oo, e1=e1, t1=t1, e2=e2, t2=t2, untouched=untouched)
     n['sq_e1'] += 1
+os.environ.pop('SQD_STEM_WAVE', None); os.environ.pop('SQD_STEM_WGRAD_GATHER', None)
 print(f'{n} cases ok in {time.time() - t0:.0f} s; worst stem error {worst:.2f} of the tolerance')

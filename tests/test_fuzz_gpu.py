@@ -25,3 +25,26 @@ def test_conv_family_randomised_sweep(capsys):
     finally:
         sys.argv = argv
     assert "fuzz ok" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_stem_family_randomised_sweep(capsys, monkeypatch):
+    """scratch/fuzz_stem.py, fixed seed, short budget: the wave stem kernels (values bit for bit against the workgroup kernel, arg-max
+    codes), the gather stem weight gradient (against the dense kernel on the same codes and, flip-aware, against autograd), stem +
+    first squeeze, squeeze + expand1x1, on random image sizes / channel windows."""
+    for k in ('SQD_STEM_WAVE', 'SQD_STEM_WGRAD_GATHER'):          # the script switches kernels through the environment: restore it afterwards
+        monkeypatch.setenv(k, os.environ.get(k, '2' if k == 'SQD_STEM_WAVE' else '1'))
+    argv = sys.argv
+    sys.argv = ["fuzz_stem.py", "12", "20261004"]
+    try:
+        cwd = os.getcwd()
+        os.chdir(ROOT)
+        try:
+            runpy.run_path(os.path.join(ROOT, "scratch", "fuzz_stem.py"), run_name="__main__")
+        except SystemExit as e:
+            assert not e.code, capsys.readouterr().out
+        finally:
+            os.chdir(cwd)
+    finally:
+        sys.argv = argv
+    assert "cases ok" in capsys.readouterr().out
