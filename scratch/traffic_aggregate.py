@@ -11,8 +11,10 @@ def short_name(k):
     m = re.match(r"conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), \d+>", short)
     if m: return f"conv_igemm<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)}>"
     # <TAPS, KC, MT, NT, WAVES, MINW, FUSE, WSTAT>: the name bench.py uses ignores MINW / WSTAT, FUSE = fused Fire expand
-    m = re.match(r"conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false), (true|false)>", short)
+    # (a ninth parameter, CHAIN = squeeze + expand1x1 in one launch, since round 3)
+    m = re.match(r"conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false), (true|false)(, (true|false))?>", short)
     if m:
+        if m.group(9) == "true": return f"fire_sq_e1<{m.group(4)}>"
         base = "fire_expand" if m.group(6) == "true" else "conv_dma"
         return f"{base}<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>"
     m = re.match(r"conv_wino_kernel<(\d+), (\d+)>", short)
