@@ -212,6 +212,27 @@ int sqd_pack_wino_weight(const float* w_oihw, float* u_packed, int No, int Ci, i
  * {w_oihw ptr, u_packed ptr, No, Ci, Npad, dgrad, C/8 * Npad * 8}; blocks_per_desc workgroups walk each record. */
 int sqd_pack_wino_weights_batched(const void* descs_dev, int n, int blocks_per_desc, void* stream);
 
+/* The same convolution with a BALANCED (stream-K) work split (csrc/conv_wino_sk.hip): same layers (Fire expand3x3,
+ * src/model/squeezedet.py:14,20-22; ConvDet, :73-75,83; their data gradients, src/engine/trainer.py:47), same operands
+ * (u_packed from sqd_pack_wino_weight with Npad a multiple of 32) and epilogue order (+= y, * ymul, * yscale, mask, ReLU).
+ * Every resident workgroup gets an equally long run of (4- or 8-group super-group, slice, K chunk) stages; a slice whose upper 16
+ * channels do not exist (N = 72) runs as 16-channel stages over two groups per wave; units cut by a run boundary are summed in
+ * part order through `ws` by the last arriver (bitwise reproducible).
+ *   sqd_wino_sk_grid(): workgroups per launch on the current device (two per CU);
+ *   sqd_wino_sk_schedule (HOST arrays, no GPU needed): ngroups = B * ceil(H/4) * ceil(W/16); minseg = shortest part in stages;
+ *     h_bias_pm = per-mille correction of the 16-channel class's share of the grid (1000 = proportional); writes seg_off [G + 1],
+ *     segs [<= max_segs][8] = {super-group, first channel, first stage, end stage, class, parts, part, first slab}, the record
+ *     count and the number of partial slabs;
+ *   sqd_conv_wino_sk_fwd: seg_off / segs = DEVICE copies of that schedule; ws = nslabs * 8192 floats; cnt = nslabs * 4 unsigned,
+ *     zero before the first launch (every launch leaves them zero). */
+int sqd_wino_sk_grid(void);
+int sqd_wino_sk_schedule(int ngroups, int N, int C, int G, int minseg, int h_bias_pm, int* seg_off, int* segs, int max_segs,
+                         int* nsegs_out, int* nslabs_out);
+int sqd_conv_wino_sk_fwd(const float* x, const float* u_packed, const float* bias, float* y, const float* ymask, const float* ymul,
+                         float yscale, int B, int H, int W, int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff,
+                         int relu, int accumulate, const int* seg_off, const int* segs, int G, int nslabs, float* ws, unsigned* cnt,
+                         void* stream);
+
 /* Fused MaxPool2d(3, 2, ceil_mode) + Fire squeeze 1x1 + ReLU, inference forward (src/model/squeezedet.py:39,42 followed
  * by :12,18): y[..., y_coff : y_coff+N] = ReLU(conv1x1(pool(x[..., x_coff : x_coff+C])) + bias); the pooled tensor is never
  * materialised.  x NHWC [B][H][W][x_pitch], y NHWC [B][Ho][Wo][y_pitch]; w_packed = sqd_pack_conv_weight output for a 1x1

@@ -21,7 +21,7 @@ from .tiles import *  # noqa: F401,F403
 from .tiles import (_tuning, _nearest_tuned, _CFG_DMA, _wino_wgrad_tc)  # noqa: F401
 from . import plans
 from .plans import (ConvPlan, repack_batched, dgrad_weight, FusedExpandPlan, WinoPlan, repack_wino_batched, FireWinoPlan,  # noqa: F401
-                    FireBridgePlan, WgradBatch)
+                    FireBridgePlan, WgradBatch, wino_sk_schedule, wino_sk_host_schedule)
 
 
 def _check_nhwc(t, name):
@@ -140,9 +140,10 @@ def fire_expand(x, x_coff, fplan, y, y_coff):
     return y
 
 
-def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=None, ymul=None):
-    """y[..., y_coff:y_coff+N] (=|+=) conv3x3(x[..., x_coff:x_coff+C]) (+bias) (* ymul) (zero where ymask <= 0) (ReLU),
-    Winograd F(2x2,3x3) kernel.  ``ymask`` / ``ymul`` are read through y's own channel window (same shape as y)."""
+def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=None, ymul=None, yscale=1.0):
+    """y[..., y_coff:y_coff+N] (=|+=) conv3x3(x[..., x_coff:x_coff+C]) (+bias) (* ymul) (* yscale) (zero where ymask <= 0) (ReLU),
+    Winograd F(2x2,3x3) kernel.  ``ymask`` / ``ymul`` are read through y's own channel window (same shape as y).  ``yscale``
+    (a constant factor, e.g. the dropout scale) needs the balanced kernel (``plan.cfg_id`` = tiles.WINO_SK_CFG)."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
     B, H, W, xp = x.shape
     if tuple(y.shape[:3]) != (B, H, W):
@@ -164,10 +165,20 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=No
             _check_nhwc(t, nm)
             if tuple(t.shape) != tuple(y.shape):
                 raise ValueError(f'conv_wino: {nm} must have the shape of y')
-    rc = nat.lib().sqd_conv_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(ymask), nat.ptr(ymul),
-                                     B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff, int(relu), int(accumulate),
-                                     plan.cfg_id, nat.stream_handle(x.device))
-    nat.check(rc, 'sqd_conv_wino_fwd')
+    if plan.cfg_id % 1000 == tiles.WINO_SK_CFG:
+        sk = wino_sk_schedule(B * -(-H // 4) * -(-W // 16), plan.N, plan.C, x.device)
+        rc = nat.lib().sqd_conv_wino_sk_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(ymask), nat.ptr(ymul),
+                                            float(yscale), B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff, int(relu),
+                                            int(accumulate), nat.ptr(sk.seg_off), nat.ptr(sk.segs), sk.G, sk.nslabs, nat.ptr(sk.ws),
+                                            nat.ptr(sk.cnt), nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_conv_wino_sk_fwd')
+    else:
+        if yscale != 1.0:
+            raise ValueError('conv_wino: yscale needs the balanced kernel (cfg tiles.WINO_SK_CFG)')
+        rc = nat.lib().sqd_conv_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(ymask), nat.ptr(ymul),
+                                         B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff, int(relu), int(accumulate),
+                                         plan.cfg_id, nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_conv_wino_fwd')
     if br is not None:
         br.done()
     return y

@@ -127,6 +127,64 @@ class WinoPlan:
             self.bias = bias.detach()
 
 
+_SK_SCHEDULES = {}
+
+
+def wino_sk_params():
+    """(minseg, h_bias_pm) of the balanced Winograd schedule: shortest part of a cut unit in stages, per-mille correction of the
+    16-channel class's share of the grid (env overrides for A/B runs)."""
+    import os
+    return int(os.environ.get('SQD_SK_MINSEG', 2)), int(os.environ.get('SQD_SK_HBIAS', 1000))
+
+
+def wino_sk_grid():
+    """Workgroups of a balanced Winograd launch: every resident slot of the device (``SQD_SK_GRID`` overrides it: tests force
+    many / few parts per unit with it; any grid gives the same results up to the summation order of cut units)."""
+    import os
+    g = int(os.environ.get('SQD_SK_GRID', 0))
+    return g if g > 0 else int(nat.lib().sqd_wino_sk_grid())
+
+
+def wino_sk_host_schedule(ngroups, N, C, G, minseg=2, h_bias_pm=1000):
+    """sqd_wino_sk_schedule as numpy arrays: (seg_off int32 [G + 1], segs int32 [nsegs, 8], nslabs).  Pure host code."""
+    import ctypes
+    import numpy as np
+    nchunks, nslices = C // 8, -(-N // 32)
+    max_segs = G * (2 + 2 * (-(-(ngroups * nslices * nchunks) // (4 * G * nchunks)) + 1)) + 16
+    seg_off = np.zeros(G + 1, dtype=np.int32)
+    segs = np.zeros((max_segs, 8), dtype=np.int32)
+    ns, nslabs = ctypes.c_int(), ctypes.c_int()
+    rc = nat.lib().sqd_wino_sk_schedule(int(ngroups), int(N), int(C), int(G), int(minseg), int(h_bias_pm), seg_off.ctypes.data_as(ctypes.c_void_p),
+                                        segs.ctypes.data_as(ctypes.c_void_p), max_segs, ctypes.byref(ns), ctypes.byref(nslabs))
+    nat.check(rc, 'sqd_wino_sk_schedule')
+    return seg_off, segs[:ns.value].copy(), nslabs.value
+
+
+class WinoSkSchedule:
+    """Device copy of the balanced schedule of one (pixel geometry, N, C) layer shape + its partial-slab workspace and arrival
+    counters (zeroed once; every launch leaves them zero).  Shared by every layer of that shape: launches on one stream are ordered."""
+
+    def __init__(self, ngroups, N, C, device):
+        self.G = wino_sk_grid()
+        minseg, hb = wino_sk_params()
+        seg_off, segs, nslabs = wino_sk_host_schedule(ngroups, N, C, self.G, minseg, hb)
+        self.seg_off = torch.from_numpy(seg_off).to(device)
+        self.segs = torch.from_numpy(segs).contiguous().to(device)
+        self.nslabs = nslabs
+        self.ws = torch.empty(max(nslabs, 1) * 8192, device=device, dtype=torch.float32)
+        self.cnt = torch.zeros(max(nslabs, 1) * 4, device=device, dtype=torch.int32)
+
+
+def wino_sk_schedule(ngroups, N, C, device):
+    key = (int(ngroups), int(N), int(C), str(device), wino_sk_grid()) + wino_sk_params()
+    hit = _SK_SCHEDULES.get(key)
+    if hit is None:
+        if len(_SK_SCHEDULES) > 64:
+            _SK_SCHEDULES.clear()
+        hit = _SK_SCHEDULES[key] = WinoSkSchedule(ngroups, N, C, device)
+    return hit
+
+
 def repack_wino_batched(plans_and_weights, is_dgrad):
     """Re-transform many WinoPlans with ONE kernel launch (pointer-stable).  plans_and_weights: [(WinoPlan, weight)]."""
     if not plans_and_weights:

@@ -152,10 +152,13 @@ def choose_fused_cfg(C, E, npix):
     return (pref or ok)[0]
 
 
+WINO_SK_CFG = 16            # the balanced (stream-K) Winograd kernel, csrc/conv_wino_sk.hip (32-channel packing, four waves)
+
+
 def wino_cfgs():
     """{cfg_id: (slice width, waves per workgroup)} of the Winograd F(2x2,3x3) kernel family."""
     import ctypes
-    out = {}
+    out = {WINO_SK_CFG: (32, 4)}
     for i in range(nat.lib().sqd_wino_num_cfgs()):
         bn, wv = ctypes.c_int(), ctypes.c_int()
         nat.check(nat.lib().sqd_wino_cfg_info(i, ctypes.byref(bn), ctypes.byref(wv)), 'sqd_wino_cfg_info')
@@ -167,6 +170,8 @@ def wino_kernel_name(cfg_id):
     """Name of a Winograd configuration as bench.py / the profiles print it: conv_wino<NT,WAVES> (ids 0..3),
     conv_wino_dp<..> (4..7: deep-prefetch staging), conv_wino_us<..> (8..11: U-stationary, barrier-free)."""
     c = cfg_id % 1000
+    if c == WINO_SK_CFG:
+        return 'conv_wino_sk'
     bn, wv = wino_cfgs()[c]
     return f'conv_wino{("", "_dp", "_us")[c // 4]}<{bn // 16},{wv}>'
 
@@ -175,7 +180,7 @@ def wino_cfg_ok(cfg_id, C):
     """Whether Winograd configuration ``cfg_id`` can run a layer with ``C`` input channels: ids 8..11 (U-stationary kernel)
     keep the slice's whole transformed weight set in LDS next to the patch ring."""
     c = cfg_id % 1000
-    if c < 8:
+    if c < 8 or c == WINO_SK_CFG:
         return True
     bn, wv = wino_cfgs()[c]
     return (2 * wv * 256 * 4 + (C // 8) * 32 * bn * 4) * 4 <= 160 * 1024
