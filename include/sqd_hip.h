@@ -171,6 +171,14 @@ int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales,
                    int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
                    float score_thresh, void* stream);
 
+/* The same with shifts ([B][2] = (dy, dx), may be NULL) added to the boxes after the scale division: the padding / crops terms of
+ * boxes_postprocess (src/utils/boxes.py:149-155) for images pre-processed by sqd_preprocess_u8_padcrop_fwd (the reference's
+ * cfg.forbid_resize branch); per axis only one of padding / crops is non-zero, so one add of (crops - padding) is bit-exact. */
+int sqd_detect_shift_fwd(const float* pred, const float* anchors, const float* scales, const float* shifts, unsigned* keys_ws,
+                         int* det_count, long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
+                         int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh, float score_thresh,
+                         void* stream);
+
 /* Detector.filter on already decoded dense tensors (class_ids int64 [B][A], scores [B][A], boxes [B][A][4]). */
 int sqd_filter_fwd(const long long* class_ids, const float* scores, const float* boxes, unsigned* keys_ws, int* det_count,
                    long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
@@ -183,6 +191,15 @@ int sqd_filter_fwd(const long long* class_ids, const float* scores, const float*
  * out: NCHW fp32 [B][3][H][W]; scales [B][2] = (H/H0, W/W0) or NULL; mean3 / std3: HOST pointers to 3 floats. */
 int sqd_preprocess_u8_fwd(const unsigned char* src, const long long* offsets, const int* sizes, float* out,
                           float* scales, const float* mean3, const float* std3, int B, int H, int W, void* stream);
+
+/* The input pipeline's OTHER branch, cfg.forbid_resize (src/datasets/base.py:53-54): whiten (src/utils/image.py:9-19), then
+ * crop_or_pad (:91-124: per axis zero-pad a smaller image / centre-crop a larger one to the target, floor half in front),
+ * HWC->CHW.  Integer index arithmetic + whiten's one float32 subtract and divide: bit-exact against the reference.
+ * Arguments as sqd_preprocess_u8_fwd; shifts [B][2] fp32 = (crops[0] - padding[0], crops[2] - padding[2]) for
+ * sqd_detect_shift_fwd, or NULL; padcrop [B][8] int32 = padding (top, bottom, left, right), crops (top, bottom, left, right),
+ * or NULL. */
+int sqd_preprocess_u8_padcrop_fwd(const unsigned char* src, const long long* offsets, const int* sizes, float* out, float* shifts,
+                                  int* padcrop, const float* mean3, const float* std3, int B, int H, int W, void* stream);
 
 /* Fused Fire expand (Fire.forward, src/model/squeezedet.py:18-22: expand1x1 and expand3x3 of the squeeze output,
  * concatenated): y[..., y_coff : y_coff+E] = ReLU(conv1x1(x)), y[..., y_coff+E : y_coff+2E] = ReLU(conv3x3(x)) in ONE
@@ -220,18 +237,34 @@ int sqd_pack_wino_weights_batched(const void* descs_dev, int n, int blocks_per_d
  * part order through `ws` by the last arriver (bitwise reproducible).
  *   sqd_wino_sk_grid(): workgroups per launch on the current device (two per CU);
  *   sqd_wino_sk_schedule (HOST arrays, no GPU needed): ngroups = B * ceil(H/4) * ceil(W/16); minseg = shortest part in stages;
- *     h_bias_pm = per-mille correction of the 16-channel class's share of the grid (1000 = proportional); writes seg_off [G + 1],
+ *     h_bias_pm = per-mille correction of the 16-channel class's share of the grid (1000 = proportional); ksplit = 0: contiguous
+ *     ("stream-K") runs, k >= 1: every unit cut at the same K boundaries into k parts dealt round-robin; writes seg_off [G + 1],
  *     segs [<= max_segs][8] = {super-group, first channel, first stage, end stage, class, parts, part, first slab}, the record
  *     count and the number of partial slabs;
  *   sqd_conv_wino_sk_fwd: seg_off / segs = DEVICE copies of that schedule; ws = nslabs * 8192 floats; cnt = nslabs * 4 unsigned,
  *     zero before the first launch (every launch leaves them zero). */
 int sqd_wino_sk_grid(void);
-int sqd_wino_sk_schedule(int ngroups, int N, int C, int G, int minseg, int h_bias_pm, int* seg_off, int* segs, int max_segs,
+int sqd_wino_sk_schedule(int ngroups, int N, int C, int G, int minseg, int h_bias_pm, int ksplit, int* seg_off, int* segs, int max_segs,
                          int* nsegs_out, int* nslabs_out);
 int sqd_conv_wino_sk_fwd(const float* x, const float* u_packed, const float* bias, float* y, const float* ymask, const float* ymul,
                          float yscale, int B, int H, int W, int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff,
                          int relu, int accumulate, const int* seg_off, const int* segs, int G, int nslabs, float* ws, unsigned* cnt,
+                         const unsigned long long* drop_state, int drop_keep16, float drop_scale, unsigned long long* drop_advance,
                          void* stream);
+
+/* Counter-based dropout in front of ConvDet (nn.Dropout(p, inplace=True), src/model/squeezedet.py:71-72,81-82; csrc/sqd_common.h):
+ * the keep decision of element e of the dropped NHWC tensor is a pure function of (seed, step, e) -- one 64-bit hash per four
+ * consecutive elements, keep where a 16-bit field < keep16 = round((1 - p) * 65536), kept values scaled by scale = 1 / (1 - p).
+ * state: DEVICE uint64[2] = {seed, step}.  The last Fire's expand launches apply it in their epilogues (sqd_conv_drop_fwd: the
+ * weight-stationary 1x1 configurations, sqd_conv_cfg_is_dma >= 3; sqd_conv_wino_sk_fwd's drop_state) with e = element index in
+ * the OUTPUT BUFFER (pixel * y_pitch + y_coff + channel); sqd_dropout_mask_fwd writes the same multipliers (scale or 0) of
+ * elements [0, 4 * n4) as a tensor (layer configurations without a fused epilogue; witness of the fused ones);
+ * sqd_dropout_advance adds 1 to step (once per forward; sqd_conv_wino_sk_fwd's drop_advance does the same inside a launch). */
+int sqd_conv_drop_fwd(const float* x, const float* w_packed, const float* bias, float* y, int B, int H, int W, int C, int x_pitch,
+                      int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu, const unsigned long long* drop_state, int keep16,
+                      float scale, int cfg_id, void* stream);
+int sqd_dropout_mask_fwd(const unsigned long long* state, int keep16, float scale, float* mask, long long n4, void* stream);
+int sqd_dropout_advance(unsigned long long* state, void* stream);
 
 /* Fused MaxPool2d(3, 2, ceil_mode) + Fire squeeze 1x1 + ReLU, inference forward (src/model/squeezedet.py:39,42 followed
  * by :12,18): y[..., y_coff : y_coff+N] = ReLU(conv1x1(pool(x[..., x_coff : x_coff+C])) + bias); the pooled tensor is never
@@ -318,6 +351,15 @@ int sqd_fire_pool_bridge_fwd(const float* x, const float* u_packed, const float*
  * order: g = grad * min(1, max_norm / (total_norm + 1e-6)); g += wd * p; buf = momentum * buf + g; p -= lr * buf. */
 int sqd_sgd_clip_step(const void* descs_dev, int n, const float* grad_base, const float* total_norm, float max_norm, float lr,
                       float momentum, float weight_decay, int blocks_per_desc, void* stream);
+/* The gradient norm of clip_grad_norm_ (src/engine/trainer.py:49) without a torch reduction kernel: sqd_grad_sumsq writes
+ * sqd_grad_sumsq_parts() partial sums of squares of the flat gradient (fixed tree: bitwise reproducible); sqd_sgd_clip_step_parts is
+ * sqd_sgd_clip_step with total_norm = sqrt(sum of the partials in index order), every workgroup evaluating it for itself; norm_out
+ * (DEVICE float or NULL) receives the norm. */
+int sqd_grad_sumsq(const float* grad_flat, long long n, float* parts, void* stream);
+int sqd_grad_sumsq_parts(void);
+int sqd_sgd_clip_step_parts(const void* descs_dev, int n, const float* grad_base, const float* sumsq_parts, float* norm_out,
+                            float max_norm, float lr, float momentum, float weight_decay, int blocks_per_desc, void* stream);
+
 
 #ifdef __cplusplus
 }

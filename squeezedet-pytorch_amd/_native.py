@@ -48,8 +48,10 @@ _SIGNATURES = {
     'sqd_resolve_fwd': [c_p] * 7 + [c_i] * 5 + [c_p],
     'sqd_decode_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_detect_fwd': [c_p] * 9 + [c_i] * 6 + [c_f, c_f, c_p],
+    'sqd_detect_shift_fwd': [c_p] * 10 + [c_i] * 6 + [c_f, c_f, c_p],
     'sqd_filter_fwd': [c_p] * 9 + [c_i] * 4 + [c_f, c_f, c_p],
     'sqd_preprocess_u8_fwd': [c_p] * 5 + [ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i, c_i, c_p],
+    'sqd_preprocess_u8_padcrop_fwd': [c_p] * 6 + [ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i, c_i, c_p],
     'sqd_pool_squeeze_fwd': [c_p] * 4 + [c_i] * 10 + [c_p],
     'sqd_fire_expand_fwd': [c_p] * 4 + [c_i] * 11 + [c_p],
     'sqd_kitti_ap': [c_i] + [c_p] * 12,
@@ -57,14 +59,20 @@ _SIGNATURES = {
     'sqd_wino_cfg_info': [c_i, c_p, c_p],
     'sqd_conv_wino_fwd': [c_p] * 6 + [c_i] * 13 + [c_p],
     'sqd_wino_sk_grid': [],
-    'sqd_wino_sk_schedule': [c_i] * 6 + [c_p, c_p, c_i, c_p, c_p],
-    'sqd_conv_wino_sk_fwd': [c_p] * 6 + [c_f] + [c_i] * 12 + [c_p, c_p, c_i, c_i, c_p, c_p, c_p],
+    'sqd_wino_sk_schedule': [c_i] * 7 + [c_p, c_p, c_i, c_p, c_p],
+    'sqd_conv_wino_sk_fwd': [c_p] * 6 + [c_f] + [c_i] * 12 + [c_p, c_p, c_i, c_i, c_p, c_p] + [c_p, c_i, c_f, c_p] + [c_p],
+    'sqd_conv_drop_fwd': [c_p] * 4 + [c_i] * 11 + [c_p, c_i, c_f, c_i, c_p],
+    'sqd_dropout_mask_fwd': [c_p, c_i, c_f, c_p, ctypes.c_longlong, c_p],
+    'sqd_dropout_advance': [c_p, c_p],
     'sqd_pack_wino_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_pack_wino_weights_batched': [c_p, c_i, c_i, c_p],
     'sqd_pack_wino_fire': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_fire_wino_fwd': [c_p] * 5 + [c_i] * 13 + [c_p],
     'sqd_fire_bridge_fwd': [c_p] * 6 + [c_i] * 13 + [c_p],
     'sqd_sgd_clip_step': [c_p, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p],
+    'sqd_grad_sumsq': [c_p, ctypes.c_longlong, c_p, c_p],
+    'sqd_grad_sumsq_parts': [],
+    'sqd_sgd_clip_step_parts': [c_p, c_i, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p],
     'sqd_fire_pool_bridge_fwd': [c_p] * 6 + [c_i] * 15 + [c_p],
     'sqd_encode_gt_fwd': [c_p] * 8 + [c_i, c_i, c_i, c_i, c_p],
     'sqd_loss_fwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],

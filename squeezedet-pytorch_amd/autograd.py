@@ -20,8 +20,10 @@ def _needs_grad(base):
     return torch.is_grad_enabled() and any(p.requires_grad for p in base.parameters())
 
 
-def run_backbone_forward(base, image, save=False, drop_mask=None):
-    """Launch the forward plan.  Returns (pred_nhwc [B,H,W,A_per_cell*(C+5)], saved dict | None)."""
+def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
+    """Launch the forward plan.  Returns (pred_nhwc [B,H,W,A_per_cell*(C+5)], saved dict | None).  Dropout in front of ConvDet
+    (training): ``drop`` (an ops.DropState) applies it inside the last Fire's expand launches, or ``drop_mask`` (a scaled keep mask,
+    NHWC) multiplies it in."""
     if not image.is_cuda:
         raise RuntimeError('SqueezeDetBase runs on the MI355X HIP kernels only: input must be a CUDA/HIP tensor')
     if image.dtype != torch.float32:
@@ -92,7 +94,7 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                 Bq, H, W, C = a.shape
             assert C == cin, f'layer {i}: expected {cin} channels, got {C}'
             npix = Bq * H * W
-            fusable = not save and not (drop_mask is not None and i == len(layers) - 1)
+            fusable = not save and not ((drop_mask is not None or drop is not None) and i == len(layers) - 1)
             nxt = layers[i + 1] if i + 1 < len(layers) else None
             nxt2 = layers[i + 2] if i + 2 < len(layers) else None
             # which launch takes this Fire's expand pair (pure table look-ups; decided before the squeeze because the squeeze may ride
@@ -107,10 +109,20 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                 xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fusable and base.fuse_expand_wino and base.use_winograd) else None
                 fcfg = ops.choose_fused_cfg(s, e1, npix) if (fusable and xcfg is None and base.fuse_expand and e1 == e3) else None
             ym = drop_mask if (drop_mask is not None and i == len(layers) - 1) else None
+            dr = drop if (drop is not None and i == len(layers) - 1) else None
+            dcfg = None
+            if dr is not None:
+                # the fused form needs a weight-stationary 1x1 configuration and the balanced Winograd kernel (8 | squeeze width);
+                # otherwise this step's mask is drawn as a tensor by the stand-alone kernel and multiplied in like a given mask
+                dcfg = ops.conv_drop_cfg(s, e1, npix) if (base.fused_dropout and s % 8 == 0 and base.use_winograd) else None
+                if dcfg is None:
+                    ym = ops.dropout_mask(dr, (Bq, H, W, e1 + e3))
+                    drop_mask = ym
+                    dr = None
             # squeeze + expand1x1 in ONE launch (the squeeze tile feeds the expand1x1 from registers; forward of inference AND training)
             # wherever the two would otherwise be separate plain launches
             chain = (bridged is None and unpooled is None and zseg is None and ycfg is None and xcfg is None and fcfg is None and ym is None
-                     and base.fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1))
+                     and dr is None and base.fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1))
             out = None
             if bridged is not None:
                 sq, bridged = bridged, None
@@ -154,9 +166,15 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
                 # inference: both expands in one launch (they read the same squeeze tile; the 1x1 rides along as extra
                 # channel groups that only run the centre tap)
                 ops.fire_expand(sq, 0, base.fused_expand_plan(i, fire, fcfg), out, 0)
+            elif dr is not None:
+                # dropout in front of ConvDet (reference: squeezedet.py:81-82) inside the two expand launches: the keep decision of an
+                # element is a function of (seed, step, its index in `out`), evaluated in the epilogue -- no mask tensor
+                ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, dcfg), out, 0, relu=True, drop=dr)
+                ops.conv_wino(sq, 0, base.wino_plan(f'{i}.expand3x3', fire.expand3x3, ops.WINO_SK_CFG), out, e1, relu=True, drop=dr)
+                drop_applied = True
             else:
-                # dropout in front of ConvDet (reference: squeezedet.py:81-82): relu(x) * m == relu(x * m) for the non-negative
-                # scaled keep mask, so it is the `ymul` epilogue of the last Fire's two expand kernels -- no extra pass
+                # ... or as a given mask: relu(x) * m == relu(x * m) for the non-negative scaled keep mask, so it is the `ymul`
+                # epilogue of the last Fire's two expand kernels -- no extra pass
                 ops.conv(sq, 0, base.plan(f'{i}.expand1x1', fire.expand1x1, ops.choose_cfg(1, s, e1, npix)), out, 0, relu=True,
                          ymul=ym, ymul_coff=0)
                 base.conv3x3(f'{i}.expand3x3', fire.expand3x3, sq, 0, out, e1, relu=True, ymul=ym)
@@ -165,31 +183,32 @@ def run_backbone_forward(base, image, save=False, drop_mask=None):
             if save:
                 saved[f'fire{i}'] = (a, sq, out)
             a = out
+    if drop is not None and not drop_applied and drop_mask is None:
+        drop_mask = ops.dropout_mask(drop, tuple(a.shape))
     if drop_mask is not None and not drop_applied:
         a = a * drop_mask                      # (layer tables that do not end in a Fire: elementwise fallback)
     Bq, H, W, C = a.shape
     cd = base.convdet
     pred = torch.empty(Bq, H, W, cd.out_channels, device=a.device, dtype=torch.float32)
-    base.conv3x3('convdet', cd, a, 0, pred, 0, relu=False)
+    fused_rng = drop is not None and drop_applied and drop_mask is None
+    if drop is not None and C % 8 == 0 and base.use_winograd:
+        # ConvDet on the balanced Winograd kernel; its launch advances the dropout step (this forward's mask is consumed)
+        ops.conv_wino(a, 0, base.wino_plan('convdet', cd, ops.WINO_SK_CFG), pred, 0, relu=False, drop_advance=drop)
+    else:
+        base.conv3x3('convdet', cd, a, 0, pred, 0, relu=False)
+        if drop is not None:
+            ops.dropout_advance(drop)
     if save:
         saved['convdet_in'] = a
         saved['drop_mask'] = drop_mask
+        # with the fused form the backward needs no mask: convdet_in > 0 exactly where the element was kept AND its ReLU was active
+        saved['drop_scale'] = float(drop.scale) if fused_rng else None
     return pred, saved
 
 
 def _make_drop_mask(base, like_nhwc_shape, device):
-    if base._forced_drop_mask is not None:
-        return base._forced_drop_mask.to(device).permute(0, 2, 3, 1).contiguous()
-    # nn.Dropout semantics (Bernoulli keep mask scaled by 1/(1-p)) drawn directly in NHWC: one fused torch RNG kernel
-    # on a tensor of ones yields the scaled mask itself (elementwise plumbing; the stream differs from the reference's
-    # CPU generator either way -- tests inject the mask)
-    key = (tuple(like_nhwc_shape), str(device))
-    ones = base._ones_cache.get(key)
-    if ones is None:
-        base._ones_cache.clear()
-        ones = torch.ones(like_nhwc_shape, device=device)
-        base._ones_cache[key] = ones
-    return torch.nn.functional.dropout(ones, base.dropout_prob, training=True)
+    """An injected mask (tests: NCHW, already scaled by 1 / (1 - p)) in the layout the epilogues read."""
+    return base._forced_drop_mask.to(device).permute(0, 2, 3, 1).contiguous()
 
 
 def _feature_shape(base, image):
@@ -208,13 +227,18 @@ def _feature_shape(base, image):
 
 def backbone_apply(base, image):
     train_drop = base.training and base.dropout is not None
-    drop_mask = _make_drop_mask(base, _feature_shape(base, image), image.device) if train_drop else None
+    drop_mask = drop = None
+    if train_drop:
+        if base._forced_drop_mask is not None:
+            drop_mask = _make_drop_mask(base, _feature_shape(base, image), image.device)
+        else:
+            drop = base.drop_state(image.device)
     if _needs_grad(base):
         from .backward import BackboneFn
         params = [p for _, p in base.named_parameters()]
-        pred = BackboneFn.apply(base, image, drop_mask, *params)
+        pred = BackboneFn.apply(base, image, drop_mask, drop, *params)
     else:
-        pred, _ = run_backbone_forward(base, image, save=False, drop_mask=drop_mask)
+        pred, _ = run_backbone_forward(base, image, save=False, drop_mask=drop_mask, drop=drop)
     B = pred.shape[0]
     out = pred.view(B, -1, base.num_classes + 5)
     if out.shape[1] != base.num_anchors:

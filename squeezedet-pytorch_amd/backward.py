@@ -116,7 +116,16 @@ def run_backbone_backward(base, saved, dpred):
     assert layers[last][0] == 'fire'
     out_last = saved[f'fire{last}'][2]
     dA = torch.empty_like(out_last)
-    base.dgrad3x3('convdet', cd, dpred, 0, dA, ymul=saved['drop_mask'], ymask=out_last)
+    if saved.get('drop_scale') is not None:
+        # fused dropout: out_last IS the dropped ReLU output (> 0 exactly where kept and active), so the gradient is masked by it and
+        # scaled by the constant 1 / (1 - p): no mask tensor is read
+        if ncd % 8 == 0:
+            ops.conv_wino(dpred, 0, base.wino_plan('convdet', cd, ops.WINO_SK_CFG, 'dgrad'), dA, 0, ymask=out_last, yscale=saved['drop_scale'])
+        else:
+            base.dgrad3x3('convdet', cd, dpred, 0, dA, ymask=out_last)
+            dA.mul_(saved['drop_scale'])
+    else:
+        base.dgrad3x3('convdet', cd, dpred, 0, dA, ymul=saved['drop_mask'], ymask=out_last)
     for i in range(last, 1, -1):
         l = layers[i]
         if l[0] == 'pool':
@@ -182,8 +191,8 @@ def run_backbone_backward(base, saved, dpred):
 
 class BackboneFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, base, image, drop_mask, *params):
-        pred, saved = run_backbone_forward(base, image.detach(), save=True, drop_mask=drop_mask)
+    def forward(ctx, base, image, drop_mask, drop, *params):
+        pred, saved = run_backbone_forward(base, image.detach(), save=True, drop_mask=drop_mask, drop=drop)
         ctx.base = base
         ctx.saved = saved
         ctx.names = [n for n, _ in base.named_parameters()]
@@ -193,7 +202,7 @@ class BackboneFn(torch.autograd.Function):
     def backward(ctx, dpred):
         grads = run_backbone_backward(ctx.base, ctx.saved, dpred)
         ctx.saved = None
-        return (None, None, None) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
 class LossFn(torch.autograd.Function):

@@ -107,6 +107,9 @@ def _rng_state_here(model):
     dev = _model_device(model)
     if dev is not None:
         st['cuda'] = torch.cuda.get_rng_state(dev)
+    base = getattr(_unwrap(model), 'base', None)
+    if base is not None and hasattr(base, 'get_dropout_rng'):
+        st['sqd_dropout'] = base.get_dropout_rng()          # (seed, step) of the counter-based dropout in front of ConvDet, or None
     return st
 
 
@@ -188,8 +191,13 @@ def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, restore_rng=
         dev = _model_device(model)
         if dev is not None and 'cuda' in st:
             torch.cuda.set_rng_state(st['cuda'], dev)
-        if len(states) == world:
-            # this rank's own streams are back: a later attach_data_parallel / Trainer(...) must not re-seed them
-            from .trainer import mark_rank_streams_set
-            mark_rank_streams_set(True)
+        base = getattr(_unwrap(model), 'base', None)
+        if dev is not None and base is not None and st.get('sqd_dropout') is not None and hasattr(base, 'set_dropout_rng'):
+            seed, step = st['sqd_dropout']
+            # a file with fewer streams than ranks: every rank continues the saved step on a seed of its own
+            base.set_dropout_rng(seed + (rank // len(states)) * 0x9e3779b97f4a7c15 if len(states) != world else seed, step, dev)
+        from .trainer import mark_rank_streams_set
+        # all ranks' own streams are back: a later attach_data_parallel / Trainer(...) must not re-seed them.  Fewer streams than
+        # ranks: several ranks now share a torch stream, so the next attach has to offset them again
+        mark_rank_streams_set(len(states) == world)
     return ckpt['epoch']

@@ -43,6 +43,8 @@ struct ConvArgs {
   int xmask_pitch, xmask_coff;
   const float* ymask; const float* ymul;      // epilogue: zero where ymask <= 0 (ReLU backward), multiply by ymul (dropout)
   int ymask_pitch, ymask_coff, ymul_pitch, ymul_coff;
+  // epilogue (conv_ws family, sqd_conv_drop_fwd): counter-based dropout of the output, sqd_common.h; drop_state = {seed, step} or null
+  const unsigned long long* drop_state; int drop_keep; float drop_scale;
   long long total_px;
   // CHAIN (sqd_fire_squeeze_expand1x1_fwd): a second 1x1 convolution applied to this launch's own (ReLU'd) output tile before it
   // leaves the registers -- Fire.squeeze -> squeeze_activation -> Fire.expand1x1 -> expand1x1_activation (src/model/squeezedet.py:17-19)
@@ -783,8 +785,9 @@ __global__ __launch_bounds__(WV * 64) void conv_ws_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
   const float relu_lo = a.relu ? 0.f : -__builtin_inff();
-  const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
-  const bool plain_epi = !acc_i && !has_mul && !has_mask;
+  const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr, has_drop = a.drop_state != nullptr;
+  const bool plain_epi = !acc_i && !has_mul && !has_mask && !has_drop;
+  const SqdDrop dropk = has_drop ? sqd_drop_key(a.drop_state[0], a.drop_state[1], a.drop_keep, a.drop_scale) : SqdDrop{0u, 0u, 0u, 0.f};
   const float* const wL = wS + (g * BN + lr) * 4;       // + (plane group * 4 * BN + j * 16) * 4: per-lane base of the A operands
   const float* const bL0 = ringW + (g * 16 + lr) * 4;   // + (slot * 128 + sk * 64) * 4
 
@@ -856,6 +859,8 @@ __global__ __launch_bounds__(WV * 64) void conv_ws_kernel(ConvArgs a) {
           f32x4 v = acc[j] + biasv[j];
           if (acc_i) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, off, ysoff, 0));
           if (has_mul) v *= __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mulres, (lr * a.ymul_pitch + 4 * g) * 4 + j * 64, (int)((unsigned)tile * 16u * (unsigned)a.ymul_pitch * 4u), 0));
+          if (has_drop)        // element index in the output BUFFER (pixel * pitch + channel): the same element gets the same bits from any kernel
+            v *= sqd_drop_mul4((unsigned long long)(((long long)tile * 16 + lr) * a.y_pitch + a.y_coff + n0 + j * 16 + 4 * g) >> 2, dropk);
           if (has_mask) {
             const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(maskres, (lr * a.ymask_pitch + 4 * g) * 4 + j * 64, (int)((unsigned)tile * 16u * (unsigned)a.ymask_pitch * 4u), 0));
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
@@ -1209,11 +1214,12 @@ extern "C" int sqd_conv_cfg_info(int cfg_id, int* taps, int* kc, int* tile_px, i
   return SQD_OK;
 }
 
-extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
-                            const float* xmask, const float* ymask, const float* ymul, int B, int H, int W, int C,
-                            int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
-                            int accumulate, int xmask_pitch, int xmask_coff, int ymask_pitch, int ymask_coff,
-                            int ymul_pitch, int ymul_coff, int cfg_id, void* stream) {
+static int conv_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y,
+                         const float* xmask, const float* ymask, const float* ymul, int B, int H, int W, int C,
+                         int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
+                         int accumulate, int xmask_pitch, int xmask_coff, int ymask_pitch, int ymask_coff,
+                         int ymul_pitch, int ymul_coff, int cfg_id, void* stream, const unsigned long long* drop_state, int drop_keep,
+                         float drop_scale) {
   SQD_CHECK_ARG(x && w_packed && y);
   SQD_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && N > 0);
   // cfg_id = tile configuration + 1000 * k: k > 0 caps the persistent grid at k workgroups per CU (fewer, longer tile
@@ -1237,8 +1243,10 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   a.relu = relu; a.accumulate = accumulate; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8; a.wg_cap = wg_cap; a.fuse_e = 0;
   a.xmask_pitch = xmask_pitch; a.xmask_coff = xmask_coff;
   a.total_px = (long long)B * H * W;
+  a.drop_state = drop_state; a.drop_keep = drop_keep; a.drop_scale = drop_scale;
   hipStream_t s = (hipStream_t)stream;
   const ConvCfg& c = kConvCfgs[cfg_id];
+  if (drop_state && c.dma < 3) return SQD_ERR_UNSUPPORTED;      // only the weight-stationary 1x1 family carries the dropout epilogue
 #define SQD_WS_CASE(Nn) \
   if (c.dma >= 3 && c.nt == Nn) return (c.dma == 4) ? launch_conv_ws<Nn, 8>(a, s) : launch_conv_ws<Nn, 4>(a, s);
   SQD_WS_CASE(1) SQD_WS_CASE(2) SQD_WS_CASE(3) SQD_WS_CASE(4) SQD_WS_CASE(6)
@@ -1305,6 +1313,27 @@ extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* 
   SQD_CONV_CASE(1, 64, 2, 2)
 #undef SQD_CONV_CASE
   return SQD_ERR_UNSUPPORTED;
+}
+
+extern "C" int sqd_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
+                            const float* xmask, const float* ymask, const float* ymul, int B, int H, int W, int C,
+                            int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
+                            int accumulate, int xmask_pitch, int xmask_coff, int ymask_pitch, int ymask_coff,
+                            int ymul_pitch, int ymul_coff, int cfg_id, void* stream) {
+  return conv_fwd_impl(x, w_packed, bias, y, xmask, ymask, ymul, B, H, W, C, x_pitch, x_coff, N, Npad, y_pitch, y_coff, relu, accumulate,
+                       xmask_pitch, xmask_coff, ymask_pitch, ymask_coff, ymul_pitch, ymul_coff, cfg_id, stream, nullptr, 0, 0.f);
+}
+
+// Forward convolution + bias (+ ReLU) + counter-based dropout of the output (sqd_common.h): the last Fire's expand1x1 in training
+// mode (reference: Fire.forward + nn.Dropout, src/model/squeezedet.py:18-22,81-82; relu and dropout commute, the scale being > 0).
+// drop_state: DEVICE {seed, step} (uint64 x 2); keep16 = round((1 - p) * 65536); scale = 1 / (1 - p).  cfg_id must be a
+// weight-stationary 1x1 configuration (sqd_conv_cfg_is_dma >= 3), else SQD_ERR_UNSUPPORTED.
+extern "C" int sqd_conv_drop_fwd(const float* x, const float* w_packed, const float* bias, float* y, int B, int H, int W, int C,
+                                 int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
+                                 const unsigned long long* drop_state, int keep16, float scale, int cfg_id, void* stream) {
+  SQD_CHECK_ARG(drop_state && keep16 >= 0 && keep16 <= 65536);
+  return conv_fwd_impl(x, w_packed, bias, y, nullptr, nullptr, nullptr, B, H, W, C, x_pitch, x_coff, N, Npad, y_pitch, y_coff, relu, 0,
+                       0, 0, 0, 0, 0, 0, cfg_id, stream, drop_state, keep16, scale);
 }
 
 // Fused Fire expand: y[..., y_coff : y_coff+E] = ReLU(conv1x1(x)), y[..., y_coff+E : y_coff+2E] = ReLU(conv3x3(x)) in one

@@ -22,6 +22,8 @@
 //     so the kernel cannot deadlock whatever the residency).  The last arriver returns the counter to zero.
 #include "sqd_common.h"
 #include <type_traits>
+#include <algorithm>
+#include <stdlib.h>
 
 #ifndef SQD_SK_U_FIRST
 #define SQD_SK_U_FIRST 0          /* 1: the next stage's U slice is requested right behind the stage barrier (A/B builds) */
@@ -37,6 +39,9 @@ struct WinoSkArgs {
   int relu, accumulate;
   const float* ymask; const float* ymul;     // epilogue (same pitch / channel offset as y): multiply by ymul, zero where ymask <= 0
   float yscale;                              // epilogue: multiply by a constant (1 = off)
+  const unsigned long long* drop_state;      // epilogue: counter-based dropout of the output (sqd_common.h), {seed, step} or null
+  int drop_keep; float drop_scale;
+  unsigned long long* drop_advance;          // != null: one lane of the launch adds 1 to drop_advance[1] (the forward's mask is consumed)
   int gxn, gyn;
   unsigned gxn_m, gyn_m;
   int ngroups;
@@ -67,8 +72,10 @@ __device__ __forceinline__ f32x4 sk_relu4(f32x4 v, float lo) {
   return v;
 }
 
-// NT 16-channel blocks per slice, GW groups per wave (NT * GW == 2).
-template <int NT, int GW>
+// NT 16-channel blocks per slice, GW groups per wave (NT * GW == 2).  FULL: the epilogue options of the backward and of training
+// (accumulate, ymul, yscale, dropout, ymask); the plain instantiation (bias + optional ReLU: every inference launch) keeps them out
+// of its register budget.
+template <int NT, int GW, bool FULL>
 __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, const int send) {
   static_assert(NT * GW == 2, "128 accumulator registers per wave");
   constexpr int WV = 4;
@@ -166,60 +173,33 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
   const float* const uR0 = UB + g * 64 + lr * 4;
   f32x4* const parkW = (f32x4*)(VB + wv_s * 2048) + lane;    // slot k = (gw * 4 + px) * NT + j
 
-  const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
-  const float yscale = a.yscale;
+  const int acc_i = FULL && a.accumulate, has_mul = FULL && a.ymul != nullptr, has_mask = FULL && a.ymask != nullptr;
+  const int has_drop = FULL && a.drop_state != nullptr;
+  const float yscale = FULL ? a.yscale : 1.0f;
   const int has_scale = yscale != 1.0f;
+  const SqdDrop dropk = has_drop ? sqd_drop_key(a.drop_state[0], a.drop_state[1], a.drop_keep, a.drop_scale) : SqdDrop{0u, 0u, 0u, 0.f};
   auto epi = [&](f32x4 v, float* dst, const float* mul, const float* mask) {
-    if (acc_i) v += *(const f32x4*)dst;                       // (the bias is already inside: accumulator (1,1) started from it)
-    if (has_mul) v *= *(const f32x4*)mul;
-    if (has_scale) v *= yscale;
-    if (has_mask) {
-      const f32x4 m = *(const f32x4*)mask;
-      v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    if constexpr (FULL) {
+      if (acc_i) v += *(const f32x4*)dst;                     // (the bias is already inside: accumulator (1,1) started from it)
+      if (has_mul) v *= *(const f32x4*)mul;
+      if (has_scale) v *= yscale;
+      if (has_drop) v *= sqd_drop_mul4((unsigned long long)(dst - a.y) >> 2, dropk);      // element index in the output buffer
+      if (has_mask) {
+        const f32x4 m = *(const f32x4*)mask;
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+      }
     }
     *(f32x4*)dst = sk_relu4(v, relu_lo);
   };
   // partial slabs: buffer resource; stores and loads carry sc1 (aux 16): write-through, L1-bypassing
   const __amdgpu_buffer_rsrc_t wsres = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws, 0, 0x7ffffff0, 0x00020000);
 
-  // the finished segment's tile(s): stored, or (a unit cut by a range boundary) handed over / reduced
-  auto flush = [&](int ps) {
-    const SkSeg sg = sk_load_seg(a.segs + ps);
+  // The finished segment's tile(s) sit in the parking area (inverse-transformed).  A whole unit is stored straight away; a unit
+  // cut into parts goes through three steps, one per stage top, so that no step waits for memory on the stage's critical path:
+  //   A: the partial slab is stored (write-through);  B (the stage-top vmcnt(0) has drained those stores): the arrival ticket is
+  //   drawn;  C (the ticket has returned): the last arriver adds every part's slab in part order and stores the tile.
+  auto store_tile = [&](const SkSeg sg) {                    // epilogue: parking area -> y
     const int n0 = sg.n0;
-#ifndef SK_ABL_NOPART
-    if (sg.nparts > 1) {
-      const unsigned slabB = (unsigned)((sg.slab0 + sg.part) * WV + wv_s) * 8192u;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_sk, parkW[k * 64]), wsres, lane * 16 + k * 1024, (int)slabB, 16);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 1" ::: "memory");                // (SGPR-soffset 16-byte store followed by a write of its data register: conv_wino.hip)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's slab has left the chip's caches ...
-      unsigned t = 0;
-      unsigned* const cw = a.cnt + (sg.slab0 * WV + wv_s);
-      if (lane == 0) t = __hip_atomic_fetch_add(cw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before it is counted
-      t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-      if ((int)t != sg.nparts - 1) return;
-      // last arriver of this (unit, wave): every part's slab is complete.  Add them in part order, through the parking area.
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (lane == 0) __hip_atomic_store(cw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int pt = 0; pt < sg.nparts; ++pt) {
-        const unsigned sb = (unsigned)((sg.slab0 + pt) * WV + wv_s) * 8192u;
-#pragma unroll
-        for (int kb = 0; kb < 8; kb += 4) {                  // (four loads in flight: the accumulators of the running segment are live here)
-          f32x4 v[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsres, lane * 16 + (kb + k) * 1024, (int)sb, 16));
-#pragma unroll
-          for (int k = 0; k < 4; ++k) parkW[(kb + k) * 64] = (pt == 0) ? v[k] : parkW[(kb + k) * 64] + v[k];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-#endif
 #pragma unroll
     for (int gw = 0; gw < GW; ++gw) {
       const GPos gp = group_pos(sg.tile, gw);
@@ -240,6 +220,42 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
       }
     }
   };
+  auto step_a = [&](int ps) {                                // -> true: a cut unit, its slab is on the way
+    const SkSeg sg = sk_load_seg(a.segs + ps);
+    if (sg.nparts <= 1) { store_tile(sg); return false; }
+    const unsigned slabB = (unsigned)((sg.slab0 + sg.part) * WV + wv_s) * 8192u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_sk, parkW[k * 64]), wsres, lane * 16 + k * 1024, (int)slabB, 16);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 1" ::: "memory");                  // (SGPR-soffset 16-byte store followed by a write of its data register: conv_wino.hip)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return true;
+  };
+  auto step_b = [&](int ps) {                                // this wave's slab has left the chip's caches (vmcnt(0) since): count it
+    const int slab0 = __builtin_amdgcn_readfirstlane(((const int*)(a.segs + ps))[7]);
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(a.cnt + (slab0 * WV + wv_s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  auto step_c = [&](int ps, unsigned t) {
+    const SkSeg sg = sk_load_seg(a.segs + ps);
+    if (__builtin_amdgcn_readfirstlane((int)t) != sg.nparts - 1) return;
+    // last arriver of this (unit, wave): every part's slab is complete.  Add them in part order, through the parking area.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane == 0) __hip_atomic_store(a.cnt + (sg.slab0 * WV + wv_s), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int pt = 0; pt < sg.nparts; ++pt) {                 // one slab (8 loads) in flight: the running segment's accumulators are live here
+      const unsigned sb = (unsigned)((sg.slab0 + pt) * WV + wv_s) * 8192u;
+      f32x4 va[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) va[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsres, lane * 16 + k * 1024, (int)sb, 16));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) parkW[k * 64] = (pt == 0) ? va[k] : parkW[k * 64] + va[k];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store_tile(sg);
+  };
 
   SkSeg seg = sk_load_seg(a.segs + sidx);
   unsigned csoff[GW];                                         // byte offset of the current groups' patch origins
@@ -254,7 +270,8 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
 #pragma unroll
   for (int it = 0; it < U_IT; ++it) dma_u_one(it, (unsigned)seg.c0 * u_chunkB + (unsigned)seg.n0 * 64u, 0);
   int ubuf = 0;
-  int pending = -1;                                          // segment whose tile sits in the parking area
+  int pend_a = -1, pend_b = -1, pend_c = -1;                 // segments waiting for step A (tile parked) / B (slab stored) / C (ticket drawn)
+  unsigned ticket = 0;
 
   for (;;) {
     // the slice's bias for this lane's channels, entering through accumulator (1,1) of the part that owns K chunk 0
@@ -269,7 +286,9 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
       // this wave's share of the stage's DMA must have LANDED before the barrier publishes it to the other waves
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                       // all waves left the previous U buffer
-      if (pending >= 0) { flush(pending); pending = -1; }
+      if (pend_c >= 0) { step_c(pend_c, ticket); pend_c = -1; }
+      if (pend_b >= 0) { ticket = step_b(pend_b); pend_c = pend_b; pend_b = -1; }
+      if (pend_a >= 0) { if (step_a(pend_a)) pend_b = pend_a; pend_a = -1; }
       const int last_i = 1 - (int)((unsigned)(cc + 1 - seg.c1) >> 31);
       const bool last = last_i != 0;
       // the stage fetched during this one: the next K chunk of this segment, or (last chunk) the first stage of the next segment
@@ -329,14 +348,25 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
             for (int j = 0; j < NT; ++j) afr[j] = *(const f32x4*)(uR + (step * NT + j) * 256);
           };
           auto mfma_pos = [&](int step, const f32x4 (&afr)[NT], int h) {
-            const int p = 2 * step + h;
+            if constexpr (NT == 1) {
+              // one block per position: call h covers k-step h of BOTH positions of the step, so that two consecutive MFMAs never
+              // chain on the same accumulator (the operand quad holds [position parity][k-step])
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-              for (int j = 0; j < NT; ++j) {
-                const f32x4 c0v = (FIRST && t == 0) ? ((p == 5) ? biasv[j] : (f32x4){0.f, 0.f, 0.f, 0.f}) : acc[gw][p][j];
-                acc[gw][p][j] = mfma16(afr[j][2 * h + t], vv[p][t], c0v);
+              for (int hh = 0; hh < 2; ++hh) {
+                const int p = 2 * step + hh;
+                const f32x4 c0v = (FIRST && h == 0) ? ((p == 5) ? biasv[0] : (f32x4){0.f, 0.f, 0.f, 0.f}) : acc[gw][p][0];
+                acc[gw][p][0] = mfma16(afr[0][2 * hh + h], vv[p][h], c0v);
               }
+            } else {
+              const int p = 2 * step + h;
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                  const f32x4 c0v = (FIRST && t == 0) ? ((p == 5) ? biasv[j] : (f32x4){0.f, 0.f, 0.f, 0.f}) : acc[gw][p][j];
+                  acc[gw][p][j] = mfma16(afr[j][2 * h + t], vv[p][t], c0v);
+                }
+            }
           };
           f32x4 af0[NT], af1[NT];
           load_ops(0, af0);
@@ -363,6 +393,13 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
       }
 
       if (last) {                            // inverse transform Y = A^T M A in registers; handed on after the next barrier
+        if (pend_b >= 0 || pend_c >= 0) {      // (a segment shorter than the three hand-over steps: finish them now,
+          if (pend_c >= 0) { step_c(pend_c, ticket); pend_c = -1; }       //  step C adds through the parking area that is about to be rewritten)
+          if (pend_b >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ticket = step_b(pend_b); step_c(pend_b, ticket); pend_b = -1;
+          }
+        }
 #pragma unroll
         for (int gw = 0; gw < GW; ++gw)
 #pragma unroll
@@ -388,7 +425,7 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
 #pragma unroll
             for (int px = 0; px < 4; ++px) parkW[((gw * 4 + px) * NT + j) * 64] = ov[px];     // lane-contiguous 16-byte slots: conflict-free
           }
-        pending = sidx;
+        pend_a = sidx;
       }
       ubuf ^= 1;
     }
@@ -397,24 +434,25 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
     seg = sk_load_seg(a.segs + sidx);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the idle refetch: no LDS-DMA may be in flight when the LDS is released)
-  if (pending >= 0) flush(pending);
+  if (pend_c >= 0) step_c(pend_c, ticket);
+  if (pend_b >= 0) { ticket = step_b(pend_b); step_c(pend_b, ticket); }
+  if (pend_a >= 0 && step_a(pend_a)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ticket = step_b(pend_a); step_c(pend_a, ticket);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(256, 2) void conv_wino_sk_kernel(WinoSkArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int rk = sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);    // ranges of ONE XCD are neighbours in the unit list
   const int sidx = __builtin_amdgcn_readfirstlane(a.seg_off[rk]);
   const int send = __builtin_amdgcn_readfirstlane(a.seg_off[rk + 1]);
+  if (a.drop_advance && blockIdx.x == 0 && threadIdx.x == 0) a.drop_advance[1] += 1ull;     // (nothing in this launch reads it)
   if (sidx >= send) return;
-#if defined(SK_ONLY_F)
-  wino_sk_body<2, 1>(a, sidx, send);
-#elif defined(SK_ONLY_H)
-  wino_sk_body<1, 2>(a, sidx, send);
-#else
-  if (__builtin_amdgcn_readfirstlane(((const int*)(a.segs + sidx))[4])) wino_sk_body<1, 2>(a, sidx, send);
-  else wino_sk_body<2, 1>(a, sidx, send);
-#endif
+  if (__builtin_amdgcn_readfirstlane(((const int*)(a.segs + sidx))[4])) wino_sk_body<1, 2, FULL>(a, sidx, send);
+  else wino_sk_body<2, 1, FULL>(a, sidx, send);
 #endif
 }
 
@@ -422,21 +460,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino_sk_kernel(WinoSkArgs a) {
 // Host: the balanced schedule.  Class F units u = tile4 * nfull + slice over super-groups of 4 groups (the slices of a super-group
 // are neighbours in the list: they read the same patches, and neighbouring ranges sit on one XCD); class H units = super-groups of
 // 8 groups, present when the last slice has only its lower 16 channels.  Every stage of either class is 64 MFMAs per wave, so a
-// class's share of the G workgroups is its share of the stages, and workgroup i of a class owns stages [i S / G_c, (i + 1) S / G_c);
-// a cut closer than `minseg` stages to a unit's edge moves to the edge (no one-stage parts).  H workgroups are spread evenly
-// over the grid ranks.  Pure function of its arguments.
-// segs: records of 8 ints {tile, n0, c0, c1, class (0 F / 1 H), nparts, part, slab0}.
+// class's share of the G workgroups is its share of the stages (h_bias_pm: per-mille correction of the H share, 1000 = none).
+// H workgroups are spread evenly over the grid ranks.  Two ways of cutting a class's stages into per-workgroup runs:
+//   ksplit == 0  "stream-K": workgroup i of the class owns the contiguous stages [i S / G_c, (i + 1) S / G_c); a cut closer than
+//                `minseg` stages to a unit's edge moves to the edge;
+//   ksplit >= 1  "aligned split-K": every unit is cut at the SAME K boundaries into ksplit parts; the items (part, unit), part-major,
+//                are dealt round-robin to the class's workgroups -- the workgroups of a round then walk the same K chunks at
+//                the same time, so the transformed weights they stage are shared through the L2 (what the contiguous cut gives up).
+// Pure function of its arguments.  segs: records of 8 ints {tile, n0, c0, c1, class (0 F / 1 H), nparts, part, slab0}.
 // ---------------------------------------------------------------------------------------------------------------------
-extern "C" int sqd_wino_sk_schedule(int ngroups, int N, int C, int G, int minseg, int h_bias_pm, int* seg_off, int* segs, int max_segs,
-                                    int* nsegs_out, int* nslabs_out) {
-  SQD_CHECK_ARG(ngroups > 0 && N > 0 && N % 4 == 0 && C > 0 && C % 8 == 0 && G > 0 && minseg >= 1);
+extern "C" int sqd_wino_sk_schedule(int ngroups, int N, int C, int G, int minseg, int h_bias_pm, int ksplit, int* seg_off, int* segs,
+                                    int max_segs, int* nsegs_out, int* nslabs_out) {
+  SQD_CHECK_ARG(ngroups > 0 && N > 0 && N % 4 == 0 && C > 0 && C % 8 == 0 && G > 0 && minseg >= 1 && ksplit >= 0 && ksplit <= 64);
   SQD_CHECK_ARG(seg_off && segs && max_segs > 0 && nsegs_out && nslabs_out);
   const int nchunks = C / 8, nslices = sqd_cdiv(N, 32);
   const bool half_last = (N - 32 * (nslices - 1)) <= 16;
   const int nfull = half_last ? nslices - 1 : nslices;
   const long long tilesF = sqd_cdiv(ngroups, 4), tilesH = half_last ? sqd_cdiv(ngroups, 8) : 0;
   const long long SF = tilesF * nfull * nchunks, SH = tilesH * nchunks;
-  // workgroups per class (h_bias_pm: per-mille correction of the H share, for tuning; 1000 = proportional)
   int GH = 0;
   if (SH > 0 && SF > 0 && G < 2) return SQD_ERR_BAD_ARG;     // a workgroup runs ONE class
   if (SH > 0) {
@@ -447,6 +488,7 @@ extern "C" int sqd_wino_sk_schedule(int ngroups, int N, int C, int G, int minseg
   }
   const int GF = G - GH;
   if (SF > 0 && GF < 1) return SQD_ERR_BAD_ARG;
+  if (ksplit > nchunks) ksplit = nchunks;
   struct Cut { long long u; int c; };
   auto cut_at = [&](long long S, long long U, int Gc, int i) {
     if (i >= Gc) return Cut{U, 0};
@@ -465,39 +507,56 @@ extern "C" int sqd_wino_sk_schedule(int ngroups, int N, int C, int G, int minseg
     const long long S = isH ? SH : SF, U = isH ? tilesH : tilesF * nfull;
     const int Gc = isH ? GH : GF, i = isH ? iH++ : iF++;
     if (S == 0) continue;
-    const Cut b0 = cut_at(S, U, Gc, i), b1 = cut_at(S, U, Gc, i + 1);
-    long long u = b0.u; int c = b0.c;
-    while (u < b1.u || (u == b1.u && c < b1.c)) {
-      const int c1 = (u == b1.u) ? b1.c : nchunks;
-      if (ns >= max_segs) return SQD_ERR_BAD_ARG;
+    auto emit = [&](long long u, int c0, int c1) {
+      if (ns >= max_segs) return false;
       int* sg = segs + 8 * ns++;
       if (isH) { sg[0] = (int)u; sg[1] = 32 * nfull; }
       else { sg[0] = (int)(u / nfull); sg[1] = (int)(u % nfull) * 32; }
-      sg[2] = c; sg[3] = c1; sg[4] = isH ? 1 : 0; sg[5] = 1; sg[6] = 0; sg[7] = -1;
+      sg[2] = c0; sg[3] = c1; sg[4] = isH ? 1 : 0; sg[5] = 1; sg[6] = 0; sg[7] = -1;
+      return true;
+    };
+    if (ksplit >= 1) {
+      for (long long it = i; it < U * ksplit; it += Gc) {
+        const int part = (int)(it / U);
+        const long long u = it - (long long)part * U;
+        const int c0 = (int)((long long)part * nchunks / ksplit), c1 = (int)((long long)(part + 1) * nchunks / ksplit);
+        if (!emit(u, c0, c1)) return SQD_ERR_BAD_ARG;
+      }
+      continue;
+    }
+    const Cut b0 = cut_at(S, U, Gc, i), b1 = cut_at(S, U, Gc, i + 1);
+    long long u = b0.u; int c = b0.c;
+    while (u < b1.u || (u == b1.u && c < b1.c)) {
+      if (!emit(u, c, (u == b1.u) ? b1.c : nchunks)) return SQD_ERR_BAD_ARG;
       ++u; c = 0;
     }
   }
   seg_off[G] = ns;
-  // parts of cut units.  Within a class the segments of one unit are consecutive in rank order, but the classes interleave:
-  // match by (class, tile, n0) against the previous segment of the same class.
+  // parts of cut units: group the records by (class, tile, n0), ordered by first stage
+  int* order = (int*)malloc(sizeof(int) * (size_t)(ns > 0 ? ns : 1));
+  if (!order) return SQD_ERR_LAUNCH;
+  for (int i = 0; i < ns; ++i) order[i] = i;
+  auto key_less = [&](int x, int y) {
+    const int* p = segs + 8 * x; const int* q = segs + 8 * y;
+    if (p[4] != q[4]) return p[4] < q[4];
+    if (p[0] != q[0]) return p[0] < q[0];
+    if (p[1] != q[1]) return p[1] < q[1];
+    return p[2] < q[2];
+  };
+  std::sort(order, order + ns, key_less);
   int nslabs = 0;
-  for (int cls = 0; cls < 2; ++cls) {
-    int prev[64]; int np = 0;                                // indices of the current unit's segments
-    auto close = [&]() {
-      if (np > 1) {
-        for (int k = 0; k < np; ++k) { segs[8 * prev[k] + 5] = np; segs[8 * prev[k] + 6] = k; segs[8 * prev[k] + 7] = nslabs; }
-        nslabs += np;
-      }
-      np = 0;
-    };
-    for (int i = 0; i < ns; ++i) {
-      if (segs[8 * i + 4] != cls) continue;
-      if (np > 0 && (segs[8 * prev[0]] != segs[8 * i] || segs[8 * prev[0] + 1] != segs[8 * i + 1])) close();
-      if (np >= 64) return SQD_ERR_UNSUPPORTED;
-      prev[np++] = i;
+  for (int i = 0; i < ns;) {
+    int j = i + 1;
+    while (j < ns && segs[8 * order[j] + 4] == segs[8 * order[i] + 4] && segs[8 * order[j]] == segs[8 * order[i]] &&
+           segs[8 * order[j] + 1] == segs[8 * order[i] + 1]) ++j;
+    const int np = j - i;
+    if (np > 1) {
+      for (int k = i; k < j; ++k) { int* sg = segs + 8 * order[k]; sg[5] = np; sg[6] = k - i; sg[7] = nslabs; }
+      nslabs += np;
     }
-    close();
+    i = j;
   }
+  free(order);
   *nsegs_out = ns; *nslabs_out = nslabs;
   return SQD_OK;
 }
@@ -518,10 +577,13 @@ extern "C" int sqd_wino_sk_grid(void) { return 2 * sk_num_cus(); }
 // y[..., y_coff : y_coff + N] (=|+=) conv3x3(x[..., x_coff : x_coff + C]) (+ bias) (* ymul) (* yscale) (zero where ymask <= 0) (ReLU).
 // u_packed / Npad: sqd_pack_wino_weight with 32-channel padding.  seg_off [G + 1] / segs [nsegs][8]: device copies of what
 // sqd_wino_sk_schedule wrote for (B * ceil(H/4) * ceil(W/16), N, C, G); ws: nslabs * 4 * 2048 floats; cnt: nslabs * 4 unsigned,
-// zero before the first launch (every launch leaves them zero).
+// zero before the first launch (every launch leaves them zero).  drop_state (DEVICE {seed, step} or NULL) / drop_keep16 / drop_scale:
+// counter-based dropout of the output (sqd_common.h; the last Fire's expand3x3 in training mode, reference src/model/squeezedet.py:
+// 81-82); drop_advance (or NULL): the launch adds 1 to drop_advance[1] (ConvDet's forward: the mask of this step is consumed).
 extern "C" int sqd_conv_wino_sk_fwd(const float* x, const float* u_packed, const float* bias, float* y, const float* ymask, const float* ymul,
                                     float yscale, int B, int H, int W, int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff,
                                     int relu, int accumulate, const int* seg_off, const int* segs, int G, int nslabs, float* ws, unsigned* cnt,
+                                    const unsigned long long* drop_state, int drop_keep16, float drop_scale, unsigned long long* drop_advance,
                                     void* stream) {
   SQD_CHECK_ARG(x && u_packed && y && seg_off && segs && G > 0 && nslabs >= 0 && (nslabs == 0 || (ws && cnt)));
   SQD_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && N > 0);
@@ -537,18 +599,23 @@ extern "C" int sqd_conv_wino_sk_fwd(const float* x, const float* u_packed, const
   a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.N = N; a.Npad = Npad; a.y_pitch = y_pitch; a.y_coff = y_coff; a.relu = relu; a.accumulate = accumulate;
   a.ymask = ymask; a.ymul = ymul; a.yscale = yscale;
+  SQD_CHECK_ARG(!drop_state || (drop_keep16 >= 0 && drop_keep16 <= 65536));
+  a.drop_state = drop_state; a.drop_keep = drop_keep16; a.drop_scale = drop_scale; a.drop_advance = drop_advance;
   a.gxn = sqd_cdiv(W, 16); a.gyn = sqd_cdiv(H, 4);
   a.ngroups = B * a.gxn * a.gyn;
   if ((long long)(a.ngroups + 16) * (a.gxn > a.gyn ? a.gxn : a.gyn) >= (1ll << 32)) return SQD_ERR_UNSUPPORTED;
   a.gxn_m = a.gxn > 1 ? (unsigned)(((1ull << 32) + a.gxn - 1) / a.gxn) : 0u; a.gyn_m = a.gyn > 1 ? (unsigned)(((1ull << 32) + a.gyn - 1) / a.gyn) : 0u;
   a.seg_off = seg_off; a.segs = (const SkSeg*)segs; a.ws = ws; a.cnt = cnt;
   constexpr size_t lds = (size_t)80 * 1024;
-  auto kern = conv_wino_sk_kernel;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SQD_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)conv_wino_sk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_wino_sk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SQD_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, (hipStream_t)stream, a);
+  const bool full = accumulate || ymask || ymul || yscale != 1.0f || drop_state;
+  if (full) hipLaunchKernelGGL(conv_wino_sk_kernel<true>, dim3((unsigned)G), dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv_wino_sk_kernel<false>, dim3((unsigned)G), dim3(256), lds, (hipStream_t)stream, a);
   return sqd_launch_status();
 }

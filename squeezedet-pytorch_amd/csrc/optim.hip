@@ -8,16 +8,27 @@
 // norm of the flat gradient buffer, computed by the caller), so the step stays capturable in a hipGraph.
 #include "sqd_common.h"
 
+#define SQD_NORM_PARTS 256      // partial sums of squares of the flat gradient (sqd_grad_sumsq), summed in index order by every workgroup of the step
+
 struct SgdDesc { float* p; long long g; float* m; long long n; };      // g: element offset into g_base, or an address when g_base is null
 
 __global__ __launch_bounds__(256) void sgd_clip_batched_kernel(const SgdDesc* __restrict__ descs, const float* __restrict__ g_base,
                                                                const float* __restrict__ total_norm, float max_norm, float lr, float momentum,
-                                                               float wd) {
+                                                               float wd, int norm_parts, float* __restrict__ norm_out) {
   const SgdDesc d = descs[blockIdx.y];
   const float* __restrict__ dg = g_base ? g_base + d.g : (const float*)d.g;
   float coef = 1.f;
   if (max_norm > 0.f) {
-    coef = max_norm / (*total_norm + 1e-6f);
+    float tn;
+    if (norm_parts > 0) {                    // total_norm = the partial sums of squares of sqd_grad_sumsq: fixed-order sum, then the root
+      float ssum = 0.f;
+      for (int i = 0; i < norm_parts; ++i) ssum += total_norm[i];
+      tn = sqrtf(ssum);
+      if (norm_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *norm_out = tn;
+    } else {
+      tn = *total_norm;
+    }
+    coef = max_norm / (tn + 1e-6f);
     coef = coef < 1.f ? coef : 1.f;
   }
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -52,6 +63,41 @@ extern "C" int sqd_sgd_clip_step(const void* descs_dev, int n, const float* grad
                                  float momentum, float weight_decay, int blocks_per_desc, void* stream) {
   SQD_CHECK_ARG(descs_dev && n > 0 && n <= 65535 && blocks_per_desc > 0 && blocks_per_desc <= 4096 && (total_norm || max_norm <= 0.f));
   hipLaunchKernelGGL(sgd_clip_batched_kernel, dim3((unsigned)blocks_per_desc, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                     (const SgdDesc*)descs_dev, grad_base, total_norm, max_norm, lr, momentum, weight_decay);
+                     (const SgdDesc*)descs_dev, grad_base, total_norm, max_norm, lr, momentum, weight_decay, 0, (float*)nullptr);
+  return sqd_launch_status();
+}
+
+// ---- the gradient norm of clip_grad_norm_ (src/engine/trainer.py:49) without a torch reduction kernel ----
+// sqd_grad_sumsq: parts[i] = sum of squares of block i of the flat gradient (SQD_NORM_PARTS equal blocks; within a block a fixed
+// tree: bitwise reproducible).  sqd_sgd_clip_step_parts: the step above with total_norm = sqrt(sum of those partials in index order),
+// evaluated redundantly by every workgroup; norm_out (or NULL) receives the norm for logging.
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ parts) {
+  const long long per = (n + SQD_NORM_PARTS - 1) / SQD_NORM_PARTS;
+  const long long lo = (long long)blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  float acc = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) { const float v = g[i]; acc += v * v; }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = red[0];
+}
+
+extern "C" int sqd_grad_sumsq(const float* grad_flat, long long n, float* parts, void* stream) {
+  SQD_CHECK_ARG(grad_flat && parts && n > 0);
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(SQD_NORM_PARTS), dim3(256), 0, (hipStream_t)stream, grad_flat, n, parts);
+  return sqd_launch_status();
+}
+
+extern "C" int sqd_grad_sumsq_parts(void) { return SQD_NORM_PARTS; }
+
+extern "C" int sqd_sgd_clip_step_parts(const void* descs_dev, int n, const float* grad_base, const float* sumsq_parts, float* norm_out,
+                                       float max_norm, float lr, float momentum, float weight_decay, int blocks_per_desc, void* stream) {
+  SQD_CHECK_ARG(descs_dev && n > 0 && n <= 65535 && blocks_per_desc > 0 && blocks_per_desc <= 4096 && sumsq_parts && max_norm > 0.f);
+  hipLaunchKernelGGL(sgd_clip_batched_kernel, dim3((unsigned)blocks_per_desc, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     (const SgdDesc*)descs_dev, grad_base, sumsq_parts, max_norm, lr, momentum, weight_decay, SQD_NORM_PARTS, norm_out);
   return sqd_launch_status();
 }

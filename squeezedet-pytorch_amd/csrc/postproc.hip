@@ -149,6 +149,7 @@ extern "C" int sqd_resolve_fwd(const float* pred, const float* anchors, float* p
 
 struct DetArgs {
   const float* pred; const float* anchors; const float* scales;   // scales [B][2] = (sy, sx) or null
+  const float* shifts;                                            // [B][2] = (dy, dx) added after the scale division, or null
   const long long* in_class; const float* in_score; const float* in_box;   // dense inputs (filter mode) or null
   unsigned* keys;                                                 // (unused since the keys live in LDS; kept in the ABI)
   int S, per;
@@ -382,7 +383,11 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
     a.det_class[o] = cls;
     a.det_score[o] = score;
     a.det_anchor[o] = idx;
-    *(f32x4*)(a.det_box + 4 * o) = (f32x4){bx.x1 / sx, bx.y1 / sy, bx.x2 / sx, bx.y2 / sy};
+    f32x4 ob = (f32x4){bx.x1 / sx, bx.y1 / sy, bx.x2 / sx, bx.y2 / sy};
+    // boxes_postprocess' padding / crops terms (src/utils/boxes.py:149-155): per axis only one of the two is non-zero, so
+    // (b - padding) + crops == b + (crops - padding) bit for bit
+    if (a.shifts) { const float dy = a.shifts[2 * b], dx = a.shifts[2 * b + 1]; ob.x += dx; ob.y += dy; ob.z += dx; ob.w += dy; }
+    *(f32x4*)(a.det_box + 4 * o) = ob;
   }
 }
 
@@ -405,20 +410,31 @@ static int launch_detect(DetArgs a, hipStream_t stream) {
 // the per-anchor keys in global memory).  Outputs are fixed-capacity
 // [B][K]; rows >= det_count[b] are left untouched.  scales ([B][2] = (sy,sx), may be null) folds
 // boxes_postprocess' division into the store.
-extern "C" int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, unsigned* keys_ws, int* det_count,
-                              long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
-                              int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
-                              float score_thresh, void* stream) {
+// sqd_detect_shift_fwd: the same with shifts ([B][2] = (dy, dx), may be null) added to the boxes after the scale division --
+// boxes_postprocess' padding / crops terms of the reference's forbid_resize branch (src/utils/boxes.py:149-155).
+extern "C" int sqd_detect_shift_fwd(const float* pred, const float* anchors, const float* scales, const float* shifts, unsigned* keys_ws,
+                                    int* det_count, long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
+                                    int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
+                                    float score_thresh, void* stream) {
   SQD_CHECK_ARG(pred && anchors && det_count && det_class && det_score && det_box && det_anchor);
   SQD_CHECK_ARG(B > 0 && A > 0 && num_classes >= 1 && num_classes <= SQD_MAX_CLASSES);
   SQD_CHECK_ARG(((uintptr_t)pred & 15) == 0 && ((uintptr_t)det_box & 15) == 0);
   DetArgs a;
+  a.shifts = shifts;
   a.pred = pred; a.anchors = anchors; a.scales = scales; a.in_class = nullptr; a.in_score = nullptr; a.in_box = nullptr; a.keys = keys_ws;
   a.det_count = det_count; a.det_class = det_class; a.det_score = det_score; a.det_box = det_box; a.det_anchor = det_anchor;
   a.B = B; a.A = A; a.C = num_classes; a.K = keep_top_k;
   a.wmax = (float)(input_w - 1); a.hmax = (float)(input_h - 1);
   a.nms_thresh = nms_thresh; a.score_thresh = score_thresh;
   return launch_detect(a, (hipStream_t)stream);
+}
+
+extern "C" int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales, unsigned* keys_ws, int* det_count,
+                              long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
+                              int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
+                              float score_thresh, void* stream) {
+  return sqd_detect_shift_fwd(pred, anchors, scales, nullptr, keys_ws, det_count, det_class, det_score, det_box, det_anchor, B, A,
+                              num_classes, input_h, input_w, keep_top_k, nms_thresh, score_thresh, stream);
 }
 
 // Detector.filter(det) proper: the same kernel fed with already decoded dense tensors
@@ -430,6 +446,7 @@ extern "C" int sqd_filter_fwd(const long long* class_ids, const float* scores, c
   SQD_CHECK_ARG(B > 0 && A > 0 && num_classes >= 1 && num_classes <= SQD_MAX_CLASSES);
   SQD_CHECK_ARG(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)det_box & 15) == 0);
   DetArgs a;
+  a.shifts = nullptr;
   a.pred = nullptr; a.anchors = nullptr; a.scales = nullptr; a.in_class = class_ids; a.in_score = scores; a.in_box = boxes; a.keys = keys_ws;
   a.det_count = det_count; a.det_class = det_class; a.det_score = det_score; a.det_box = det_box; a.det_anchor = det_anchor;
   a.B = B; a.A = A; a.C = num_classes; a.K = keep_top_k;

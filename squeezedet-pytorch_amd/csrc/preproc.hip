@@ -75,3 +75,57 @@ extern "C" int sqd_preprocess_u8_fwd(const unsigned char* src, const long long* 
   hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)sqd_cdiv(W, 256), (unsigned)H, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
   return sqd_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The reference's OTHER pre-processing branch, cfg.forbid_resize (src/datasets/base.py:53-54): whiten (src/utils/image.py:9-19),
+// then crop_or_pad (:91-124) -- per axis, a smaller image is zero-padded to the target (floor half in front, np.pad constant 0
+// AFTER whitening: padded pixels are 0.0), a larger one is centre-cropped (floor half cut off in front) -- then HWC -> CHW.
+// Pure index arithmetic plus the one float32 subtract and divide of whiten: bit-exact against the reference.
+// Also writes what boxes_postprocess (src/utils/boxes.py:149-155) needs to map detections back: padding / crops (top, bottom,
+// left, right) and the box shift (dy, dx) = (crops[0] - padding[0], crops[2] - padding[2]) the fused detect kernel adds.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PadCropArgs {
+  const unsigned char* src; const long long* offsets; const int* sizes;
+  float* out; float* shifts; int* padcrop;
+  float mean[3], stdv[3];
+  int B, H, W;
+};
+
+__global__ __launch_bounds__(256) void preprocess_padcrop_kernel(PadCropArgs a) {
+  const int b = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int H0 = a.sizes[2 * b], W0 = a.sizes[2 * b + 1];
+  // (target - size) // 2 in front when padding, (size - target) // 2 cut in front when cropping
+  const int pt = H0 < a.H ? (a.H - H0) / 2 : 0, ct = H0 > a.H ? (H0 - a.H) / 2 : 0;
+  const int pl = W0 < a.W ? (a.W - W0) / 2 : 0, cl = W0 > a.W ? (W0 - a.W) / 2 : 0;
+  if (x == 0 && y == 0) {
+    if (a.padcrop) {
+      int* pc = a.padcrop + 8 * b;
+      pc[0] = pt; pc[1] = H0 < a.H ? (a.H - H0) - pt : 0; pc[2] = pl; pc[3] = W0 < a.W ? (a.W - W0) - pl : 0;
+      pc[4] = ct; pc[5] = H0 > a.H ? (H0 - a.H) - ct : 0; pc[6] = cl; pc[7] = W0 > a.W ? (W0 - a.W) - cl : 0;
+    }
+    if (a.shifts) { a.shifts[2 * b] = (float)(ct - pt); a.shifts[2 * b + 1] = (float)(cl - pl); }
+  }
+  if (x >= a.W) return;
+  const int sy = y - pt + ct, sx = x - pl + cl;
+  const bool inside = sy >= 0 && sy < H0 && sx >= 0 && sx < W0;
+  const long long plane = (long long)a.H * a.W;
+  float* o = a.out + (long long)b * 3 * plane + (long long)y * a.W + x;
+  const unsigned char* p = a.src + a.offsets[b] + ((long long)(inside ? sy : 0) * W0 + (inside ? sx : 0)) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c * plane] = inside ? ((float)p[c] - a.mean[c]) / a.stdv[c] : 0.f;
+}
+
+// Arguments as sqd_preprocess_u8_fwd; shifts: [B][2] fp32 (dy, dx) or NULL; padcrop: [B][8] int32 = padding (top, bottom, left,
+// right) then crops (top, bottom, left, right), or NULL.
+extern "C" int sqd_preprocess_u8_padcrop_fwd(const unsigned char* src, const long long* offsets, const int* sizes, float* out,
+                                             float* shifts, int* padcrop, const float* mean3, const float* std3, int B, int H, int W,
+                                             void* stream) {
+  SQD_CHECK_ARG(src && offsets && sizes && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535);
+  PadCropArgs a;
+  a.src = src; a.offsets = offsets; a.sizes = sizes; a.out = out; a.shifts = shifts; a.padcrop = padcrop; a.B = B; a.H = H; a.W = W;
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; SQD_CHECK_ARG(std3[c] != 0.f); }
+  hipLaunchKernelGGL(preprocess_padcrop_kernel, dim3((unsigned)sqd_cdiv(W, 256), (unsigned)H, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+  return sqd_launch_status();
+}

@@ -139,7 +139,6 @@ class SqueezeDetBase(nn.Module):
         self._fused_plans = {}
         self._wino_plans = {}
         self._wgrad_batches = {}
-        self._ones_cache = {}
         self.last_grad_flat = None                # flat gradient buffer of the latest backward (every .grad is a view of it)
         self.grad_sync = None                     # trainer.GradientExchange when data parallel (attach_data_parallel)
         self.use_winograd = True                  # 3x3 forward convs: Winograd F(2x2,3x3) kernel where tuning.json says it is faster
@@ -152,6 +151,10 @@ class SqueezeDetBase(nn.Module):
         self.fuse_stem_squeeze = True             # inference forward: the first Fire's squeeze inside the stem launch (ops.stem_pool_squeeze)
         self._pack_table_keepalive = None
         self._forced_drop_mask = None       # tests: NCHW mask (already scaled by 1/(1-p)) instead of RNG
+        # counter-based dropout (ops.DropState): applied in the last Fire's expand epilogues, its step advanced by ConvDet's launch,
+        # no mask tensor and no torch RNG kernel in the step.  fused_dropout = False draws the mask as a tensor (stand-alone kernel)
+        self.fused_dropout = True
+        self._drop = None                   # (torch.initial_seed() it was derived from, ops.DropState)
         import os
         # forward (inference and training): squeeze + expand1x1 of a Fire in one launch (ops.fire_sq_e1) wherever they would be two plain
         # launches.  OFF: measured slower in the step (inference 1.553 -> 1.607 ms, training 5.49 -> 5.57 ms; per Fire 100 vs 88 us at
@@ -259,6 +262,27 @@ class SqueezeDetBase(nn.Module):
             return ops.conv_wino(dy, dy_coff, self.wino_plan(name, mod, wc, 'dgrad'), dx, 0, accumulate=accumulate, ymask=ymask, ymul=ymul)
         return ops.conv(dy, dy_coff, self.plan(name, mod, ops.choose_cfg(9, C, N, Bq * H * W), 'dgrad'), dx, 0,
                         accumulate=accumulate, ymask=ymask, ymul=ymul)
+
+    # ---- dropout state ----
+    def drop_state(self, device):
+        """The device-side {seed, step} of this module's dropout (created on first use from ``torch.initial_seed()``; re-derived,
+        step 0, when the process was re-seeded with ANOTHER seed since -- ``torch.manual_seed`` keeps working as the one seed of a run,
+        and the per-rank seed offsets of ``trainer.attach_data_parallel`` give every rank its own masks; re-seeding with the same
+        value is not observable here and continues the stream: ``set_dropout_rng(seed, 0, device)`` restarts it explicitly)."""
+        seed = torch.initial_seed()
+        if self._drop is None or self._drop[0] != seed or self._drop[1].state.device != torch.device(device) or self._drop[1].p != self.dropout_prob:
+            self._drop = (seed, ops.DropState(self.dropout_prob, seed ^ 0x5851f42d4c957f2d, device))
+        return self._drop[1]
+
+    def get_dropout_rng(self):
+        """(seed, step) of the dropout stream or None (checkpoints)."""
+        return None if self._drop is None else self._drop[1].get()
+
+    def set_dropout_rng(self, seed, step, device):
+        """Restore a saved dropout stream (checkpoint resume); it stays in force until the process is re-seeded."""
+        d = ops.DropState(self.dropout_prob, 0, device)
+        d.set(seed, step)
+        self._drop = (torch.initial_seed(), d)
 
     def invalidate_plans(self):
         """Drop every packed / transformed weight copy.  The caches notice optimizer steps, ``load_state_dict``, ``.to()``

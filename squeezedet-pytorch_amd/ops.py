@@ -29,9 +29,92 @@ def _check_nhwc(t, name):
         raise ValueError(f'{name} must be a contiguous fp32 CUDA tensor [B,H,W,C], got {tuple(t.shape)} {t.dtype} {t.device}')
 
 
+class DropState:
+    """Device state {seed, step} of the counter-based dropout in front of ConvDet (csrc/sqd_common.h; reference nn.Dropout,
+    src/model/squeezedet.py:71-72,81-82) + its rate.  ``keep16`` = round((1 - p) * 65536), ``scale`` = 1 / (1 - p)."""
+    __slots__ = ('state', 'p', 'keep16', 'scale')
+
+    def __init__(self, p, seed, device, step=0):
+        if not 0.0 <= p < 1.0:
+            raise ValueError(f'dropout probability must be in [0, 1), got {p}')
+        self.p = float(p)
+        self.keep16 = int(round((1.0 - self.p) * 65536))
+        self.scale = 1.0 / (1.0 - self.p)
+        self.state = torch.tensor([int(seed) & 0x7fffffffffffffff, int(step)], dtype=torch.int64, device=device)
+
+    def get(self):
+        """(seed, step) as Python ints (one device-to-host copy: checkpoints, tests)."""
+        s = self.state.cpu()
+        return int(s[0]), int(s[1])
+
+    def set(self, seed, step):
+        self.state.copy_(torch.tensor([int(seed) & 0x7fffffffffffffff, int(step)], dtype=torch.int64))
+
+
+def dropout_mask(drop, shape):
+    """The scaled keep mask of ``drop``'s CURRENT (seed, step) for an NHWC tensor of ``shape`` (numel % 4 == 0), from the stand-alone
+    kernel: element e = flat index.  Does not advance the step."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if n % 4:
+        raise ValueError('dropout_mask: number of elements must be a multiple of 4')
+    m = torch.empty(shape, device=drop.state.device, dtype=torch.float32)
+    br = _Bracket('dropout_mask', f'{n} elements', 0.0, 4.0 * n) if timing._timer is not None else None
+    nat.check(nat.lib().sqd_dropout_mask_fwd(nat.ptr(drop.state), drop.keep16, float(drop.scale), nat.ptr(m), n // 4,
+                                              nat.stream_handle(m.device)), 'sqd_dropout_mask_fwd')
+    if br is not None:
+        br.done()
+    return m
+
+
+def dropout_advance(drop):
+    """step += 1 on the device (one forward consumed its mask) when no kernel of the forward carried the advance."""
+    nat.check(nat.lib().sqd_dropout_advance(nat.ptr(drop.state), nat.stream_handle(drop.state.device)), 'sqd_dropout_advance')
+
+
+def dropout_mask_reference(seed, step, keep16, scale, n):
+    """Host restatement (numpy, uint32 arithmetic) of csrc/sqd_common.h's sqd_drop_mul4 for elements [0, n): what every kernel that
+    applies the dropout -- fused epilogue or stand-alone -- must reproduce bit for bit."""
+    import numpy as np
+
+    def mix(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
+        return x
+    u = lambda v: np.array([v & 0xffffffff], dtype=np.uint32)
+    with np.errstate(over='ignore'):
+        s0, s1, t0, t1 = u(seed), u(seed >> 32), u(step), u(step >> 32)
+        k0 = mix(s0 ^ mix(t0 + np.uint32(0x9e3779b9)))
+        k1 = mix(s1 ^ mix(t0 ^ np.uint32(0x85ebca6b)) ^ (t1 * np.uint32(0xc2b2ae35)))
+        e4 = np.arange((n + 3) // 4, dtype=np.uint64)
+        lo = (e4 & np.uint64(0xffffffff)).astype(np.uint32) ^ ((e4 >> np.uint64(32)).astype(np.uint32) * np.uint32(0x9e3779b9))
+        h1 = mix(lo ^ k0)
+        h2 = mix(h1 ^ k1)
+    f = np.stack([h1 & np.uint32(0xffff), h1 >> np.uint32(16), h2 & np.uint32(0xffff), h2 >> np.uint32(16)], 1).reshape(-1)[:n]
+    return np.where(f < np.uint32(keep16), np.float32(scale), np.float32(0.0)).astype(np.float32)
+
+
+def conv_drop_cfg(C, N, npix):
+    """A weight-stationary 1x1 configuration (the family whose epilogue carries the fused dropout) for a C -> N layer: the table's
+    choice if it is one, else the widest slice whose weights fit the LDS; None if there is none."""
+    hit = choose_cfg(1, C, N, npix)
+    if _CFG_DMA.get(hit % 1000, 0) >= 3 and conv_cfg_ok(hit, C):
+        return hit
+    best = None
+    for cid, (taps, kc, px, bn) in cfg_table().items():
+        if taps == 1 and _CFG_DMA.get(cid, 0) >= 3 and conv_cfg_ok(cid, C):
+            pad = -(-N // bn) * bn / N
+            key = (pad, -bn, -(8 if _CFG_DMA[cid] == 4 else 4))
+            if best is None or key < best[0]:
+                best = (key, cid)
+    return None if best is None else best[1]
+
+
 def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, xmask_coff=0, ymask=None, ymask_coff=0,
-         ymul=None, ymul_coff=0):
-    """y[..., y_coff:y_coff+N] (=|+=) conv(x[..., x_coff:x_coff+C] [* (xmask>0)]) (+bias) (ReLU)."""
+         ymul=None, ymul_coff=0, drop=None):
+    """y[..., y_coff:y_coff+N] (=|+=) conv(x[..., x_coff:x_coff+C] [* (xmask>0)]) (+bias) (ReLU).  ``drop`` (a DropState; forward
+    only, ``plan`` on a weight-stationary 1x1 configuration): counter-based dropout of the output in the epilogue."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
     B, H, W, xp = x.shape
     if tuple(y.shape[:3]) != (B, H, W):
@@ -66,11 +149,19 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
         br = _Bracket(cfg_kernel_name(plan.cfg_id),
                       f'{plan.taps}tap C{plan.C} N{plan.N} {H}x{W}', 2.0 * npix * plan.N * plan.C * plan.taps,
                       4.0 * (npix * (plan.C + plan.N) + plan.N * plan.C * plan.taps))
-    rc = nat.lib().sqd_conv_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(xmask),
-                                nat.ptr(ymask), nat.ptr(ymul), B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff,
-                                int(relu), int(accumulate), mp, xmask_coff, ymp, ymask_coff, ylp, ymul_coff,
-                                plan.cfg_id, nat.stream_handle(x.device))
-    nat.check(rc, 'sqd_conv_fwd')
+    if drop is not None:
+        if accumulate or xmask is not None or ymask is not None or ymul is not None:
+            raise ValueError('conv: the fused dropout is a forward-only epilogue')
+        rc = nat.lib().sqd_conv_drop_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), B, H, W, plan.C, xp, x_coff, plan.N,
+                                         plan.Npad, yp, y_coff, int(relu), nat.ptr(drop.state), drop.keep16, float(drop.scale),
+                                         plan.cfg_id, nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_conv_drop_fwd')
+    else:
+        rc = nat.lib().sqd_conv_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(xmask),
+                                    nat.ptr(ymask), nat.ptr(ymul), B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff,
+                                    int(relu), int(accumulate), mp, xmask_coff, ymp, ymask_coff, ylp, ymul_coff,
+                                    plan.cfg_id, nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_conv_fwd')
     if br is not None:
         br.done()
     return y
@@ -140,10 +231,11 @@ def fire_expand(x, x_coff, fplan, y, y_coff):
     return y
 
 
-def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=None, ymul=None, yscale=1.0):
+def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=None, ymul=None, yscale=1.0, drop=None, drop_advance=None):
     """y[..., y_coff:y_coff+N] (=|+=) conv3x3(x[..., x_coff:x_coff+C]) (+bias) (* ymul) (* yscale) (zero where ymask <= 0) (ReLU),
     Winograd F(2x2,3x3) kernel.  ``ymask`` / ``ymul`` are read through y's own channel window (same shape as y).  ``yscale``
-    (a constant factor, e.g. the dropout scale) needs the balanced kernel (``plan.cfg_id`` = tiles.WINO_SK_CFG)."""
+    (a constant factor, e.g. the dropout scale), ``drop`` (a DropState: counter-based dropout of the output) and ``drop_advance`` (a
+    DropState whose step this launch advances) need the balanced kernel (``plan.cfg_id`` = tiles.WINO_SK_CFG)."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
     B, H, W, xp = x.shape
     if tuple(y.shape[:3]) != (B, H, W):
@@ -170,11 +262,13 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=No
         rc = nat.lib().sqd_conv_wino_sk_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(ymask), nat.ptr(ymul),
                                             float(yscale), B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff, int(relu),
                                             int(accumulate), nat.ptr(sk.seg_off), nat.ptr(sk.segs), sk.G, sk.nslabs, nat.ptr(sk.ws),
-                                            nat.ptr(sk.cnt), nat.stream_handle(x.device))
+                                            nat.ptr(sk.cnt), nat.ptr(drop.state) if drop is not None else None,
+                                            drop.keep16 if drop is not None else 0, float(drop.scale) if drop is not None else 0.0,
+                                            nat.ptr(drop_advance.state) if drop_advance is not None else None, nat.stream_handle(x.device))
         nat.check(rc, 'sqd_conv_wino_sk_fwd')
     else:
-        if yscale != 1.0:
-            raise ValueError('conv_wino: yscale needs the balanced kernel (cfg tiles.WINO_SK_CFG)')
+        if yscale != 1.0 or drop is not None or drop_advance is not None:
+            raise ValueError('conv_wino: yscale / drop / drop_advance need the balanced kernel (cfg tiles.WINO_SK_CFG)')
         rc = nat.lib().sqd_conv_wino_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(ymask), nat.ptr(ymul),
                                          B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff, int(relu), int(accumulate),
                                          plan.cfg_id, nat.stream_handle(x.device))

@@ -120,13 +120,17 @@ def _wgrad(batch, H, W, N, C, taps):
 
 
 def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
-                         use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True, fuse_sq_e1=False):
+                         use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True, fuse_sq_e1=False, dropout=True,
+                         fused_dropout=True):
     """Launches of one training iteration's forward (activations saved, no inference-only fusion: ``autograd.py`` gates
     the bridges and fused expands on ``not save``), multi-task loss forward / backward and the backbone backward, as
     (kernel name, shape tag) in launch order.  The optimizer launch and torch's own elementwise kernels (dropout mask,
     ``loss.mean()``) are not KernelTimer-bracketed and not listed.  ``data_parallel_stages``: with a gradient exchange
     attached the slab reduction runs once per backward stage instead of once at the end.  ``fuse_squeeze_bwd`` =
-    ``SqueezeDetBase.fuse_squeeze_bwd``."""
+    ``SqueezeDetBase.fuse_squeeze_bwd``.  ``dropout`` (``cfg.dropout_prob > 0``): the counter-based dropout in front of ConvDet rides
+    in the last Fire's expand launches (a weight-stationary 1x1 configuration + the balanced Winograd kernel) and ConvDet's forward and
+    data gradient run on the balanced Winograd kernel; where that form does not apply (``fused_dropout`` off, squeeze width not a
+    multiple of 8) the mask is drawn by the stand-alone ``dropout_mask`` launch."""
     layers = layer_table(arch)
     ks = layers[0][3]
     H, W = ops.stem_out_size(input_size[0], input_size[1], ks)
@@ -149,23 +153,42 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
             H, W = ops.pool_out_size(H, W)
             continue
         _, cin, s, e1, e3 = l
-        # (the last Fire carries the dropout multiply in its expand epilogues: two plain launches)
-        if fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1) and i != len(layers) - 1:
+        # (the last Fire carries the dropout in its expand epilogues: two plain launches)
+        is_last = i == len(layers) - 1
+        dcfg = None
+        if is_last and dropout:
+            dcfg = ops.conv_drop_cfg(s, e1, batch * H * W) if (fused_dropout and s % 8 == 0 and use_winograd) else None
+            if dcfg is None:
+                plan.append(('dropout_mask', f'{batch * H * W * (e1 + e3)} elements'))
+        if fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1) and not (is_last and dropout):
             plan.append((f'fire_sq_e1<{s // 16}>', f'sq+e1 C{cin} S{s} E{e1} {H}x{W}'))
+            plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
         else:
             plan.append(_conv1x1(batch, H, W, cin, s))
-            plan.append(_conv1x1(batch, H, W, s, e1))
-        plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
+            if dcfg is not None:
+                plan.append((ops.cfg_kernel_name(dcfg), f'1tap C{s} N{e1} {H}x{W}'))
+                plan.append(('conv_wino_sk', f'9tap C{s} N{e3} {H}x{W}'))
+            else:
+                plan.append(_conv1x1(batch, H, W, s, e1))
+                plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
         C = e1 + e3
     ncd = anchors_per_grid * (num_classes + 5)
     ccd = convdet_in_channels(arch)
-    plan.append(_conv3x3(batch, H, W, ccd, ncd, use_winograd))
+    fused_rng = dropout and layers[-1][0] == 'fire' and (fused_dropout and layers[-1][2] % 8 == 0 and use_winograd
+                                                           and ops.conv_drop_cfg(layers[-1][2], layers[-1][3], batch * H * W) is not None)
+    if dropout and ccd % 8 == 0 and use_winograd:
+        plan.append(('conv_wino_sk', f'9tap C{ccd} N{ncd} {H}x{W}'))
+    else:
+        plan.append(_conv3x3(batch, H, W, ccd, ncd, use_winograd))
     A = H * W * anchors_per_grid
     plan.append(('loss_fwd', f'loss A{A}'))
     plan.append(('loss_bwd', f'lossbwd A{A}'))
     # ---- backward (backward.run_backbone_backward) ----
     plan.append(_wgrad(batch, H, W, ncd, ccd, 9))
-    plan.append(_conv3x3(batch, H, W, ncd, ccd, use_winograd))                       # ConvDet data gradient
+    if fused_rng and ncd % 8 == 0:
+        plan.append(('conv_wino_sk', f'9tap C{ncd} N{ccd} {H}x{W}'))                 # ConvDet data gradient (mask = its own input, constant scale)
+    else:
+        plan.append(_conv3x3(batch, H, W, ncd, ccd, use_winograd))                   # ConvDet data gradient
     rows_total, rows_done = 1, 0                       # slab-reduction records: ConvDet, then 3 per Fire in backward order
     last = len(layers) - 1
     for i in range(last, 1, -1):

@@ -130,11 +130,19 @@ class WinoPlan:
 _SK_SCHEDULES = {}
 
 
-def wino_sk_params():
-    """(minseg, h_bias_pm) of the balanced Winograd schedule: shortest part of a cut unit in stages, per-mille correction of the
-    16-channel class's share of the grid (env overrides for A/B runs)."""
+def wino_sk_params(N=None, C=None):
+    """(minseg, h_bias_pm, ksplit) of the balanced Winograd schedule for a C -> N layer: shortest part of a cut unit in stages,
+    per-mille correction of the 16-channel class's share of the grid, and how units are cut: ksplit = k >= 1 cuts every unit at the
+    same K boundaries into k parts dealt round-robin (the workgroups of a round walk the same K chunks together: the transformed
+    weights they stage are shared through the L2), 0 = contiguous runs of exactly equal length.  Measured on the 24x78 bs=20 shapes
+    (profiles/r04b_sk_schedule_variants.log): a long reduction (ConvDet, 96 chunks) is fastest cut in four (215 us against 241 for
+    the unit kernel and 270 for contiguous runs, whose workgroups sit at 512 different K positions); short reductions are fastest
+    uncut (k = 1), where the round-robin deal alone beats the unit kernel's grid rounding on many-slice layers (C72 -> N768: 177
+    against 231 us).  Env overrides for A/B runs."""
     import os
-    return int(os.environ.get('SQD_SK_MINSEG', 2)), int(os.environ.get('SQD_SK_HBIAS', 1000))
+    ks = 1 if (C is None or C // 8 < 48) else 4
+    return (int(os.environ.get('SQD_SK_MINSEG', 2)), int(os.environ.get('SQD_SK_HBIAS', 1000)),
+            int(os.environ.get('SQD_SK_KSPLIT', ks)))
 
 
 def wino_sk_grid():
@@ -145,16 +153,17 @@ def wino_sk_grid():
     return g if g > 0 else int(nat.lib().sqd_wino_sk_grid())
 
 
-def wino_sk_host_schedule(ngroups, N, C, G, minseg=2, h_bias_pm=1000):
+def wino_sk_host_schedule(ngroups, N, C, G, minseg=2, h_bias_pm=1000, ksplit=0):
     """sqd_wino_sk_schedule as numpy arrays: (seg_off int32 [G + 1], segs int32 [nsegs, 8], nslabs).  Pure host code."""
     import ctypes
     import numpy as np
     nchunks, nslices = C // 8, -(-N // 32)
-    max_segs = G * (2 + 2 * (-(-(ngroups * nslices * nchunks) // (4 * G * nchunks)) + 1)) + 16
+    max_segs = G * (2 + 2 * (-(-(ngroups * nslices * nchunks) // (4 * G * nchunks)) + 1)) + 16 + (ngroups + 4) * nslices * max(ksplit, 1)
     seg_off = np.zeros(G + 1, dtype=np.int32)
     segs = np.zeros((max_segs, 8), dtype=np.int32)
     ns, nslabs = ctypes.c_int(), ctypes.c_int()
-    rc = nat.lib().sqd_wino_sk_schedule(int(ngroups), int(N), int(C), int(G), int(minseg), int(h_bias_pm), seg_off.ctypes.data_as(ctypes.c_void_p),
+    rc = nat.lib().sqd_wino_sk_schedule(int(ngroups), int(N), int(C), int(G), int(minseg), int(h_bias_pm), int(ksplit),
+                                        seg_off.ctypes.data_as(ctypes.c_void_p),
                                         segs.ctypes.data_as(ctypes.c_void_p), max_segs, ctypes.byref(ns), ctypes.byref(nslabs))
     nat.check(rc, 'sqd_wino_sk_schedule')
     return seg_off, segs[:ns.value].copy(), nslabs.value
@@ -166,8 +175,8 @@ class WinoSkSchedule:
 
     def __init__(self, ngroups, N, C, device):
         self.G = wino_sk_grid()
-        minseg, hb = wino_sk_params()
-        seg_off, segs, nslabs = wino_sk_host_schedule(ngroups, N, C, self.G, minseg, hb)
+        minseg, hb, ks = wino_sk_params(N, C)
+        seg_off, segs, nslabs = wino_sk_host_schedule(ngroups, N, C, self.G, minseg, hb, ks)
         self.seg_off = torch.from_numpy(seg_off).to(device)
         self.segs = torch.from_numpy(segs).contiguous().to(device)
         self.nslabs = nslabs
@@ -176,7 +185,7 @@ class WinoSkSchedule:
 
 
 def wino_sk_schedule(ngroups, N, C, device):
-    key = (int(ngroups), int(N), int(C), str(device), wino_sk_grid()) + wino_sk_params()
+    key = (int(ngroups), int(N), int(C), str(device), wino_sk_grid()) + wino_sk_params(N, C)
     hit = _SK_SCHEDULES.get(key)
     if hit is None:
         if len(_SK_SCHEDULES) > 64:

@@ -138,13 +138,17 @@ def find_base(model):
     raise TypeError('no SqueezeDetBase inside the model')
 
 
-_RANK_STREAMS = {'set': False}     # this process's random streams already differ from the other ranks' (seeded here or restored)
+# this process's random streams already differ from the other ranks' (seeded here or restored), and the seed they had then: a later
+# torch.manual_seed() by the user makes all ranks equal again, which the next attach notices by the changed initial seed
+_RANK_STREAMS = {'set': False, 'seed': None}
 
 
 def mark_rank_streams_set(flag=True):
     """Tell ``attach_data_parallel`` that this process's random streams are already rank-specific (``checkpoint.load_checkpoint``
-    calls this after restoring the rank's own streams, so a later ``Trainer(...)`` / ``attach_data_parallel`` leaves them alone)."""
+    calls this after restoring the rank's own streams, so a later ``Trainer(...)`` / ``attach_data_parallel`` leaves them alone);
+    ``False``: they are NOT (a checkpoint with fewer streams than ranks was loaded) and the next attach offsets them again."""
     _RANK_STREAMS['set'] = bool(flag)
+    _RANK_STREAMS['seed'] = torch.initial_seed() if flag else None
 
 
 def attach_data_parallel(model, optimizer=None, group=None, overlap=True, broadcast=True, seed_offset=True):
@@ -172,11 +176,12 @@ def attach_data_parallel(model, optimizer=None, group=None, overlap=True, broadc
                     off = 0
                     for t in tensors:
                         t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
-    if seed_offset and not _RANK_STREAMS['set']:
+    if seed_offset and (not _RANK_STREAMS['set'] or _RANK_STREAMS['seed'] != torch.initial_seed()):
         rank = d.get_rank(group)
         if rank:
             torch.manual_seed(torch.initial_seed() + rank)     # seeds the CPU and every GPU generator of this process
         _RANK_STREAMS['set'] = True
+        _RANK_STREAMS['seed'] = torch.initial_seed()           # (the dropout in front of ConvDet derives its stream from this seed)
     return ex
 
 
@@ -369,6 +374,7 @@ class FusedClipSGD(torch.optim.Optimizer):
             self._bufs.append(self.momentum_flat[off:off + p.numel()]); off += p.numel()
             self.state[p]['momentum_buffer'] = self._bufs[-1]       # views: attach_data_parallel broadcasts optimizer state tensors in place
         self._table = self._table_key = None
+        self._norm_ws = None                           # partial sums of squares + the norm (device)
         self.last_norm = None
 
     @property
@@ -430,11 +436,21 @@ class FusedClipSGD(torch.optim.Optimizer):
             self._table_key = key
         norm = None
         max_norm = self.max_norm
-        if max_norm > 0:
-            norm = flat[:self.total].norm() if flat is not None else torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
-        nat.check(nat.lib().sqd_sgd_clip_step(nat.ptr(self._table), len(params), nat.ptr(flat), nat.ptr(norm), max_norm, self.lr,
-                                              self.momentum, self.weight_decay, 64, nat.stream_handle(params[0].device)),
-                  'sqd_sgd_clip_step')
+        if max_norm > 0 and flat is not None:
+            # the norm of the flat gradient buffer: partial sums of squares by one small launch, finished (fixed order) inside the step
+            if self._norm_ws is None:
+                self._norm_ws = torch.empty(int(nat.lib().sqd_grad_sumsq_parts()) + 1, device=flat.device, dtype=torch.float32)
+            parts, norm = self._norm_ws[:-1], self._norm_ws[-1]
+            nat.check(nat.lib().sqd_grad_sumsq(nat.ptr(flat), self.total, nat.ptr(parts), nat.stream_handle(flat.device)), 'sqd_grad_sumsq')
+            nat.check(nat.lib().sqd_sgd_clip_step_parts(nat.ptr(self._table), len(params), nat.ptr(flat), nat.ptr(parts), nat.ptr(norm),
+                                                        max_norm, self.lr, self.momentum, self.weight_decay, 64,
+                                                        nat.stream_handle(params[0].device)), 'sqd_sgd_clip_step_parts')
+        else:
+            if max_norm > 0:
+                norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+            nat.check(nat.lib().sqd_sgd_clip_step(nat.ptr(self._table), len(params), nat.ptr(flat), nat.ptr(norm), max_norm, self.lr,
+                                                  self.momentum, self.weight_decay, 64, nat.stream_handle(params[0].device)),
+                      'sqd_sgd_clip_step')
         torch.autograd.graph.increment_version(params)        # (the packed-weight caches key on the version counters)
         self.last_norm = norm
         return norm if closure is None else loss

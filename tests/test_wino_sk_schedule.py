@@ -12,15 +12,15 @@ SHAPES = [(600, 72, 768), (600, 384, 96), (600, 192, 48), (600, 256, 64), (600, 
 
 
 @pytest.mark.parametrize('ngroups,N,C', SHAPES)
-@pytest.mark.parametrize('G,minseg', [(512, 2), (512, 1), (3, 2), (1, 1), (64, 3)])
-def test_schedule_covers_every_stage_once(ngroups, N, C, G, minseg):
+@pytest.mark.parametrize('G,minseg,ksplit', [(512, 2, 0), (512, 1, 0), (3, 2, 0), (1, 1, 0), (64, 3, 0), (512, 2, 4), (7, 2, 3), (512, 2, 1)])
+def test_schedule_covers_every_stage_once(ngroups, N, C, G, minseg, ksplit):
     nch, nsl = C // 8, -(-N // 32)
     half = (N - 32 * (nsl - 1)) <= 16
     if half and nsl > 1 and G == 1:                      # two workgroup classes need two workgroups
         with pytest.raises(RuntimeError):
-            plans.wino_sk_host_schedule(ngroups, N, C, G, minseg)
+            plans.wino_sk_host_schedule(ngroups, N, C, G, minseg, 1000, ksplit)
         return
-    seg_off, segs, nslabs = plans.wino_sk_host_schedule(ngroups, N, C, G, minseg)
+    seg_off, segs, nslabs = plans.wino_sk_host_schedule(ngroups, N, C, G, minseg, 1000, ksplit)
     nfull = nsl - 1 if half else nsl
     assert seg_off[0] == 0 and seg_off[G] == len(segs) and np.all(np.diff(seg_off) >= 0)
     units = {}
@@ -43,7 +43,7 @@ def test_schedule_covers_every_stage_once(ngroups, N, C, G, minseg):
             s0 = parts[0][4]
             assert not (slabs & set(range(s0, s0 + len(parts)))), 'slab ranges of two units overlap'
             slabs |= set(range(s0, s0 + len(parts)))
-            if minseg > 1 and nch >= 2 * minseg:
+            if ksplit == 0 and minseg > 1 and nch >= 2 * minseg:
                 assert parts[0][1] - parts[0][0] >= minseg and parts[-1][1] - parts[-1][0] >= minseg, 'a cut closer than minseg to a unit edge'
         if cls == 0:
             assert n0 % 32 == 0 and n0 < 32 * nfull and t < -(-ngroups // 4)
