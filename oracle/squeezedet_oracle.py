@@ -20,6 +20,7 @@ __all__ = [
     "backbone_forward", "resolve_predictions", "inference_head", "nms", "filter_detections",
     "boxes_postprocess", "multitask_loss", "compute_deltas", "encode_gt", "train_step_reference",
     "xyxy_to_xywh", "xywh_to_xyxy", "KITTI_RGB_MEAN", "KITTI_RGB_STD", "resize_linear_f32", "preprocess_image",
+    "crop_or_pad_image", "boxes_unpad_uncrop",
 ]
 
 EPSILON = 1e-10  # src/model/modules.py:3, src/utils/boxes.py:9
@@ -275,6 +276,18 @@ def boxes_postprocess(boxes: np.ndarray, scales: Sequence[float]) -> np.ndarray:
     return out
 
 
+def boxes_unpad_uncrop(boxes: np.ndarray, padding, crops) -> np.ndarray:
+    """The padding / crops branches of src/utils/boxes.py:149-155 (the ``cfg.forbid_resize`` pre-processing records both, no
+    ``scales``): x -= padding[2], y -= padding[0]; then x += crops[2], y += crops[0]; float32, in that order.  Pinned by
+    tests/golden/padcrop.npz (the reference's own ``boxes_postprocess`` outputs)."""
+    out = np.array(boxes, dtype=np.float32, copy=True)
+    out[:, [0, 2]] -= padding[2]
+    out[:, [1, 3]] -= padding[0]
+    out[:, [0, 2]] += crops[2]
+    out[:, [1, 3]] += crops[0]
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # loss -- src/model/squeezedet.py:133-174, src/model/modules.py:48-63
 # --------------------------------------------------------------------------------------
@@ -481,3 +494,29 @@ def preprocess_image(img_u8: np.ndarray, input_size: Tuple[int, int], mean=KITTI
     scales = np.array([input_size[0] / x.shape[0], input_size[1] / x.shape[1]], dtype=np.float32)
     y = resize_linear_f32(x, input_size)
     return np.ascontiguousarray(y.transpose(2, 0, 1)), scales
+
+
+def crop_or_pad_image(img_u8: np.ndarray, input_size: Tuple[int, int], mean=KITTI_RGB_MEAN, std=KITTI_RGB_STD):
+    """The input pipeline's ``cfg.forbid_resize`` branch for one image (src/datasets/base.py:51-54): float32 cast (kitti.py:52),
+    whiten (image.py:17), ``crop_or_pad`` (image.py:91-124) -- per axis a smaller image is zero-padded AFTER whitening (floor half of
+    the difference in front, ``np.pad`` constant 0), a larger one centre-cropped (floor half cut in front) -- HWC->CHW
+    (detector.py:140).  Returns (image float32 [3,H,W], padding int16 [4], crops int16 [4]), both (top, bottom, left, right).
+    Pinned against the reference's own functions by tests/golden/padcrop.npz."""
+    x = img_u8.astype(np.float32)
+    x = (x - np.asarray(mean, np.float32).reshape(1, 1, 3)) / np.asarray(std, np.float32).reshape(1, 1, 3)
+    H, W = int(input_size[0]), int(input_size[1])
+    h, w = x.shape[:2]
+    padding, crops = np.zeros(4, np.int16), np.zeros(4, np.int16)
+    if h < H:
+        padding[0] = (H - h) // 2; padding[1] = (H - h) - padding[0]
+    elif h > H:
+        crops[0] = (h - H) // 2; crops[1] = (h - H) - crops[0]
+    if w < W:
+        padding[2] = (W - w) // 2; padding[3] = (W - w) - padding[2]
+    elif w > W:
+        crops[2] = (w - W) // 2; crops[3] = (w - W) - crops[2]
+    out = np.zeros((H, W, 3), np.float32)
+    ys, xs = int(crops[0]), int(crops[2])                       # first source row / column kept
+    nh, nw = min(h, H), min(w, W)
+    out[int(padding[0]):int(padding[0]) + nh, int(padding[2]):int(padding[2]) + nw] = x[ys:ys + nh, xs:xs + nw]
+    return np.ascontiguousarray(out.transpose(2, 0, 1)), padding, crops

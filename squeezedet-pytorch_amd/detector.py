@@ -29,14 +29,15 @@ class Detector(object):
 
     # ---- device-side batched path (no host sync) ----
     @torch.no_grad()
-    def detect_device(self, image, scales=None, out=None):
+    def detect_device(self, image, scales=None, out=None, shifts=None):
         """image [B,3,H,W] on the GPU -> (count [B] i32, class_ids [B,K] i64, scores [B,K], boxes [B,K,4],
-        anchor_idx [B,K] i32), all on the GPU; rows >= count[b] are padding."""
+        anchor_idx [B,K] i32), all on the GPU; rows >= count[b] are padding.  ``scales`` / ``shifts`` [B,2]: ``boxes_postprocess``'
+        scale division and padding / crops terms, folded into the detect kernel."""
         cfg = self.cfg
         pred = self.model.base(image)
         anchors = self.model.resolver.anchors_on(pred.device)
         return ops.detect(pred, anchors, cfg.input_size, cfg.num_classes, cfg.keep_top_k, cfg.nms_thresh,
-                          cfg.score_thresh, scales=scales, out=out)
+                          cfg.score_thresh, scales=scales, out=out, shifts=shifts)
 
     @torch.no_grad()
     def detect(self, batch):
@@ -49,13 +50,18 @@ class Detector(object):
         # fold the eval-time scale division (boxes_postprocess, src/utils/boxes.py:145-147) into the kernel
         # when that is the only active transform; otherwise post-process on the host like the reference
         simple = all(set(m.keys()) <= {'scales', 'index', 'image_id', 'orig_size', 'rgb_mean', 'rgb_std', 'drifts',
-                                       'drifted_size', 'flipped'}
+                                       'drifted_size', 'flipped', 'padding', 'crops'}
                      and not m.get('flipped', False) and not np.any(m.get('drifts', 0)) for m in metas)
-        scales = None
-        if simple and all('scales' in m for m in metas):
+        scales = shifts = None
+        padcrop = simple and all('padding' in m and 'crops' in m and 'scales' not in m for m in metas)
+        if simple and not padcrop and all('scales' in m and 'padding' not in m and 'crops' not in m for m in metas):
             scales = torch.tensor(np.stack([np.asarray(m['scales'], dtype=np.float32) for m in metas]),
                                   device=image.device, dtype=torch.float32)
-        cnt, cls, sc, bx, idx = self.detect_device(image, scales=scales)
+        if padcrop:
+            # the forbid_resize branch (src/datasets/base.py:53-54): un-pad / un-crop = one add per axis (only one of the two is non-zero)
+            shifts = torch.tensor(np.stack([[float(m['crops'][0]) - float(m['padding'][0]), float(m['crops'][2]) - float(m['padding'][2])]
+                                            for m in metas]).astype(np.float32), device=image.device)
+        cnt, cls, sc, bx, idx = self.detect_device(image, scales=scales, shifts=shifts)
         cnt, cls, sc, bx, idx = (t.cpu().numpy() for t in (cnt, cls, sc, bx, idx))   # one D2H round
         results = []
         for b in range(B):
@@ -65,29 +71,32 @@ class Detector(object):
                 continue
             det = {'class_ids': cls[b, :n].copy(), 'scores': sc[b, :n].copy(), 'boxes': bx[b, :n].copy(),
                    'anchor_idx': idx[b, :n].astype(np.int64)}
-            if scales is None:
+            if scales is None and shifts is None:
                 det['boxes'] = boxes_postprocess(det['boxes'], metas[b])
             det['image_meta'] = metas[b]
             results.append(det)
         return results
 
     @torch.no_grad()
-    def detect_images(self, images, image_ids=None):
+    def detect_images(self, images, image_ids=None, rgb_mean=None, rgb_std=None):
         """Raw path: list of uint8 HWC RGB images (any sizes) -> detections in original-image coordinates.
-        Upload of the uint8 pixels, GPU pre-processing (whiten + resize + CHW), backbone, fused detection with the
-        per-image scale division, one compact D2H copy."""
+        Upload of the uint8 pixels, GPU pre-processing (whiten + resize -- or, with ``cfg.forbid_resize``, whiten + crop_or_pad --
+        + CHW), backbone, fused detection with the per-image scale division (or un-pad / un-crop shift), one compact D2H copy.
+        ``rgb_mean`` / ``rgb_std``: the dataset's whitening statistics (default: ``cfg.rgb_mean`` / ``cfg.rgb_std``, else KITTI's)."""
         from .preprocess import preprocess_batch
         cfg = self.cfg
-        mean = getattr(cfg, 'rgb_mean', None)
-        std = getattr(cfg, 'rgb_std', None)
+        mean = rgb_mean if rgb_mean is not None else getattr(cfg, 'rgb_mean', None)
+        std = rgb_std if rgb_std is not None else getattr(cfg, 'rgb_std', None)
         kw = {} if mean is None or std is None else {'rgb_mean': np.asarray(mean).reshape(-1), 'rgb_std': np.asarray(std).reshape(-1)}
-        image, scales, meta = preprocess_batch(images, cfg.input_size, device=cfg.device, **kw)
-        cnt, cls, sc, bx, idx = (t.cpu().numpy() for t in self.detect_device(image, scales=scales))
+        forbid = bool(getattr(cfg, 'forbid_resize', False))
+        image, aux, meta = preprocess_batch(images, cfg.input_size, device=cfg.device, forbid_resize=forbid, **kw)
+        dets = self.detect_device(image, shifts=aux) if forbid else self.detect_device(image, scales=aux)
+        cnt, cls, sc, bx, idx = (t.cpu().numpy() for t in dets)
         results = []
         for b in range(len(images)):
             n = int(cnt[b])
-            m = {'orig_size': meta['orig_size'][b], 'scales': meta['scales'][b], 'index': b,
-                 'image_id': image_ids[b] if image_ids is not None else str(b)}
+            m = {'orig_size': meta['orig_size'][b], 'index': b, 'image_id': image_ids[b] if image_ids is not None else str(b)}
+            m.update({'padding': meta['padding'][b], 'crops': meta['crops'][b]} if forbid else {'scales': meta['scales'][b]})
             if n == 0:
                 results.append({'image_meta': m})
                 continue
@@ -110,20 +119,29 @@ class Detector(object):
         t_start = time.time()
         results = []
         data_s = net_s = 0.0
-        with ThreadPoolExecutor(max_workers=max(1, int(getattr(cfg, 'num_workers', 1)))) as pool:
-            load = lambda idxs: list(pool.map(dataset.load_image, idxs))       # noqa: E731  [(image, image_id), ...]
-            pending = pool.submit(load, batches[0]) if batches else None
+        # One future per IMAGE, submitted straight to the pool (a per-batch task that itself waits on the pool's workers deadlocks a
+        # one-worker pool); num_workers = 0 (the reference's "load in the main process") loads inline.
+        workers = int(getattr(cfg, 'num_workers', 4))
+        mean, std = getattr(dataset, 'rgb_mean', None), getattr(dataset, 'rgb_std', None)
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            if workers > 0:
+                submit = lambda idxs: [pool.submit(dataset.load_image, i) for i in idxs]       # noqa: E731
+                collect = lambda futs: [f.result() for f in futs]                              # noqa: E731  [(image, image_id), ...]
+            else:
+                submit = lambda idxs: idxs                                                     # noqa: E731
+                collect = lambda idxs: [dataset.load_image(i) for i in idxs]                   # noqa: E731
+            pending = submit(batches[0]) if batches else None
             for it, idxs in enumerate(batches):
                 t0 = time.time()
-                loaded = pending.result()
-                pending = pool.submit(load, batches[it + 1]) if it + 1 < len(batches) else None
+                loaded = collect(pending)
+                pending = submit(batches[it + 1]) if it + 1 < len(batches) else None
                 data_s = time.time() - t0
                 t0 = time.time()
                 raw = [np.asarray(im) for im, _ in loaded]
                 ids = [iid for _, iid in loaded]
                 as_u8 = [im if im.dtype == np.uint8 else im.astype(np.uint8) for im in raw]
                 if all(im.ndim == 3 and im.shape[2] == 3 and (im.dtype == np.uint8 or np.array_equal(u8, im)) for im, u8 in zip(raw, as_u8)):
-                    out = self.detect_images(as_u8, image_ids=ids)
+                    out = self.detect_images(as_u8, image_ids=ids, rgb_mean=mean, rgb_std=std)
                     for r, i in zip(out, idxs):
                         r['image_meta']['index'] = i
                 else:

@@ -580,9 +580,11 @@ def _det_workspace(B, A, device):
     return torch.zeros(4, device=device, dtype=torch.int32)
 
 
-def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3, scales=None, out=None):
+def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3, scales=None, out=None, shifts=None):
     """Fused decode + top-k + class-wise NMS + threshold for a batch.
-    Returns (count int32 [B], class_ids int64 [B,K], scores [B,K], boxes [B,K,4], anchor_idx int32 [B,K])."""
+    Returns (count int32 [B], class_ids int64 [B,K], scores [B,K], boxes [B,K,4], anchor_idx int32 [B,K]).  ``scales`` [B,2] =
+    (sy, sx): boxes are divided by them; ``shifts`` [B,2] = (dy, dx): added afterwards (the padding / crops terms of
+    ``boxes_postprocess``, src/utils/boxes.py:149-155)."""
     if pred.dim() != 3 or pred.shape[2] != num_classes + 5 or pred.dtype != torch.float32 or not pred.is_cuda:
         raise ValueError(f'detect: bad pred {tuple(pred.shape)}')
     pred = pred.contiguous()
@@ -591,6 +593,8 @@ def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4
         raise ValueError('detect: anchors must be fp32 [A,4] on the same device')
     if scales is not None and (tuple(scales.shape) != (B, 2) or scales.dtype != torch.float32 or scales.device != pred.device):
         raise ValueError('detect: scales must be fp32 [B,2] (sy, sx)')
+    if shifts is not None and (tuple(shifts.shape) != (B, 2) or shifts.dtype != torch.float32 or shifts.device != pred.device or not shifts.is_contiguous()):
+        raise ValueError('detect: shifts must be contiguous fp32 [B,2] (dy, dx)')
     bufs = out if out is not None else _det_buffers(B, keep_top_k, pred.device, A)
     if len(bufs) == 5:
         bufs = tuple(bufs) + (_det_workspace(B, A, pred.device),)
@@ -598,11 +602,11 @@ def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4
     if keys.dtype != torch.int32 or keys.device != pred.device:
         raise ValueError('detect: workspace must be an int32 tensor on the same device')
     br = _Bracket('detect', f'detect A{A}', 0.0, 4.0 * B * A * (num_classes + 5)) if timing._timer is not None else None
-    rc = nat.lib().sqd_detect_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(keys), nat.ptr(cnt), nat.ptr(cls),
-                                  nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes, int(input_size[0]),
-                                  int(input_size[1]), int(keep_top_k), float(nms_thresh), float(score_thresh),
-                                  nat.stream_handle(pred.device))
-    nat.check(rc, 'sqd_detect_fwd')
+    rc = nat.lib().sqd_detect_shift_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(shifts), nat.ptr(keys),
+                                        nat.ptr(cnt), nat.ptr(cls), nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes,
+                                        int(input_size[0]), int(input_size[1]), int(keep_top_k), float(nms_thresh), float(score_thresh),
+                                        nat.stream_handle(pred.device))
+    nat.check(rc, 'sqd_detect_shift_fwd')
     if br is not None:
         br.done()
     return bufs[:5]

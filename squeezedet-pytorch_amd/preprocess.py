@@ -44,9 +44,13 @@ def _pack_pool():
     return _POOL
 
 
-def preprocess_batch(images, input_size, device='cuda', rgb_mean=KITTI_RGB_MEAN, rgb_std=KITTI_RGB_STD, out=None):
+def preprocess_batch(images, input_size, device='cuda', rgb_mean=KITTI_RGB_MEAN, rgb_std=KITTI_RGB_STD, out=None, forbid_resize=False):
     """images: list of uint8 numpy arrays [H0, W0, 3] (RGB, any sizes).  Returns (image fp32 NCHW [B,3,H,W] on
-    ``device``, scales fp32 [B,2] = (H/H0, W/W0) on ``device``, image_meta dict of per-image lists/arrays)."""
+    ``device``, scales fp32 [B,2] = (H/H0, W/W0) on ``device``, image_meta dict of per-image lists/arrays).
+    ``forbid_resize`` (``cfg.forbid_resize``, src/datasets/base.py:53-54): whiten + ``crop_or_pad`` instead of whiten + resize --
+    the second return value is then the box shift fp32 [B,2] = (dy, dx) = (crops - padding)(top, left) that ``ops.detect(...,
+    shifts=)`` adds (``boxes_postprocess``' padding / crops terms), and ``image_meta`` carries ``padding`` / ``crops`` (int16 [B,4],
+    (top, bottom, left, right)) instead of ``scales``.  Bit-exact against the reference (tests/golden/padcrop.npz)."""
     if len(images) == 0:
         raise ValueError('preprocess_batch: empty batch')
     H, W = int(input_size[0]), int(input_size[1])
@@ -85,12 +89,25 @@ def preprocess_batch(images, input_size, device='cuda', rgb_mean=KITTI_RGB_MEAN,
     scales = torch.empty(B, 2, device=dev, dtype=torch.float32)
     mean = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(rgb_mean).reshape(-1)])
     std = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(rgb_std).reshape(-1)])
+    base_meta = {'orig_size': np.concatenate([sizes, np.full((B, 1), 3, np.int32)], 1),
+                 'drifts': np.zeros((B, 2), np.int32), 'flipped': [False] * B,
+                 'rgb_mean': np.tile(np.asarray(rgb_mean, np.float32).reshape(1, 1, 1, 3), (B, 1, 1, 1)),
+                 'rgb_std': np.tile(np.asarray(rgb_std, np.float32).reshape(1, 1, 1, 3), (B, 1, 1, 1))}
+    if forbid_resize:
+        rc = nat.lib().sqd_preprocess_u8_padcrop_fwd(nat.ptr(src), nat.ptr(d_off), nat.ptr(d_sizes), nat.ptr(out), nat.ptr(scales), None,
+                                                     mean, std, B, H, W, nat.stream_handle(dev))
+        nat.check(rc, 'sqd_preprocess_u8_padcrop_fwd')
+        padding, crops = np.zeros((B, 4), np.int16), np.zeros((B, 4), np.int16)      # the same integers on the host (image.py:99-115)
+        for i, (h0, w0) in enumerate(sizes):
+            for size, target, k in ((int(h0), H, 0), (int(w0), W, 2)):
+                if size < target:
+                    padding[i, k] = (target - size) // 2; padding[i, k + 1] = (target - size) - padding[i, k]
+                elif size > target:
+                    crops[i, k] = (size - target) // 2; crops[i, k + 1] = (size - target) - crops[i, k]
+        base_meta.update(padding=padding, crops=crops)
+        return out, scales, base_meta
     rc = nat.lib().sqd_preprocess_u8_fwd(nat.ptr(src), nat.ptr(d_off), nat.ptr(d_sizes), nat.ptr(out), nat.ptr(scales), mean, std,
                                          B, H, W, nat.stream_handle(dev))
     nat.check(rc, 'sqd_preprocess_u8_fwd')
-    meta = {'orig_size': np.concatenate([sizes, np.full((B, 1), 3, np.int32)], 1),
-            'scales': np.stack([np.array([H / s[0], W / s[1]], dtype=np.float32) for s in sizes]),
-            'drifts': np.zeros((B, 2), np.int32), 'flipped': [False] * B,
-            'rgb_mean': np.tile(np.asarray(rgb_mean, np.float32).reshape(1, 1, 1, 3), (B, 1, 1, 1)),
-            'rgb_std': np.tile(np.asarray(rgb_std, np.float32).reshape(1, 1, 1, 3), (B, 1, 1, 1))}
+    meta = dict(base_meta, scales=np.stack([np.array([H / s[0], W / s[1]], dtype=np.float32) for s in sizes]))
     return out, scales, meta
