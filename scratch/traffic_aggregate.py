@@ -17,6 +17,7 @@ def short_name(k):
         if m.group(9) == "true": return f"fire_sq_e1<{m.group(4)}>"
         base = "fire_expand" if m.group(6) == "true" else "conv_dma"
         return f"{base}<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>"
+    if short.startswith("conv_wino_sk_kernel"): return "conv_wino_sk"                  # balanced (stream-K) Winograd kernel, round 4
     m = re.match(r"conv_wino_kernel<(\d+), (\d+)>", short)
     if m: return f"conv_wino<{m.group(1)},{m.group(2)}>"
     m = re.match(r"conv_ws_kernel<(\d+), (\d+), \d+>", short)

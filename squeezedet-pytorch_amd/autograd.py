@@ -191,13 +191,12 @@ def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
     cd = base.convdet
     pred = torch.empty(Bq, H, W, cd.out_channels, device=a.device, dtype=torch.float32)
     fused_rng = drop is not None and drop_applied and drop_mask is None
-    if drop is not None and C % 8 == 0 and base.use_winograd:
-        # ConvDet on the balanced Winograd kernel; its launch advances the dropout step (this forward's mask is consumed)
-        ops.conv_wino(a, 0, base.wino_plan('convdet', cd, ops.WINO_SK_CFG), pred, 0, relu=False, drop_advance=drop)
-    else:
-        base.conv3x3('convdet', cd, a, 0, pred, 0, relu=False)
-        if drop is not None:
-            ops.dropout_advance(drop)
+    base.conv3x3('convdet', cd, a, 0, pred, 0, relu=False)
+    if drop is not None:
+        # this forward's mask is consumed: step += 1 on the device.  (The balanced Winograd kernel can carry the advance inside its
+        # launch -- ops.conv_wino(..., drop_advance=) -- but measured inside the step it runs ConvDet's forward slower than the unit
+        # kernel of the table, 219-230 against 208-216 us, which costs more than this one-thread launch.)
+        ops.dropout_advance(drop)
     if save:
         saved['convdet_in'] = a
         saved['drop_mask'] = drop_mask

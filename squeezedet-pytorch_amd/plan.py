@@ -128,8 +128,8 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
     ``loss.mean()``) are not KernelTimer-bracketed and not listed.  ``data_parallel_stages``: with a gradient exchange
     attached the slab reduction runs once per backward stage instead of once at the end.  ``fuse_squeeze_bwd`` =
     ``SqueezeDetBase.fuse_squeeze_bwd``.  ``dropout`` (``cfg.dropout_prob > 0``): the counter-based dropout in front of ConvDet rides
-    in the last Fire's expand launches (a weight-stationary 1x1 configuration + the balanced Winograd kernel) and ConvDet's forward and
-    data gradient run on the balanced Winograd kernel; where that form does not apply (``fused_dropout`` off, squeeze width not a
+    in the last Fire's expand launches (a weight-stationary 1x1 configuration + the balanced Winograd kernel) and ConvDet's data
+    gradient runs on the balanced Winograd kernel (mask = its own input, constant scale); where that form does not apply (``fused_dropout`` off, squeeze width not a
     multiple of 8) the mask is drawn by the stand-alone ``dropout_mask`` launch."""
     layers = layer_table(arch)
     ks = layers[0][3]
@@ -176,10 +176,7 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
     ccd = convdet_in_channels(arch)
     fused_rng = dropout and layers[-1][0] == 'fire' and (fused_dropout and layers[-1][2] % 8 == 0 and use_winograd
                                                            and ops.conv_drop_cfg(layers[-1][2], layers[-1][3], batch * H * W) is not None)
-    if dropout and ccd % 8 == 0 and use_winograd:
-        plan.append(('conv_wino_sk', f'9tap C{ccd} N{ncd} {H}x{W}'))
-    else:
-        plan.append(_conv3x3(batch, H, W, ccd, ncd, use_winograd))
+    plan.append(_conv3x3(batch, H, W, ccd, ncd, use_winograd))
     A = H * W * anchors_per_grid
     plan.append(('loss_fwd', f'loss A{A}'))
     plan.append(('loss_bwd', f'lossbwd A{A}'))

@@ -1,4 +1,4 @@
-"""Randomised parity sweep (scratch/fuzz_conv.py, fixed seed, short budget): every tile configuration x odd shapes,
+"""Randomised parity sweep (tools/fuzz_conv.py, fixed seed, short budget): every tile configuration x odd shapes,
 channel windows, partial K chunks, epilogue options, fused expand and weight gradients against torch CPU fp32."""
 import os
 import runpy
@@ -17,7 +17,7 @@ def test_conv_family_randomised_sweep(capsys):
         cwd = os.getcwd()
         os.chdir(ROOT)
         try:
-            runpy.run_path(os.path.join(ROOT, "scratch", "fuzz_conv.py"), run_name="__main__")
+            runpy.run_path(os.path.join(ROOT, "tools", "fuzz_conv.py"), run_name="__main__")
         except SystemExit as e:                                   # the script exits 1 on the first mismatch
             assert not e.code, capsys.readouterr().out
         finally:
@@ -29,7 +29,7 @@ def test_conv_family_randomised_sweep(capsys):
 
 @pytest.mark.gpu
 def test_stem_family_randomised_sweep(capsys, monkeypatch):
-    """scratch/fuzz_stem.py, fixed seed, short budget: the wave stem kernels (values bit for bit against the workgroup kernel, arg-max
+    """tools/fuzz_stem.py, fixed seed, short budget: the wave stem kernels (values bit for bit against the workgroup kernel, arg-max
     codes), the gather stem weight gradient (against the dense kernel on the same codes and, flip-aware, against autograd), stem +
     first squeeze, squeeze + expand1x1, on random image sizes / channel windows."""
     for k in ('SQD_STEM_WAVE', 'SQD_STEM_WGRAD_GATHER'):          # the script switches kernels through the environment: restore it afterwards
@@ -40,7 +40,7 @@ def test_stem_family_randomised_sweep(capsys, monkeypatch):
         cwd = os.getcwd()
         os.chdir(ROOT)
         try:
-            runpy.run_path(os.path.join(ROOT, "scratch", "fuzz_stem.py"), run_name="__main__")
+            runpy.run_path(os.path.join(ROOT, "tools", "fuzz_stem.py"), run_name="__main__")
         except SystemExit as e:
             assert not e.code, capsys.readouterr().out
         finally:
