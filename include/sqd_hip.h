@@ -173,7 +173,10 @@ int sqd_detect_fwd(const float* pred, const float* anchors, const float* scales,
 
 /* The same with shifts ([B][2] = (dy, dx), may be NULL) added to the boxes after the scale division: the padding / crops terms of
  * boxes_postprocess (src/utils/boxes.py:149-155) for images pre-processed by sqd_preprocess_u8_padcrop_fwd (the reference's
- * cfg.forbid_resize branch); per axis only one of padding / crops is non-zero, so one add of (crops - padding) is bit-exact. */
+ * cfg.forbid_resize branch); per axis only one of padding / crops is non-zero, so one add of (crops - padding) is bit-exact.
+ * keys_ws: NULL (one workgroup per image, as sqd_detect_fwd) or a workspace of B * ceil4(A) + B uint32 whose last B words are zero
+ * before the first launch (every launch leaves them zero): the anchors of an image are then scored by eight workgroups and the
+ * image's last arriver selects and suppresses -- same results bit for bit. */
 int sqd_detect_shift_fwd(const float* pred, const float* anchors, const float* scales, const float* shifts, unsigned* keys_ws,
                          int* det_count, long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
                          int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh, float score_thresh,

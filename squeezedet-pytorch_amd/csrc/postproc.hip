@@ -151,14 +151,15 @@ struct DetArgs {
   const float* pred; const float* anchors; const float* scales;   // scales [B][2] = (sy, sx) or null
   const float* shifts;                                            // [B][2] = (dy, dx) added after the scale division, or null
   const long long* in_class; const float* in_score; const float* in_box;   // dense inputs (filter mode) or null
-  unsigned* keys;                                                 // (unused since the keys live in LDS; kept in the ABI)
+  unsigned* keys;                                                 // workspace [B][ceil4(A)] keys + [B] arrival counters, or null (one workgroup per image)
   int S, per;
   int* det_count; long long* det_class; float* det_score; float* det_box; int* det_anchor;
   int B, A, C, K;
   float wmax, hmax, nms_thresh, score_thresh;
 };
 
-#define DET_SCORE_THREADS 1024      // threads per image (16 waves)
+#define DET_SCORE_THREADS 1024      // threads per workgroup (16 waves)
+#define DET_SPLIT 8                 // workgroups scoring one image when a key workspace is given
 
 __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -172,22 +173,29 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
   __shared__ int sorted_pos[DET_K];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = (int)blockIdx.x;
+  const int S = a.S;                                          // workgroups scoring one image (1: everything in this workgroup)
+  const int b = (int)blockIdx.x / S, seg = (int)blockIdx.x - b * S;
   const int A = a.A, C = a.C, K = a.K;
   const float* pred = a.pred ? a.pred + (long long)b * A * (C + 5) : nullptr;
   const bool dense = a.in_score != nullptr;
+  const int lo_a = seg * a.per, hi_a = min(A, lo_a + a.per);  // this workgroup's anchors (a.per is a multiple of 4)
 
-  // 1. score every anchor of the image straight into LDS (no key workspace in global memory, no second launch, no
-  //    cross-workgroup hand-off).  Two passes keep the exp / divide work dense:
+  // 1. score the anchors straight into LDS.  Two passes keep the exp / divide work dense:
   //    1a. confidence only: score = max_c softmax_c * conf <= conf (softmax_c <= 1 and the products round monotonically), so
   //        conf <= threshold already decides key = 0 -- exactly; the others are listed in LDS (any order);
   //    1b. the listed anchors (typically ~15 %) get the full score.
+  //    With S > 1 the image's anchors are split over S workgroups (one CU reads a 539 KB `pred` slice in ~20 us; eight read it in
+  //    ~3): each writes its keys to the global workspace (write-through), drains and draws a ticket; the last arriver of the image
+  //    loads all keys back into its LDS and carries on alone -- selection and NMS never leave that workgroup (in-launch hand-off of
+  //    cdna_hip_programming.md Guideline 16: sc1 payload + drained stores + agent-scope counter, no release fence, so the hundreds
+  //    of megabytes ConvDet's launch left dirty in the L2s are not written back for it; that is what made round 2's version of this
+  //    cost 61-156 us).
   if (tid == 0) s_nlive = 0u;
   __syncthreads();
-  for (int i0 = 0; i0 < A; i0 += DET_SCORE_THREADS) {
+  for (int i0 = lo_a; i0 < hi_a; i0 += DET_SCORE_THREADS) {
     const int i = i0 + tid;
     bool live = false;
-    if (i < A) {
+    if (i < hi_a) {
       if (dense) {
         const float s = a.in_score[(long long)b * A + i];
         keysL[i] = (s > a.score_thresh) ? __float_as_uint(s) : 0u;
@@ -216,6 +224,30 @@ __global__ __launch_bounds__(DET_SCORE_THREADS) void detect_kernel(DetArgs a) {
     }
   }
   __syncthreads();
+  if (S > 1) {
+    typedef unsigned int u32x4_d __attribute__((ext_vector_type(4)));
+    const int A4 = (A + 3) & ~3;
+    const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.keys + (long long)b * A4), 0, 0x7ffffff0, 0x00020000);
+    for (int q = lo_a / 4 + tid; q < (hi_a + 3) / 4; q += DET_SCORE_THREADS) {       // (keys past A inside the last quad: never read back)
+      u32x4_d v = *(const u32x4_d*)(keysL + 4 * q);
+      __builtin_amdgcn_raw_buffer_store_b128(v, kres, q * 16, 0, 16);               // sc1: write-through
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its stores ...
+    __syncthreads();                                         // ... before ONE lane counts the workgroup in
+    unsigned* const tick = a.keys + (long long)a.B * A4 + b;
+    if (tid == 0) s_cnt = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if ((int)s_cnt != S - 1) return;                         // not the last arriver of this image: done
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the counter returns to zero for the next launch
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int q = tid; q < A4 / 4; q += DET_SCORE_THREADS)
+      *(u32x4_d*)(keysL + 4 * q) = __builtin_amdgcn_raw_buffer_load_b128(kres, q * 16, 0, 16);   // sc1 loads: every key of the image
+    __syncthreads();
+  }
 
   if (tid < DET_K) { cand_key[tid] = 0u; cand_idx[tid] = 0x7fffffff - DET_K + tid; }   // distinct sentinels: ranks stay a permutation
   if (tid == 0) { s_prefix = 0u; s_need = (unsigned)K; s_cnt = 0u; }
@@ -401,17 +433,22 @@ static int launch_detect(DetArgs a, hipStream_t stream) {
       return SQD_ERR_LAUNCH;
     lds_enabled = 150 * 1024;
   }
-  a.S = 1; a.per = a.A;
-  hipLaunchKernelGGL(detect_kernel, dim3((unsigned)a.B), dim3(DET_SCORE_THREADS), lds, stream, a);
+  // pred mode with a workspace: eight workgroups score an image, its last arriver selects and suppresses (the workspace holds B x
+  // ceil4(A) keys + B counters that are zero between launches)
+  a.S = (a.pred && a.keys) ? DET_SPLIT : 1;
+  a.per = (((a.A + 3) / 4 + a.S - 1) / a.S) * 4;
+  hipLaunchKernelGGL(detect_kernel, dim3((unsigned)(a.B * a.S)), dim3(DET_SCORE_THREADS), lds, stream, a);
   return sqd_launch_status();
 }
 
-// Fused decode + Detector.filter for a batch, straight from pred.  keys_ws: unused (may be NULL; earlier versions kept
+// Fused decode + Detector.filter for a batch, straight from pred.  sqd_detect_fwd's keys_ws: unused (may be NULL; earlier versions kept
 // the per-anchor keys in global memory).  Outputs are fixed-capacity
 // [B][K]; rows >= det_count[b] are left untouched.  scales ([B][2] = (sy,sx), may be null) folds
 // boxes_postprocess' division into the store.
 // sqd_detect_shift_fwd: the same with shifts ([B][2] = (dy, dx), may be null) added to the boxes after the scale division --
-// boxes_postprocess' padding / crops terms of the reference's forbid_resize branch (src/utils/boxes.py:149-155).
+// boxes_postprocess' padding / crops terms of the reference's forbid_resize branch (src/utils/boxes.py:149-155) -- and, when keys_ws
+// is given (B * ceil4(A) + B uint32, the last B zero before the first launch; every launch leaves them zero), the scoring of an
+// image spread over eight workgroups whose last arriver selects and suppresses.  keys_ws NULL: one workgroup per image.
 extern "C" int sqd_detect_shift_fwd(const float* pred, const float* anchors, const float* scales, const float* shifts, unsigned* keys_ws,
                                     int* det_count, long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
                                     int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
@@ -433,7 +470,8 @@ extern "C" int sqd_detect_fwd(const float* pred, const float* anchors, const flo
                               long long* det_class, float* det_score, float* det_box, int* det_anchor, int B, int A,
                               int num_classes, int input_h, int input_w, int keep_top_k, float nms_thresh,
                               float score_thresh, void* stream) {
-  return sqd_detect_shift_fwd(pred, anchors, scales, nullptr, keys_ws, det_count, det_class, det_score, det_box, det_anchor, B, A,
+  (void)keys_ws;                      // (this entry point never required a sized workspace: one workgroup per image)
+  return sqd_detect_shift_fwd(pred, anchors, scales, nullptr, nullptr, det_count, det_class, det_score, det_box, det_anchor, B, A,
                               num_classes, input_h, input_w, keep_top_k, nms_thresh, score_thresh, stream);
 }
 

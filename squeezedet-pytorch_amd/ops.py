@@ -575,9 +575,15 @@ def det_buffers_packed(B, K, device, A=None):
     return bufs, flat
 
 
+def det_workspace_words(B, A):
+    """int32 words of the detect workspace: B x ceil4(A) keys + B arrival counters (sqd_detect_shift_fwd)."""
+    return B * (-(-A // 4) * 4) + B
+
+
 def _det_workspace(B, A, device):
-    """Placeholder for the ABI's ``keys_ws`` argument (the one-launch detect kernel keeps its keys in LDS)."""
-    return torch.zeros(4, device=device, dtype=torch.int32)
+    """Workspace of the fused detect launch (``keys_ws``): the keys the eight scoring workgroups of an image hand to its last arriver
+    + one arrival counter per image.  Zeroed once: every launch returns the counters to zero."""
+    return torch.zeros(det_workspace_words(B, A), device=device, dtype=torch.int32)
 
 
 def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4, score_thresh=0.3, scales=None, out=None, shifts=None):
@@ -601,6 +607,8 @@ def detect(pred, anchors, input_size, num_classes, keep_top_k=64, nms_thresh=0.4
     cnt, cls, sc, bx, idx, keys = bufs
     if keys.dtype != torch.int32 or keys.device != pred.device:
         raise ValueError('detect: workspace must be an int32 tensor on the same device')
+    if keys.numel() < det_workspace_words(B, A) or not keys.is_contiguous():
+        keys = None                                  # (a caller-made placeholder: one workgroup per image)
     br = _Bracket('detect', f'detect A{A}', 0.0, 4.0 * B * A * (num_classes + 5)) if timing._timer is not None else None
     rc = nat.lib().sqd_detect_shift_fwd(nat.ptr(pred), nat.ptr(anchors.contiguous()), nat.ptr(scales), nat.ptr(shifts), nat.ptr(keys),
                                         nat.ptr(cnt), nat.ptr(cls), nat.ptr(sc), nat.ptr(bx), nat.ptr(idx), B, A, num_classes,

@@ -309,7 +309,10 @@ def wgrad_uses_wino(N, C, taps, B, H, W, wino=None):
 def _wino_wgrad_tc(N, C):
     """Input-channel blocks of 16 per workgroup of the Winograd wgrad kernel: 2 (32 channels) unless that would leave the
     last block half empty (C = 16, 48, ...: measured 50 vs 62 us on C48 -> N192) or the 5-block ConvDet variant runs."""
-    return 1 if (N % 64 or C % 32 == 16 or C < 32) else 2
+    if N % 64:
+        import os
+        return 2 if (os.environ.get('SQD_WW52', '0')[:1] == '1' and C % 32 == 0) else 1
+    return 1 if (C % 32 == 16 or C < 32) else 2
 
 
 def _wgrad_wide():
@@ -326,7 +329,7 @@ def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False):
     if wgrad_uses_wino(N, C, taps, B, H, W, wino):
         ngroups = B * -(-H // 4) * -(-W // 16)                    # 4x16-pixel groups = the K axis of the 16 position GEMMs
         # (out-channel, in-channel) blocks of dU per workgroup: 64 x 16|32, or all of N <= 80 x 16 (ConvDet)
-        blocks = -(-C // 16) if N % 64 else (N // 64) * -(-C // (16 * _wino_wgrad_tc(N, C)))
+        blocks = -(-C // (16 * _wino_wgrad_tc(N, C))) if N % 64 else (N // 64) * -(-C // (16 * _wino_wgrad_tc(N, C)))
         S = max(1, min(ngroups, _TARGET_WGS_WINO // blocks if blocks <= _TARGET_WGS_WINO else 1))
         if tuned is not None and tuned >= 1:
             S = max(1, min(ngroups, int(tuned)))

@@ -497,3 +497,31 @@ def test_detect_into_packed_result_buffer():
     host = flat.cpu()                                            # one copy carries everything
     assert torch.equal(host[:4 * pred.shape[0]].view(torch.int32), plain[0].cpu()) and flat.numel() % 16 == 0
     assert all(t.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for t in bufs[:5])
+
+
+@pytest.mark.parametrize("B,A,seed", [(20, 16848, 1), (3, 16848, 2), (2, 1000, 3), (5, 37, 4), (1, 25600, 5)])
+def test_detect_split_scoring_equals_one_workgroup_per_image(B, A, seed):
+    """The fused detect launch with its key workspace (the anchors of an image scored by eight workgroups, the image's last arriver
+    selecting and suppressing; csrc/postproc.hip) == the same launch without (one workgroup per image), bit for bit, launch after
+    launch (the arrival counters return to zero), for anchor counts that are / are not multiples of the split."""
+    from squeezedet_pytorch_amd import ops
+    rs = np.random.RandomState(seed)
+    pred = torch.from_numpy((rs.standard_normal((B, A, 8)) * 1.5).astype(np.float32)).cuda()
+    anchors = torch.from_numpy(np.abs(rs.standard_normal((A, 4)) * 50 + 100).astype(np.float32)).cuda()
+    K = 64
+    one = ops._det_buffers(B, K, pred.device) + (torch.zeros(4, device='cuda', dtype=torch.int32),)      # placeholder -> one workgroup per image
+    ref = [t.clone() for t in ops.detect(pred, anchors, (384, 1248), 3, K, 0.4, 0.3, out=one)]
+    bufs = ops._det_buffers(B, K, pred.device, A)
+    assert bufs[5].numel() == ops.det_workspace_words(B, A)
+    for it in range(3):
+        for t in bufs[:5]:
+            t.zero_()
+        got = ops.detect(pred, anchors, (384, 1248), 3, K, 0.4, 0.3, out=bufs)
+        torch.cuda.synchronize()
+        assert int(bufs[5][-B:].abs().sum()) == 0, 'arrival counters must return to zero'
+        cnt = got[0].cpu().numpy()
+        assert np.array_equal(cnt, ref[0].cpu().numpy()) and (cnt > 0).all()
+        for b in range(B):
+            n = int(cnt[b])
+            for g, r in zip(got[1:], ref[1:]):
+                assert torch.equal(g[b, :n], r[b, :n]), (it, b)
