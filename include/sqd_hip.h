@@ -308,6 +308,16 @@ int sqd_loss_fwd(const float* pred, const float* gt, const float* anchors, float
 int sqd_loss_bwd(const float* pred, const float* gt, const float* anchors, const float* nobj, const float* coef,
                  float* dpred, int B, int A, int num_classes, int input_h, int input_w, float w_class,
                  float w_pos, float w_neg, float w_bbox, void* stream);
+/* `loss.mean()` + its backward (src/engine/trainer.py:43-47) inside the loss launches: sqd_loss_mean_fwd also writes mean4 [4] =
+ * batch means of (class, score, bbox, total); sqd_loss_mean_bwd takes gmean (DEVICE float: gradient arriving at mean(total), 1 for
+ * loss.mean().backward()) and gives every image's components gmean / B.  No torch reduction / elementwise kernel in the step. */
+int sqd_loss_mean_fwd(const float* pred, const float* gt, const float* anchors, float* workspace, float* losses, float* nobj,
+                      float* mean4, int B, int A, int num_classes, int input_h, int input_w, float w_class, float w_pos,
+                      float w_neg, float w_bbox, void* stream);
+int sqd_loss_mean_bwd(const float* pred, const float* gt, const float* anchors, const float* nobj, const float* gmean, float* dpred,
+                      int B, int A, int num_classes, int input_h, int input_w, float w_class, float w_pos, float w_neg,
+                      float w_bbox, void* stream);
+
 
 /* Fire.forward's two expand convolutions + torch.cat (src/model/squeezedet.py:18-22) in ONE Winograd launch (inference):
  * y[..., y_coff3 : +N3] = ReLU(conv3x3(x, w3) + b3), y[..., y_coff1 : +N1] = ReLU(conv1x1(x, w1) + b1).  A 1x1 convolution only

@@ -77,6 +77,8 @@ _SIGNATURES = {
     'sqd_encode_gt_fwd': [c_p] * 8 + [c_i, c_i, c_i, c_i, c_p],
     'sqd_loss_fwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],
     'sqd_loss_bwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],
+    'sqd_loss_mean_fwd': [c_p] * 7 + [c_i] * 5 + [c_f] * 4 + [c_p],
+    'sqd_loss_mean_bwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],
 }
 # symbols added by later build stages; bound when present in the library
 _OPTIONAL = {}

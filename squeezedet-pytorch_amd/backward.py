@@ -223,3 +223,26 @@ class LossFn(torch.autograd.Function):
         coef = (g[:3] + g[3:4]).contiguous()       # gradient of `total` reaches all three components
         dpred = ops.loss_bwd(pred, gt, anchors, nobj, coef, input_size, num_classes, weights)
         return dpred, None, None, None
+
+
+class LossMeanFn(torch.autograd.Function):
+    """``Loss(pred, gt)[0].mean()`` (src/engine/trainer.py:43) as ONE autograd node: the batch mean comes out of the loss launch, its
+    backward hands the scalar gradient straight to the loss backward kernel -- no torch reduction / select / elementwise kernels
+    between the loss and the backbone's backward."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, anchors, loss_mod):
+        res = loss_mod.resolver
+        weights = (loss_mod.class_loss_weight, loss_mod.positive_score_loss_weight,
+                   loss_mod.negative_score_loss_weight, loss_mod.bbox_loss_weight)
+        losses, nobj, mean4 = ops.loss_mean_fwd(pred.detach(), gt, anchors, res.input_size, res.num_classes, weights)
+        ctx.save_for_backward(pred.detach(), gt, anchors, nobj)
+        ctx.meta = (res.input_size, res.num_classes, weights)
+        ctx.mark_non_differentiable(losses)
+        return mean4[3], losses            # (0-dim view of the total's mean; the per-image vectors for the statistics)
+
+    @staticmethod
+    def backward(ctx, g, _gl):
+        pred, gt, anchors, nobj = ctx.saved_tensors
+        input_size, num_classes, weights = ctx.meta
+        return ops.loss_mean_bwd(pred, gt, anchors, nobj, g.reshape(1), input_size, num_classes, weights), None, None, None

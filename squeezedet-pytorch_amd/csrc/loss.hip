@@ -118,9 +118,30 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_partial_kernel(LossArgs a, 
   }
 }
 
-// losses[4][B] = (class, score = pos+neg, bbox, total); nobj[B]
+// losses[4][B] = (class, score = pos+neg, bbox, total); nobj[B].  mean4 (or null): the four batch means, loss.mean() of
+// src/engine/trainer.py:43 without a torch reduction kernel -- ONE block then walks the images (thread t takes b = t, t + 64, ...:
+// a fixed order) and the 64 partial sums meet in a fixed shuffle tree.
 __global__ void loss_finalize_kernel(const float* __restrict__ partial, float* __restrict__ losses, float* __restrict__ nobj,
-                                     int B, int A, float w_class, float w_pos, float w_neg, float w_bbox) {
+                                     int B, int A, float w_class, float w_pos, float w_neg, float w_bbox, float* __restrict__ mean4) {
+  if (mean4) {
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < B; b += 64) {
+      float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < LOSS_NPART; ++k)
+        for (int j = 0; j < 5; ++j) s[j] += partial[((long long)b * LOSS_NPART + k) * 5 + j];
+      const float n = s[0];
+      const float cls = w_class * s[1] / n, pos = w_pos * s[2] / n, neg = w_neg * s[3] / ((float)A - n), bbx = w_bbox * s[4] / n;
+      const float v[4] = {cls, pos + neg, bbx, cls + pos + neg + bbx};
+      for (int j = 0; j < 4; ++j) { losses[j * B + b] = v[j]; m[j] += v[j]; }
+      nobj[b] = n;
+    }
+    for (int j = 0; j < 4; ++j) {
+      float v = m[j];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+      if (threadIdx.x == 0) mean4[j] = v / (float)B;
+    }
+    return;
+  }
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -140,7 +161,8 @@ __global__ void loss_finalize_kernel(const float* __restrict__ partial, float* _
 
 // dpred[b][a][:] = u_class[b]*d(class_b) + u_score[b]*d(score_b) + u_bbox[b]*d(bbox_b), coef[3][B]
 __global__ __launch_bounds__(LOSS_THREADS) void loss_bwd_kernel(LossArgs a, const float* __restrict__ nobj,
-                                                                const float* __restrict__ coef, float* __restrict__ dpred) {
+                                                                const float* __restrict__ coef, float* __restrict__ dpred,
+                                                                const float* __restrict__ gmean) {
   const long long total = (long long)a.B * a.A;
   const int C = a.C;
   for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < total; row += (long long)gridDim.x * blockDim.x) {
@@ -150,7 +172,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_bwd_kernel(LossArgs a, cons
     AnchorTerms t;
     anchor_terms(a, p, g, a.anchors + 4 * i, t);
     const float n = nobj[b];
-    const float uc = coef[0 * a.B + b], us = coef[1 * a.B + b], ub = coef[2 * a.B + b];
+    // upstream gradients: per image and component (coef [3][B]), or (gmean: d / d mean(total)) the same gmean[0] / B for all
+    const float gm = gmean ? gmean[0] / (float)a.B : 0.f;
+    const float uc = gmean ? gm : coef[0 * a.B + b], us = gmean ? gm : coef[1 * a.B + b], ub = gmean ? gm : coef[2 * a.B + b];
     float* o = dpred + row * (C + 5);
     // class logits: w_c*mask/n * (sum(onehot)*softmax_j - onehot_j)
     const float kc = uc * a.w_class * t.mask / n;
@@ -213,7 +237,21 @@ extern "C" int sqd_loss_fwd(const float* pred, const float* gt, const float* anc
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_NPART, (unsigned)B), dim3(LOSS_THREADS), 0, s, a, workspace);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3((unsigned)sqd_cdiv(B, 64)), dim3(64), 0, s, workspace, losses, nobj, B, A,
-                     w_class, w_pos, w_neg, w_bbox);
+                     w_class, w_pos, w_neg, w_bbox, (float*)nullptr);
+  return sqd_launch_status();
+}
+
+// The same + mean4 [4] = the batch means of (class, score, bbox, total): `loss.mean()` of the training step
+// (src/engine/trainer.py:43) computed by the finalize launch itself.
+extern "C" int sqd_loss_mean_fwd(const float* pred, const float* gt, const float* anchors, float* workspace, float* losses,
+                                 float* nobj, float* mean4, int B, int A, int num_classes, int input_h, int input_w, float w_class,
+                                 float w_pos, float w_neg, float w_bbox, void* stream) {
+  LossArgs a;
+  if (int rc = fill_args(a, pred, gt, anchors, B, A, num_classes, input_h, input_w, w_class, w_pos, w_neg, w_bbox)) return rc;
+  SQD_CHECK_ARG(workspace && losses && nobj && mean4);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_NPART, (unsigned)B), dim3(LOSS_THREADS), 0, s, a, workspace);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, workspace, losses, nobj, B, A, w_class, w_pos, w_neg, w_bbox, mean4);
   return sqd_launch_status();
 }
 
@@ -226,6 +264,20 @@ extern "C" int sqd_loss_bwd(const float* pred, const float* gt, const float* anc
   SQD_CHECK_ARG(nobj && coef && dpred);
   const long long total = (long long)B * A;
   const int blocks = (int)((total + LOSS_THREADS - 1) / LOSS_THREADS);
-  hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a, nobj, coef, dpred);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a, nobj, coef, dpred, (const float*)nullptr);
+  return sqd_launch_status();
+}
+
+// Backward of mean(total): gmean = DEVICE float, the gradient arriving at the mean (1 for `loss.mean().backward()`); every image's
+// three components get gmean / B.
+extern "C" int sqd_loss_mean_bwd(const float* pred, const float* gt, const float* anchors, const float* nobj, const float* gmean,
+                                 float* dpred, int B, int A, int num_classes, int input_h, int input_w, float w_class,
+                                 float w_pos, float w_neg, float w_bbox, void* stream) {
+  LossArgs a;
+  if (int rc = fill_args(a, pred, gt, anchors, B, A, num_classes, input_h, input_w, w_class, w_pos, w_neg, w_bbox)) return rc;
+  SQD_CHECK_ARG(nobj && gmean && dpred);
+  const long long total = (long long)B * A;
+  const int blocks = (int)((total + LOSS_THREADS - 1) / LOSS_THREADS);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a, nobj, (const float*)nullptr, dpred, gmean);
   return sqd_launch_status();
 }

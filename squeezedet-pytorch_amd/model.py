@@ -408,6 +408,13 @@ class Loss(nn.Module):
         from .autograd import loss_apply
         return loss_apply(self, pred, gt)
 
+    def mean_loss(self, pred, gt):
+        """``forward(pred, gt)[0].mean()`` and the (detached) statistics as one autograd node whose forward and backward are the loss
+        kernels alone (backward.LossMeanFn): -> (mean total loss, 0-dim; stats dict of per-image vectors)."""
+        from .backward import LossMeanFn
+        mean, vec = LossMeanFn.apply(pred, gt, self.resolver.anchors_on(pred.device), self)
+        return mean, {'loss': vec[3], 'class_loss': vec[0], 'score_loss': vec[1], 'bbox_loss': vec[2]}
+
 
 class SqueezeDetWithLoss(nn.Module):
     """ Model for training """
@@ -421,3 +428,9 @@ class SqueezeDetWithLoss(nn.Module):
         pred = self.base(batch['image'])
         loss, loss_stats = self.loss(pred, batch['gt'])
         return loss, loss_stats
+
+    def forward_mean(self, batch):
+        """``forward(batch)[0].mean()`` (the scalar the reference's trainer differentiates, src/engine/trainer.py:43) + the per-image
+        statistics, with the mean and its backward inside the loss kernels (no torch kernel between loss and backbone)."""
+        pred = self.base(batch['image'])
+        return self.loss.mean_loss(pred, batch['gt'])

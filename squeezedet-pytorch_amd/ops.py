@@ -807,6 +807,41 @@ def loss_fwd(pred, gt, anchors, input_size, num_classes, weights):
     return losses, nobj
 
 
+def loss_mean_fwd(pred, gt, anchors, input_size, num_classes, weights):
+    """-> (losses [4,B], nobj [B], mean4 [4] = batch means of class / score / bbox / total): ``loss.mean()`` inside the loss launches."""
+    B, A = _check_loss_args(pred, gt, anchors, num_classes)
+    pred, gt, anchors = pred.contiguous(), gt.contiguous(), anchors.contiguous()
+    ws = torch.empty(B * 16 * 5, device=pred.device, dtype=torch.float32)
+    losses = torch.empty(4, B, device=pred.device, dtype=torch.float32)
+    nobj = torch.empty(B, device=pred.device, dtype=torch.float32)
+    mean4 = torch.empty(4, device=pred.device, dtype=torch.float32)
+    br = _Bracket('loss_fwd', f'loss A{A}', 0.0, 4.0 * B * A * (2 * num_classes + 14)) if timing._timer is not None else None
+    rc = nat.lib().sqd_loss_mean_fwd(nat.ptr(pred), nat.ptr(gt), nat.ptr(anchors), nat.ptr(ws), nat.ptr(losses), nat.ptr(nobj), nat.ptr(mean4),
+                                     B, A, num_classes, int(input_size[0]), int(input_size[1]), *[float(w) for w in weights],
+                                     nat.stream_handle(pred.device))
+    nat.check(rc, 'sqd_loss_mean_fwd')
+    if br is not None:
+        br.done()
+    return losses, nobj, mean4
+
+
+def loss_mean_bwd(pred, gt, anchors, nobj, gmean, input_size, num_classes, weights):
+    """gmean: device scalar (gradient arriving at mean(total)) -> dpred [B,A,C+5]."""
+    B, A = _check_loss_args(pred, gt, anchors, num_classes)
+    if gmean.numel() != 1 or gmean.dtype != torch.float32 or gmean.device != pred.device:
+        raise ValueError('loss_mean_bwd: gmean must be one fp32 value on the same device')
+    pred, gt, anchors = pred.contiguous(), gt.contiguous(), anchors.contiguous()
+    dpred = torch.empty_like(pred)
+    br = _Bracket('loss_bwd', f'lossbwd A{A}', 0.0, 4.0 * B * A * (3 * num_classes + 19)) if timing._timer is not None else None
+    rc = nat.lib().sqd_loss_mean_bwd(nat.ptr(pred), nat.ptr(gt), nat.ptr(anchors), nat.ptr(nobj), nat.ptr(gmean.contiguous()), nat.ptr(dpred), B, A,
+                                     num_classes, int(input_size[0]), int(input_size[1]), *[float(w) for w in weights],
+                                     nat.stream_handle(pred.device))
+    nat.check(rc, 'sqd_loss_mean_bwd')
+    if br is not None:
+        br.done()
+    return dpred
+
+
 def loss_bwd(pred, gt, anchors, nobj, coef, input_size, num_classes, weights):
     """coef [3,B] -> dpred [B,A,C+5]."""
     B, A = _check_loss_args(pred, gt, anchors, num_classes)

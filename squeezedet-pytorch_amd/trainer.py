@@ -295,10 +295,21 @@ class Trainer(object):
                 for k, v in batch.items()}
 
     def _iteration(self, batch, train):
-        per_image_loss, parts = self.model(batch)
+        fused = train and hasattr(self.model, 'forward_mean')
+        if fused:
+            # loss.mean() and its backward inside the loss kernels (no torch reduction / elementwise launches in the step)
+            mean_loss, parts = self.model.forward_mean(batch)
+            per_image_loss = parts['loss']
+        else:
+            per_image_loss, parts = self.model(batch)
         if train:
             self.optimizer.zero_grad()
-            per_image_loss.mean().backward()       # local shard mean; the gradient exchange turns it into the global mean
+            if fused:
+                if getattr(self, '_one', None) is None or self._one.device != mean_loss.device:
+                    self._one = torch.ones((), device=mean_loss.device)
+                mean_loss.backward(self._one)      # local shard mean; the gradient exchange turns it into the global mean
+            else:
+                per_image_loss.mean().backward()
             if not (isinstance(self.optimizer, FusedClipSGD) and self.optimizer.max_norm > 0):      # (it clips inside its one launch)
                 torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], self.cfg.grad_norm)
             self.optimizer.step()
@@ -496,11 +507,12 @@ def make_train_step(cfg, state_dict, image, rank, world, dist, gt_seed=1, force_
     if parts is not None:                            # (bench.py diagnostics: the objects behind the closure)
         parts.update(model=model, optimizer=opt, base=find_base(model), exchange=ex)
 
+    one = torch.ones((), device=image.device)       # the root gradient, allocated once (autograd would fill a new tensor every step)
+
     def step():
-        loss, stats = model(batch)
-        loss = loss.mean()
+        loss, stats = model.forward_mean(batch)     # = model(batch)[0].mean(), the mean and its backward inside the loss kernels
         opt.zero_grad()
-        loss.backward()
+        loss.backward(one)
         if not fused_optimizer:
             torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm)
         opt.step()                                   # (fused: clip + SGD in one launch)

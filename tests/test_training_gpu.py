@@ -511,3 +511,26 @@ def test_fused_1x1_backward_serves_expand1x1(s, e1, B, H, W):
     assert (red[:e1 * s].view(e1, s, 1, 1) - w.grad.double()).abs().max().item() <= 2e-4 * max(1.0, float(w.grad.abs().max()))
     assert (red[e1 * s:] - b.grad.double()).abs().max().item() <= 2e-4 * max(1.0, float(b.grad.abs().max()))
     assert (dx.cpu() - _nhwc(sq.grad)).abs().max().item() <= 2e-5 * max(1.0, float(sq.grad.abs().max()))
+
+
+def test_mean_loss_node_equals_loss_mean():
+    """``SqueezeDetWithLoss.forward_mean`` (loss.mean() and its backward inside the loss kernels, backward.LossMeanFn) == the
+    reference's two lines ``loss, stats = model(batch); loss.mean().backward()`` (src/engine/trainer.py:42-47): the scalar to fp32
+    rounding of the mean, the per-image statistics bit for bit, every parameter gradient to rounding (the upstream coefficient 1/B
+    is formed inside the kernel instead of by torch's broadcast)."""
+    size = (64, 96)
+    cfg, m, sd = _train_model('squeezedet', size)
+    x = synthetic.make_images(3, size, seed=3).cuda()
+    gt = synthetic.make_gt(3, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3).cuda()
+    loss, stats = m({'image': x, 'gt': gt})
+    loss.mean().backward()
+    ref = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    mean, stats2 = m.forward_mean({'image': x, 'gt': gt})
+    assert mean.dim() == 0 and abs(float(mean) - float(loss.mean())) <= 1e-6 * abs(float(loss.mean()))
+    for k in ('loss', 'class_loss', 'score_loss', 'bbox_loss'):
+        assert torch.equal(stats[k].detach(), stats2[k])
+    mean.backward(torch.ones((), device='cuda'))
+    for n, p in m.named_parameters():
+        scale = float(ref[n].abs().max()) + 1e-20
+        assert float((p.grad - ref[n]).abs().max()) <= 2e-5 * scale, n
