@@ -372,6 +372,12 @@ int sqd_grad_sumsq(const float* grad_flat, long long n, float* parts, void* stre
 int sqd_grad_sumsq_parts(void);
 int sqd_sgd_clip_step_parts(const void* descs_dev, int n, const float* grad_base, const float* sumsq_parts, float* norm_out,
                             float max_norm, float lr, float momentum, float weight_decay, int blocks_per_desc, void* stream);
+/* The same step with the elements dealt in equal chunks (one workgroup per sqd_sgd_chunk_elems() elements of one tensor) instead of a
+ * fixed number of workgroups per tensor: chunks_dev = [nchunks][2] int64 {tensor index, first element}. */
+int sqd_sgd_chunk_elems(void);
+int sqd_sgd_clip_step_chunked(const void* descs_dev, const void* chunks_dev, int nchunks, const float* grad_base,
+                              const float* sumsq_parts, float* norm_out, float max_norm, float lr, float momentum, float weight_decay,
+                              void* stream);
 
 
 #ifdef __cplusplus

@@ -72,6 +72,8 @@ _SIGNATURES = {
     'sqd_sgd_clip_step': [c_p, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p],
     'sqd_grad_sumsq': [c_p, ctypes.c_longlong, c_p, c_p],
     'sqd_grad_sumsq_parts': [],
+    'sqd_sgd_chunk_elems': [],
+    'sqd_sgd_clip_step_chunked': [c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_p],
     'sqd_sgd_clip_step_parts': [c_p, c_i, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p],
     'sqd_fire_pool_bridge_fwd': [c_p] * 6 + [c_i] * 15 + [c_p],
     'sqd_encode_gt_fwd': [c_p] * 8 + [c_i, c_i, c_i, c_i, c_p],

@@ -239,6 +239,7 @@ class LossMeanFn(torch.autograd.Function):
         ctx.save_for_backward(pred.detach(), gt, anchors, nobj)
         ctx.meta = (res.input_size, res.num_classes, weights)
         ctx.mark_non_differentiable(losses)
+        ctx.set_materialize_grads(False)   # (no zero-filled gradient tensor for the statistics output: that is a fill launch per step)
         return mean4[3], losses            # (0-dim view of the total's mean; the per-image vectors for the statistics)
 
     @staticmethod

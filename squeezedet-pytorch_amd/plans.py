@@ -65,7 +65,7 @@ def repack_batched(plans_and_weights, is_dgrad):
             _PACK_TABLES.clear()
         table = torch.tensor(rows, dtype=torch.int64).to(dev)
         _PACK_TABLES[key] = table
-    rc = nat.lib().sqd_pack_conv_weights_batched(nat.ptr(table), len(rows), 16, nat.stream_handle(dev))
+    rc = nat.lib().sqd_pack_conv_weights_batched(nat.ptr(table), len(rows), 96, nat.stream_handle(dev))
     nat.check(rc, 'sqd_pack_conv_weights_batched')
     return table
 
@@ -211,7 +211,7 @@ def repack_wino_batched(plans_and_weights, is_dgrad):
             _PACK_TABLES.clear()
         table = torch.tensor(rows, dtype=torch.int64).to(dev)
         _PACK_TABLES[key] = table
-    nat.check(nat.lib().sqd_pack_wino_weights_batched(nat.ptr(table), len(rows), 16, nat.stream_handle(dev)), 'sqd_pack_wino_weights_batched')
+    nat.check(nat.lib().sqd_pack_wino_weights_batched(nat.ptr(table), len(rows), 96, nat.stream_handle(dev)), 'sqd_pack_wino_weights_batched')
     return table
 
 

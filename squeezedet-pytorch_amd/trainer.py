@@ -384,7 +384,7 @@ class FusedClipSGD(torch.optim.Optimizer):
         for p in self.params:
             self._bufs.append(self.momentum_flat[off:off + p.numel()]); off += p.numel()
             self.state[p]['momentum_buffer'] = self._bufs[-1]       # views: attach_data_parallel broadcasts optimizer state tensors in place
-        self._table = self._table_key = None
+        self._table = self._table_key = self._chunks = None
         self._norm_ws = None                           # partial sums of squares + the norm (device)
         self.last_norm = None
 
@@ -444,6 +444,10 @@ class FusedClipSGD(torch.optim.Optimizer):
                     raise RuntimeError('FusedClipSGD.step: parameters must stay contiguous fp32 GPU tensors')
                 rows.append([p.data_ptr(), off if flat is not None else g.data_ptr(), b.data_ptr(), p.numel()]); off += p.numel()
             self._table = torch.tensor(rows, dtype=torch.int64).to(params[0].device)
+            # equal chunks of the 64 tensors (16 .. 500 k elements): one workgroup per chunk
+            ce = int(nat.lib().sqd_sgd_chunk_elems())
+            chunks = [[i, e] for i, p in enumerate(params) for e in range(0, p.numel(), ce)]
+            self._chunks = torch.tensor(chunks, dtype=torch.int64).to(params[0].device)
             self._table_key = key
         norm = None
         max_norm = self.max_norm
@@ -453,9 +457,9 @@ class FusedClipSGD(torch.optim.Optimizer):
                 self._norm_ws = torch.empty(int(nat.lib().sqd_grad_sumsq_parts()) + 1, device=flat.device, dtype=torch.float32)
             parts, norm = self._norm_ws[:-1], self._norm_ws[-1]
             nat.check(nat.lib().sqd_grad_sumsq(nat.ptr(flat), self.total, nat.ptr(parts), nat.stream_handle(flat.device)), 'sqd_grad_sumsq')
-            nat.check(nat.lib().sqd_sgd_clip_step_parts(nat.ptr(self._table), len(params), nat.ptr(flat), nat.ptr(parts), nat.ptr(norm),
-                                                        max_norm, self.lr, self.momentum, self.weight_decay, 64,
-                                                        nat.stream_handle(params[0].device)), 'sqd_sgd_clip_step_parts')
+            nat.check(nat.lib().sqd_sgd_clip_step_chunked(nat.ptr(self._table), nat.ptr(self._chunks), self._chunks.shape[0], nat.ptr(flat),
+                                                          nat.ptr(parts), nat.ptr(norm), max_norm, self.lr, self.momentum, self.weight_decay,
+                                                          nat.stream_handle(params[0].device)), 'sqd_sgd_clip_step_chunked')
         else:
             if max_norm > 0:
                 norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))

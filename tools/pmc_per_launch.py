@@ -67,7 +67,7 @@ def main():
         for j in range(per_step):
             row = {c: sum(v[j::per_step]) / len(v[j::per_step]) for c, v in cs.items() if len(v) == n}
             t = tags.get(k, [])
-            row_tag = t[j] if len(t) == per_step else f'#{j}'
+            row_tag = (t[j] if len(t) == per_step else '?') + f' #{j}'
             result[f'{k} | {row_tag}'] = row
     keys = sorted({c for k, v in result.items() if k != '_meta' for c in v})
     lines.append('launch'.ljust(64) + ''.join(c[-22:].rjust(24) for c in keys))
