@@ -310,11 +310,11 @@ def _wino_wgrad_tc(N, C):
     """Input-channel blocks of 16 per workgroup of the Winograd wgrad kernel: 2 (32 channels) unless that would leave the
     last block half empty (C = 16, 48, ...: measured 50 vs 62 us on C48 -> N192) or the 5-block ConvDet variant runs."""
     if N % 64:
-        # the 5-block (N <= 80: ConvDet) variant with 32 input channels per workgroup: the dY tile is staged for half as many channel
-        # groups and a group iteration is long enough to cover its own prefetch (228 -> 218 us at bs=20; 14 spilled registers sit in
-        # the DMA issue, outside the MFMA blocks).  SQD_WW52=0 restores the 16-channel form.
+        # the 5-block (N <= 80: ConvDet) variant can take 32 input channels per workgroup (SQD_WW52=1): the dY tile is staged for half
+        # as many channel groups, 228 -> 218 us at bs=20 -- but a resident round then has twice the splits (S 10 -> 21), its slabs grow
+        # from 20 to 42 MB and the batched reduction pays the 10 us back (0.112 -> 0.124 ms): off
         import os
-        return 2 if (os.environ.get('SQD_WW52', '1')[:1] != '0' and C % 32 == 0) else 1
+        return 2 if (os.environ.get('SQD_WW52', '0')[:1] == '1' and C % 32 == 0) else 1
     return 1 if (C % 32 == 16 or C < 32) else 2
 
 
