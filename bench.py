@@ -46,6 +46,10 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
     ap.add_argument('--layers', action='store_true', help='add per-layer (kernel, shape) event times to the line')
     ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even at N=1 (exercises the RCCL path on one GPU)')
+    ap.add_argument('--inflight', type=int, default=2,
+                    help='inference steps in flight: 2 = two captured copies of the step (own activations and result buffers) replayed '
+                         'alternately on two streams, so the serial tail of a step (every kernel\'s last round, the detect launch) '
+                         'overlaps the head of the next; 1 = back-to-back replays on one stream (reported either way)')
     ap.add_argument('--no-pipeline', action='store_true', help='skip the end-to-end leg (pinned uint8 -> H2D -> preprocess -> net -> detect -> D2H)')
     return ap.parse_args()
 
@@ -442,7 +446,7 @@ def main():
         mean = (ctypes.c_float * 3)(*KITTI_RGB_MEAN.tolist()); std = (ctypes.c_float * 3)(*KITTI_RGB_STD.tolist())
         d_off = (torch.arange(B, dtype=torch.int64) * per).to(dev)
         d_sizes = torch.tensor([[H0, W0]] * B, dtype=torch.int32).to(dev)
-        copy_stream, back_stream, comp = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
+        copy_stream, back_stream, main = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
         K = cfg.keep_top_k
         slots = []
         for _ in range(2):
@@ -453,7 +457,8 @@ def main():
                               img=torch.empty(B, 3, Hn, Wn, device=dev), sc=torch.empty(B, 2, device=dev), out=out, flat=flat,
                               res=torch.empty(flat.shape, dtype=torch.uint8, pin_memory=True),
                               uploaded=torch.cuda.Event(), consumed=torch.cuda.Event(), done=torch.cuda.Event(),
-                              copied=torch.cuda.Event(), graph=None))
+                              copied=torch.cuda.Event(), graph=None,
+                              comp=(torch.cuda.Stream() if args.inflight >= 2 else main)))      # a compute stream per slot: two batches in flight
         d2h_bytes = slots[0]['flat'].numel()
 
         def compute(sl):
@@ -470,12 +475,14 @@ def main():
 
         def one(i):
             sl = slots[i & 1]
+            comp = sl['comp']
             comp.wait_event(sl['uploaded'])
             comp.wait_event(sl['copied'])                        # the results this slot produced two batches ago have left
-            if sl['graph'] is not None:
-                sl['graph'].replay()
-            else:
-                compute(sl)
+            with torch.cuda.stream(comp):
+                if sl['graph'] is not None:
+                    sl['graph'].replay()
+                else:
+                    compute(sl)
             sl['consumed'].record(comp)
             upload(slots[(i + 1) & 1])                           # next batch's upload overlaps this batch's compute
             with torch.cuda.stream(back_stream):                 # compact results -> pinned host memory on a stream of their own:
@@ -483,8 +490,9 @@ def main():
                 sl['res'].copy_(sl['flat'], non_blocking=True)
                 sl['copied'].record(back_stream)
         for sl in slots:
-            sl['consumed'].record(comp)
-            sl['copied'].record(comp)
+            sl['comp'].wait_stream(main)
+            sl['consumed'].record(sl['comp'])
+            sl['copied'].record(sl['comp'])
         upload(slots[0])
         for i in range(4):
             one(i)
@@ -494,13 +502,13 @@ def main():
             try:
                 side = torch.cuda.Stream()
                 for sl in slots:
-                    side.wait_stream(comp)
+                    side.wait_stream(sl['comp'])
                     with torch.cuda.stream(side):
                         g = torch.cuda.CUDAGraph()
                         mode = {'capture_error_mode': 'thread_local'} if dist is not None else {}
                         with torch.cuda.graph(g, stream=side, **mode):
                             compute(sl)
-                    comp.wait_stream(side)
+                    sl['comp'].wait_stream(side)
                     sl['graph'] = g
                 how = 'hipGraph replay of preprocess + net + detect per slot; copies eager on their streams'
             except Exception as e:  # noqa: BLE001
@@ -557,14 +565,63 @@ def main():
             return det.detect_device(x, out=out_bufs)
         elapsed, repeat, how, run = measure(infer_step, capture=True)
         summ, nprof = event_profile(infer_step, run)
+        serial_ms = elapsed / args.steps * 1e3
+        inflight = 1
+        if args.inflight >= 2 and how == 'hipGraph replay':
+            # Steps in flight: the K timed steps are the same K passes over the resident batch, but step i + 1 is enqueued on another
+            # stream than step i (its own captured graph, activations and result buffers), so it starts while step i drains -- the
+            # last round of every persistent kernel and the 20-to-160-workgroup detect launch leave most of the chip idle.  A caller
+            # with a queue of batches (Detector.detect_dataset, the pipeline leg) runs exactly like this.
+            try:
+                lanes = []
+                for _ in range(args.inflight):
+                    st = torch.cuda.Stream()
+                    ob = ops._det_buffers(B, cfg.keep_top_k, dev, cfg.num_anchors)
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        det.detect_device(x, out=ob)
+                        st.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        mode = {'capture_error_mode': 'thread_local'} if (dist is not None and not os.environ.get('SQD_BENCH_GLOBAL_CAPTURE')) else {}
+                        with torch.cuda.graph(g, stream=st, **mode):
+                            det.detect_device(x, out=ob)
+                    lanes.append((st, g, ob))
+                torch.cuda.synchronize()
+
+                def run_lanes(n):
+                    for i in range(n):
+                        st, g, _ = lanes[i % len(lanes)]
+                        with torch.cuda.stream(st):
+                            g.replay()
+                run_lanes(2 * len(lanes))
+                barrier()
+                t0 = time.perf_counter()
+                run_lanes(args.steps)
+                barrier()
+                e2 = max_over_ranks(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                run_lanes(args.steps)
+                barrier()
+                r2 = max_over_ranks(time.perf_counter() - t0)
+                same = all(torch.equal(a, b) for a, b in zip(lanes[0][2][:5], out_bufs[:5])) and \
+                    all(torch.equal(a, b) for a, b in zip(lanes[0][2][:5], lanes[-1][2][:5]))
+                if not same:
+                    raise RuntimeError('the lanes of the in-flight run disagree with the serial step')
+                elapsed, repeat, inflight = e2, r2, len(lanes)
+                how = f'hipGraph replay, {inflight} steps in flight (one stream per lane)'
+                del lanes
+            except Exception as e:  # noqa: BLE001 -- the serial measurement stands
+                print(f'[bench] in-flight run failed ({type(e).__name__}: {e}); reporting the serial replays', file=sys.stderr)
+                torch.cuda.synchronize()
         ms = elapsed / args.steps * 1e3
-        roof, kernels = roofline_of(summ, ms, nprof)
+        roof, kernels = roofline_of(summ, serial_ms, nprof)      # (kernel shares are of the serial step: in flight they overlap)
         value = B * joined * args.steps / elapsed
         gf = FWD_GFLOP_PER_IMAGE[args.arch]
         where = '1 MI355X' if joined == 1 else f'each of {joined} MI355X (independent replicas, no data-path collective)'
         result['infer'] = {
             'value': round(value, 1), 'ms_per_step': round(ms, 4), 'timed_with': how,
             'repeat_window_ms_per_step': round(repeat / args.steps * 1e3, 4),
+            'steps_in_flight': inflight, 'serial_ms_per_step': round(serial_ms, 4),      # (back-to-back replays on ONE stream)
             'eager_steps_launched': eager_steps[0],      # (profiling scripts divide launch counts by this; with --no-graph = every step)
             'workload': (f'SqueezeDet KITTI 1248x384 bs={B} inference on {where} (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
                          else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on {where}'),
@@ -676,10 +733,12 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': head['workload'], 'arch': args.arch, 'images_per_gpu_per_step': B, 'global_batch': B * joined,
                        'input': '3x384x1248 fp32 NCHW, HBM resident', 'weights': 'synthetic Kaiming-scale, seed 1234',
-                       'parallelism': (f'replicas x{joined}' if what == 'inference' else f'dp{joined}')},
+                       'parallelism': (f'replicas x{joined}' if what == 'inference' else f'dp{joined}'),
+                       **({'steps_in_flight': head['steps_in_flight']} if 'steps_in_flight' in head else {})},
             'roofline': head['roofline'], 'cpu_baseline': cpu, 'parity': parity,
             'whole_network': head.get('whole_network'), 'timed_with': head['timed_with'],
             'repeat_window_ms_per_step': head['repeat_window_ms_per_step'],
+            **({'steps_in_flight': head['steps_in_flight'], 'serial_ms_per_step': head['serial_ms_per_step']} if 'steps_in_flight' in head else {}),
             'layer_families': head['layer_families'], 'kernels_event_profile': head['kernels_event_profile'],
         }
         if 'eager_steps_launched' in head:

@@ -315,6 +315,9 @@ def _wino_wgrad_tc(N, C):
         # from 20 to 42 MB and the batched reduction pays the 10 us back (0.112 -> 0.124 ms): off
         import os
         return 2 if (os.environ.get('SQD_WW52', '0')[:1] == '1' and C % 32 == 0) else 1
+    import os
+    if os.environ.get('SQD_WW_TC1', '0')[:1] == '1':      # (A/B: 16-channel in-tiles everywhere = twice the blocks, half the splits and slab bytes)
+        return 1
     return 1 if (C % 32 == 16 or C < 32) else 2
 
 
@@ -333,7 +336,9 @@ def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False):
         ngroups = B * -(-H // 4) * -(-W // 16)                    # 4x16-pixel groups = the K axis of the 16 position GEMMs
         # (out-channel, in-channel) blocks of dU per workgroup: 64 x 16|32, or all of N <= 80 x 16 (ConvDet)
         blocks = -(-C // (16 * _wino_wgrad_tc(N, C))) if N % 64 else (N // 64) * -(-C // (16 * _wino_wgrad_tc(N, C)))
-        S = max(1, min(ngroups, _TARGET_WGS_WINO // blocks if blocks <= _TARGET_WGS_WINO else 1))
+        import os
+        tw = int(os.environ.get('SQD_WW_TARGET', _TARGET_WGS_WINO))
+        S = max(1, min(ngroups, tw // blocks if blocks <= tw else 1))
         if tuned is not None and tuned >= 1:
             S = max(1, min(ngroups, int(tuned)))
         return S, N * taps * C + N
