@@ -123,6 +123,13 @@ int sqd_stem_conv_relu_pool_fwd(const float* x_nchw, const float* w_oihw, const 
 int sqd_stem_pool_squeeze_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* w_sq, const float* b_sq,
                               float* y_nhwc, int B, int Hin, int Win, int N, int ksize, int nsq, void* stream);
 
+/* Training form of sqd_stem_pool_squeeze_fwd (the forward of src/engine/trainer.py:42 through src/model/squeezedet.py:34-37, 17-18): the
+ * pooled tensor y_pooled [B][Hp][Wp][N] and its codes (argmax, as sqd_stem_conv_relu_pool_fwd) are stored -- the backward reads both --
+ * and the first Fire's squeeze output y_sq [B][Hp][Wp][nsq] leaves the same launch.  Same limits as sqd_stem_pool_squeeze_fwd. */
+int sqd_stem_pool_squeeze_train_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* w_sq, const float* b_sq,
+                                    float* y_pooled, unsigned char* argmax, float* y_sq, int B, int Hin, int Win, int N, int ksize,
+                                    int nsq, void* stream);
+
 /* Fire.squeeze + squeeze_activation + Fire.expand1x1 + expand1x1_activation (src/model/squeezedet.py:17-19) in ONE launch: the
  * squeeze tile feeds the expand1x1 from registers.  y_sq[..., sq_coff : +Nsq] = the squeeze output (read by the expand3x3 launch and
  * by the backward), y_out[..., out_coff : +E1] = the expand1x1 half of the Fire's concat.  Both weight sets packed as by
@@ -347,6 +354,20 @@ int sqd_fire_bridge_fwd(const float* x, const float* u_packed, const float* bias
                         float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total, int Nsq,
                         int y_pitch, int y_coff, int cfg_id, void* stream);
 
+/* Training form of sqd_fire_bridge_fwd cfg 12 (C <= 16; the forward of src/engine/trainer.py:42 through src/model/squeezedet.py:18-22
+ * twice): the same launch ALSO stores the concatenated expand output, save [B][H][W][save_pitch] with expand1x1 at save_coff1 and
+ * expand3x3 at save_coff3 -- the tensor the backward reads (input of the next squeeze's weight gradient, ReLU masks).  The next
+ * Fire's squeeze has no launch of its own and does not read the 128-channel tensor back. */
+int sqd_fire_bridge_save_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                             float* y, float* save, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1,
+                             int Npad_total, int Nsq, int y_pitch, int y_coff, int save_pitch, int save_coff3, int save_coff1,
+                             void* stream);
+
+/* In-place refresh of the Fire bridges' operands after an optimizer step (src/engine/trainer.py:50 changes every parameter), ONE launch
+ * for all of them: descs_dev = n records of 7 int64 {dst, idx (int32 map), count, src0, src1, src2, src3}; dst[i] = 0 where idx[i] == -1,
+ * untouched where -2, else scale * src[(idx >> 26) & 3][idx & 0x3ffffff] with scale 1 / +0.25 / -0.25 for (idx >> 28) & 3 = 0 / 1 / 2. */
+int sqd_gather_pack_batched(const void* descs_dev, int n, int blocks_per_desc, void* stream);
+
 /* Fire k's expand pair + torch.cat + MaxPool2d(3, 2, ceil_mode=True) + Fire k+1's squeeze (src/model/squeezedet.py:18-22 and the
  * features[...] sequence at 47-52: Fire, MaxPool2d, Fire) in ONE launch (inference): y [B][Hp][Wp] window [y_coff, +Nsq) =
  * ReLU(Wsq . maxpool(cat(ReLU(conv1x1(x) + b1), ReLU(conv3x3(x) + b3))) + bsq).  Neither the expand output nor the pooled tensor
@@ -356,6 +377,16 @@ int sqd_fire_bridge_fwd(const float* x, const float* u_packed, const float* bias
 int sqd_fire_pool_bridge_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
                              float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total, int Nsq,
                              int Hp, int Wp, int y_pitch, int y_coff, int nseg, void* stream);
+
+/* Training form of sqd_fire_pool_bridge_fwd (the forward of src/engine/trainer.py:42 through src/model/squeezedet.py:18-22, 47-52): the
+ * same launch ALSO stores the POOLED expand output -- save [B][Hp][Wp][save_pitch], expand1x1 at save_coff1, expand3x3 at save_coff3 --
+ * and the pool's arg-max / ReLU codes (codes: one byte per element of save's geometry; first window position 3 dy + dx holding the
+ * pooled value, 15 where it is not > 0: the codes of sqd_maxpool3x3s2_ceil_fwd_relu).  That is all the backward reads of this stage:
+ * the unpooled expand output is never written, the max pool and the next squeeze have no launches of their own. */
+int sqd_fire_pool_bridge_save_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                                  float* y, float* save, unsigned char* codes, int B, int H, int W, int C, int x_pitch, int x_coff,
+                                  int N3, int N1, int Npad_total, int Nsq, int Hp, int Wp, int y_pitch, int y_coff, int save_pitch,
+                                  int save_coff3, int save_coff1, int nseg, void* stream);
 
 /* clip_grad_norm_ + torch.optim.SGD(momentum, weight_decay).step() (src/engine/trainer.py:47-50) for every parameter tensor in ONE
  * launch.  descs_dev: n records of 4 int64 {param ptr, grad, momentum-buffer ptr, elements}, grad = element offset into grad_base (the

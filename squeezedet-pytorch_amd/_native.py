@@ -41,6 +41,7 @@ _SIGNATURES = {
     'sqd_stem_conv_fwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_stem_conv_relu_pool_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_stem_pool_squeeze_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    'sqd_stem_pool_squeeze_train_fwd': [c_p] * 8 + [c_i] * 6 + [c_p],
     'sqd_fire_squeeze_expand1x1_fwd': [c_p] * 7 + [c_i] * 15 + [c_p],
     'sqd_maxpool3x3s2_ceil_fwd': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_fwd_relu': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
@@ -69,6 +70,8 @@ _SIGNATURES = {
     'sqd_pack_wino_fire': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_fire_wino_fwd': [c_p] * 5 + [c_i] * 13 + [c_p],
     'sqd_fire_bridge_fwd': [c_p] * 6 + [c_i] * 13 + [c_p],
+    'sqd_fire_bridge_save_fwd': [c_p] * 7 + [c_i] * 15 + [c_p],
+    'sqd_gather_pack_batched': [c_p, c_i, c_i, c_p],
     'sqd_sgd_clip_step': [c_p, c_i, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p],
     'sqd_grad_sumsq': [c_p, ctypes.c_longlong, c_p, c_p],
     'sqd_grad_sumsq_parts': [],
@@ -76,6 +79,7 @@ _SIGNATURES = {
     'sqd_sgd_clip_step_chunked': [c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_p],
     'sqd_sgd_clip_step_parts': [c_p, c_i, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p],
     'sqd_fire_pool_bridge_fwd': [c_p] * 6 + [c_i] * 15 + [c_p],
+    'sqd_fire_pool_bridge_save_fwd': [c_p] * 8 + [c_i] * 18 + [c_p],
     'sqd_encode_gt_fwd': [c_p] * 8 + [c_i, c_i, c_i, c_i, c_p],
     'sqd_loss_fwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],
     'sqd_loss_bwd': [c_p] * 6 + [c_i] * 5 + [c_f] * 4 + [c_p],

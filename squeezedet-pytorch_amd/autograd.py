@@ -48,6 +48,11 @@ def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
             fsq = feats[3].squeeze
             stem_sq = ops.stem_pool_squeeze(image, stem.weight, stem.bias, fsq.weight, fsq.bias)
             a = None
+        elif (save and base.fuse_train_forward and base.fuse_stem_squeeze and nxt is not None and nxt[0] == 'fire'
+                and ops.stem_pool_squeeze_ok(image.shape, stem.weight.shape, nxt[2])):
+            # training: the same, but the pooled tensor and its codes are stored as well (the backward reads them)
+            fsq = feats[3].squeeze
+            stem_sq, a = ops.stem_pool_squeeze(image, stem.weight, stem.bias, fsq.weight, fsq.bias, argmax=am)
         else:
             stem_sq = None
             a = ops.stem_pool(image, stem.weight, stem.bias, argmax=am)
@@ -105,6 +110,17 @@ def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
                 zseg = ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix)
             if zseg is None and fusable and nxt is not None and nxt[0] == 'fire' and base.fuse_fire_bridge and base.use_winograd:
                 ycfg = ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix)
+            # training: the Fire -> Fire bridge in its storing form (the expand output the backward needs is written by the same launch)
+            ycfg_t = None
+            if (save and base.fuse_train_forward and nxt is not None and nxt[0] == 'fire' and base.fuse_fire_bridge and base.use_winograd
+                    and not ((drop_mask is not None or drop is not None) and i == len(layers) - 1)):
+                ycfg_t = ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix)
+                if ycfg_t is not None and ycfg_t % 1000 != 12:
+                    ycfg_t = None
+            zseg_t = None
+            if (save and base.fuse_train_forward and nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire'
+                    and base.fuse_fire_bridge and base.use_winograd):
+                zseg_t = ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix)
             if zseg is None and ycfg is None:
                 xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fusable and base.fuse_expand_wino and base.use_winograd) else None
                 fcfg = ops.choose_fused_cfg(s, e1, npix) if (fusable and xcfg is None and base.fuse_expand and e1 == e3) else None
@@ -121,7 +137,7 @@ def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
                     dr = None
             # squeeze + expand1x1 in ONE launch (the squeeze tile feeds the expand1x1 from registers; forward of inference AND training)
             # wherever the two would otherwise be separate plain launches
-            chain = (bridged is None and unpooled is None and zseg is None and ycfg is None and xcfg is None and fcfg is None and ym is None
+            chain = (bridged is None and unpooled is None and zseg is None and zseg_t is None and ycfg is None and ycfg_t is None and xcfg is None and fcfg is None and ym is None
                      and dr is None and base.fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1))
             out = None
             if bridged is not None:
@@ -154,6 +170,27 @@ def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
                     ops.fire_bridge(sq, 0, base.fire_bridge_plan(i, fire, feats[i + 1], ycfg), bridged, 0)
                     a = None
                     continue
+            if zseg_t is not None:
+                # training: expand pair + concat + max pool + the next squeeze in one launch; what the backward reads of this stage -- the
+                # pooled tensor (the next squeeze's input) and the pool's arg-max / ReLU codes -- is stored by it, the unpooled expand
+                # output is never written
+                Hp, Wp = ops.pool_out_size(H, W)
+                pooled = torch.empty(Bq, Hp, Wp, e1 + e3, device=sq.device, dtype=torch.float32)
+                am = torch.empty(Bq, Hp, Wp, e1 + e3, device=sq.device, dtype=torch.uint8)
+                bridged = torch.empty(Bq, Hp, Wp, nxt2[2], device=sq.device, dtype=torch.float32)
+                ops.fire_pool_bridge(sq, 0, base.fire_bridge_plan(i, fire, feats[i + 2], 12, pooled=True), bridged, 0, nseg=zseg_t,
+                                     save=pooled, codes=am, save_coff1=0, save_coff3=e1)
+                saved[f'fire{i}'] = (a, sq, torch.empty(Bq, H, W, e1 + e3, device='meta'))       # (only the shape of the expand output is read)
+                saved[f'pool{i + 1}'] = (am, (H, W))
+                a = pooled
+                continue
+            if ycfg_t is not None:
+                out = torch.empty(Bq, H, W, e1 + e3, device=sq.device, dtype=torch.float32)
+                bridged = torch.empty(Bq, H, W, nxt[2], device=sq.device, dtype=torch.float32)
+                ops.fire_bridge(sq, 0, base.fire_bridge_plan(i, fire, feats[i + 1], ycfg_t), bridged, 0, save=out, save_coff1=0, save_coff3=e1)
+                saved[f'fire{i}'] = (a, sq, out)
+                a = out
+                continue
             if out is None:
                 out = torch.empty(Bq, H, W, e1 + e3, device=sq.device, dtype=torch.float32)
             if chain:

@@ -82,6 +82,11 @@ struct WinoArgs {
   // ... through a 3x3 / stride-2 max pool (sqd_fire_pool_bridge_fwd, wino_poolbridge.h): pooled size, strips of 7 pooled
   // columns, segments of pb_gseg group rows (4 pixel rows each) out of pb_ng
   int pb_hp, pb_wp, pb_ns, pb_nseg, pb_gseg, pb_ng;
+  // training forms of the two bridges: the tensor the backward needs is stored as well.  Fire -> Fire: sv = the concatenated expand
+  // output (windows sv_coff = expand3x3, sv_coff1 = expand1x1).  Through the pool: sv = the POOLED expand output (same two windows)
+  // and sv_codes = the pool's arg-max / ReLU codes (one byte per pooled element, maxpool_fwd_kernel<true, true>'s codes).
+  float* sv; int sv_pitch, sv_coff, sv_coff1;
+  unsigned char* sv_codes;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w_t;
@@ -1042,6 +1047,36 @@ extern "C" int sqd_pack_wino_fire(const float* w3_oihw, const float* w1_oihw, fl
   return sqd_launch_status();
 }
 
+// Batched "scaled gather" re-pack: every operand of the Fire bridges besides the expand3x3 transform is a copy of a parameter element
+// (the squeeze weights as MFMA A operands, the bias tables) or +-0.25 times one (the expand1x1 weights at the four inner transform
+// positions), at a position that only depends on the layer's shape.  The host derives the index map once (plans.FireBridgePlan);
+// after an optimizer step ONE launch refreshes the operands of every bridge in place.  descs: n records of 7 int64 {dst, idx, count,
+// src0, src1, src2, src3}; idx[i]: -1 -> dst[i] = 0, -2 -> dst[i] left alone, else bits 0..25 = element of source (bits 26..27),
+// bits 28..29 = scale (0: 1, 1: +0.25, 2: -0.25).
+struct GatherPackDesc { float* dst; const int* idx; long long n; const float* src[4]; };
+
+__global__ __launch_bounds__(256) void gather_pack_batched_kernel(const GatherPackDesc* __restrict__ descs) {
+  const GatherPackDesc d = descs[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (long long)gridDim.x * blockDim.x) {
+    const int code = d.idx[i];
+    if (code == -2) continue;
+    float v = 0.f;
+    if (code >= 0) {
+      const int sc = (code >> 28) & 3;
+      v = d.src[(code >> 26) & 3][code & 0x3ffffff];
+      v = sc == 1 ? 0.25f * v : (sc == 2 ? -0.25f * v : v);
+    }
+    d.dst[i] = v;
+  }
+}
+
+extern "C" int sqd_gather_pack_batched(const void* descs_dev, int n, int blocks_per_desc, void* stream) {
+  SQD_CHECK_ARG(descs_dev && n > 0 && n <= 65535 && blocks_per_desc > 0 && blocks_per_desc <= 4096);
+  hipLaunchKernelGGL(gather_pack_batched_kernel, dim3((unsigned)blocks_per_desc, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     (const GatherPackDesc*)descs_dev);
+  return sqd_launch_status();
+}
+
 // Winograd configurations: cfg_id -> (channel blocks per slice NT, waves per workgroup WV)
 struct WinoCfg { int nt, wv; };
 // ids 4..7: the same tilings on the deep-prefetch kernel (conv_wino_pipe_kernel); 8..11: its U-stationary, barrier-free
@@ -1166,13 +1201,43 @@ extern "C" int sqd_fire_bridge_fwd(const float* x, const float* u_packed, const 
   return SQD_ERR_UNSUPPORTED;
 }
 
+// Training form of sqd_fire_bridge_fwd (cfg 12 only: C <= 16): additionally stores the concatenated expand output -- `save`
+// [B][H][W][save_pitch], expand1x1 at save_coff1, expand3x3 at save_coff3 -- which the backward reads (input of the next squeeze's
+// weight gradient, ReLU masks).  The next Fire's squeeze then has no launch of its own and the 128-channel tensor is not read back.
+extern "C" int sqd_fire_bridge_save_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                                        float* y, float* save, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1,
+                                        int Npad_total, int Nsq, int y_pitch, int y_coff, int save_pitch, int save_coff3, int save_coff1,
+                                        void* stream) {
+  SQD_CHECK_ARG(x && u_packed && bias_tab && sq_ops && y && save && B > 0 && H > 0 && W > 0 && C > 0 && N3 > 0 && N1 > 0 && Nsq > 0);
+  SQD_CHECK_ARG(C % 8 == 0 && C <= 16 && N3 % 4 == 0 && N1 % 16 == 0 && Nsq % 4 == 0 && Nsq <= 32);
+  SQD_CHECK_ARG(x_pitch % 4 == 0 && x_coff % 4 == 0 && y_pitch % 4 == 0 && y_coff % 4 == 0);
+  SQD_CHECK_ARG(save_pitch % 4 == 0 && save_coff3 % 4 == 0 && save_coff1 % 4 == 0);
+  SQD_CHECK_ARG(x_coff >= 0 && x_coff + C <= x_pitch && y_coff >= 0 && y_coff + Nsq <= y_pitch);
+  SQD_CHECK_ARG(save_coff3 >= 0 && save_coff3 + N3 <= save_pitch && save_coff1 >= 0 && save_coff1 + N1 <= save_pitch);
+  SQD_CHECK_ARG(save_coff3 + N3 <= save_coff1 || save_coff1 + N1 <= save_coff3);
+  SQD_CHECK_ARG(Npad_total == sqd_cdiv(N3, 32) * 32 + sqd_cdiv(N1, 128) * 32);
+  const int widest = x_pitch > y_pitch ? (x_pitch > save_pitch ? x_pitch : save_pitch) : (y_pitch > save_pitch ? y_pitch : save_pitch);
+  SQD_CHECK_ARG((long long)W * 6 * widest * 4 < (1ll << 30));
+  SQD_CHECK_ARG((long long)B * H * W * x_pitch * 4 < (1ll << 32) - (1ll << 30));
+  SQD_CHECK_ARG((long long)(C >> 3) * 16 * Npad_total * 8 * 4 < (1ll << 32));
+  WinoArgs a{};
+  a.x = x; a.u = u_packed; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
+  a.N = N3; a.Npad = Npad_total; a.y_pitch = y_pitch; a.y_coff = y_coff; a.relu = 1;
+  a.N1 = N1; a.nslices3 = sqd_cdiv(N3, 32);
+  a.br_w = sq_ops; a.br_bias = bias_tab; a.br_sqb = sq_bias; a.br_nsq = Nsq;
+  a.sv = save; a.sv_pitch = save_pitch; a.sv_coff = save_coff3; a.sv_coff1 = save_coff1;
+  hipStream_t s = (hipStream_t)stream;
+  return Nsq <= 16 ? launch_wino_bridge16<1, 2>(a, s) : launch_wino_bridge16<2, 2>(a, s);
+}
+
 // Fire k's expand pair + torch.cat + MaxPool2d(3, 2, ceil_mode=True) + Fire k+1's squeeze (src/model/squeezedet.py:18-22, 47-52) in
 // ONE launch: y [B][Hp][Wp][y_pitch] window [y_coff, +Nsq) = ReLU(Wsq . maxpool(cat(ReLU(conv1x1(x) + b1), ReLU(conv3x3(x) + b3))) + bsq).
 // Operands as for sqd_fire_bridge_fwd cfg 12 (16-wide passes) except that an expand1x1 pass contributes two channel blocks
 // (N1 <= 64, N3 <= 64, C <= 16, Nsq <= 32).  Hp x Wp must be the pool's output size for H x W.  nseg: segments a column
 // strip is cut into (parallelism vs. one recomputed group row per segment).
-extern "C" int sqd_fire_pool_bridge_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
-                                        float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total,
+static int fire_pool_bridge_impl(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                                 float* y, float* save, unsigned char* codes, int save_pitch, int save_coff3, int save_coff1, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total,
                                         int Nsq, int Hp, int Wp, int y_pitch, int y_coff, int nseg, void* stream) {
   SQD_CHECK_ARG(x && u_packed && bias_tab && sq_ops && y && B > 0 && H >= 3 && W >= 3 && C > 0 && N3 > 0 && N1 > 0 && Nsq > 0);
   SQD_CHECK_ARG(C % 8 == 0 && N3 % 4 == 0 && N1 % 16 == 0 && Nsq % 4 == 0 && Nsq <= 32);
@@ -1195,5 +1260,35 @@ extern "C" int sqd_fire_pool_bridge_fwd(const float* x, const float* u_packed, c
   a.br_w = sq_ops; a.br_bias = bias_tab; a.br_sqb = sq_bias; a.br_nsq = Nsq;
   a.pb_hp = Hp; a.pb_wp = Wp;
   hipStream_t s = (hipStream_t)stream;
+  if (save || codes) {
+    SQD_CHECK_ARG(save && codes && ((uintptr_t)codes & 3) == 0);
+    SQD_CHECK_ARG(save_pitch % 4 == 0 && save_coff3 % 4 == 0 && save_coff1 % 4 == 0);
+    SQD_CHECK_ARG(save_coff3 >= 0 && save_coff3 + N3 <= save_pitch && save_coff1 >= 0 && save_coff1 + N1 <= save_pitch);
+    SQD_CHECK_ARG(save_coff3 + N3 <= save_coff1 || save_coff1 + N1 <= save_coff3);
+    SQD_CHECK_ARG((long long)(Wp + 8) * 2 * save_pitch * 4 < (1ll << 30));
+    SQD_CHECK_ARG((long long)B * (Hp + 2) * Wp * save_pitch * 4 < (1ll << 32) - (1ll << 30));
+    a.sv = save; a.sv_codes = codes; a.sv_pitch = save_pitch; a.sv_coff = save_coff3; a.sv_coff1 = save_coff1;
+    return Nsq <= 16 ? launch_wino_poolbridge16<1, true>(a, nseg, s) : launch_wino_poolbridge16<2, true>(a, nseg, s);
+  }
   return Nsq <= 16 ? launch_wino_poolbridge16<1>(a, nseg, s) : launch_wino_poolbridge16<2>(a, nseg, s);
+}
+
+extern "C" int sqd_fire_pool_bridge_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops, const float* sq_bias,
+                                        float* y, int B, int H, int W, int C, int x_pitch, int x_coff, int N3, int N1, int Npad_total,
+                                        int Nsq, int Hp, int Wp, int y_pitch, int y_coff, int nseg, void* stream) {
+  return fire_pool_bridge_impl(x, u_packed, bias_tab, sq_ops, sq_bias, y, nullptr, nullptr, 0, 0, 0, B, H, W, C, x_pitch, x_coff, N3, N1,
+                               Npad_total, Nsq, Hp, Wp, y_pitch, y_coff, nseg, stream);
+}
+
+// Training form: additionally stores the POOLED expand output (save [B][Hp][Wp][save_pitch], expand1x1 at save_coff1, expand3x3 at
+// save_coff3) and the pool's arg-max / ReLU codes (codes: one byte per element of the same geometry, first window position 3 dy + dx
+// holding the pooled value, 15 where it is not > 0) -- everything the backward reads of this stage; the unpooled expand output, the
+// max-pool launch and the next squeeze's launch are gone.
+extern "C" int sqd_fire_pool_bridge_save_fwd(const float* x, const float* u_packed, const float* bias_tab, const float* sq_ops,
+                                             const float* sq_bias, float* y, float* save, unsigned char* codes, int B, int H, int W, int C,
+                                             int x_pitch, int x_coff, int N3, int N1, int Npad_total, int Nsq, int Hp, int Wp, int y_pitch,
+                                             int y_coff, int save_pitch, int save_coff3, int save_coff1, int nseg, void* stream) {
+  SQD_CHECK_ARG(save && codes);
+  return fire_pool_bridge_impl(x, u_packed, bias_tab, sq_ops, sq_bias, y, save, codes, save_pitch, save_coff3, save_coff1, B, H, W, C, x_pitch,
+                               x_coff, N3, N1, Npad_total, Nsq, Hp, Wp, y_pitch, y_coff, nseg, stream);
 }

@@ -538,6 +538,7 @@ static int launch_stem_pool(StemPoolArgs a, hipStream_t s) {
 struct StemWaveArgs {
   const float* x; const float* w; const float* bias; float* y; uint8_t* amax;
   const float* wsq; const float* bsq;       // SQ variant: the next Fire's squeeze (1x1, 64 -> SQ channels, OIHW + bias); y is ITS output
+  float* ysq;                               // ARGMAX + SQ (training): y and amax as without SQ, the squeeze output goes HERE
   int B, Hin, Win, Ho, Wo, Hp, Wp;
   int tiles_x, tiles_y, ntiles;
   unsigned tiles_x_m, tiles_y_m;
@@ -560,6 +561,8 @@ struct StemWaveArgs {
 // channel 16j + 4g + t, so the squeeze is 16 MFMAs per pooled row against squeeze weights pre-arranged as A operands in LDS
 // (sqA[j][lane] = W[n = lane & 15][16j + 4 (lane >> 4) + 0..3]) -- the Fire bridges' trick (wino_bridge.h).  The 153 MB pooled tensor is
 // neither written nor read back by a separate squeeze launch.
+// ARGMAX and SQ together (training forward): the pooled tensor and its codes are stored as in the ARGMAX form (the backward needs them)
+// and the squeeze output goes to a.ysq; the squeeze launch that would re-read the 153 MB pooled tensor is gone.
 template <int PH, int CB, bool ARGMAX = false, int SQ = 0>
 __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -568,10 +571,10 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
   constexpr int NSLOT = 3 * IH * SL, N_IT = (NSLOT + 63) / 64, BUFF = N_IT * 64 * 4; // floats per buffer
   constexpr int K = 27, KSTEPS = 7, NT = 4, N = 64;
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int NST = SQ ? PH : PH * NT * (ARGMAX ? 2 : 1);                          // stores per tile (always issued)
+  constexpr int NST = ARGMAX ? PH * NT * 2 + (SQ ? PH : 0) : (SQ ? PH : PH * NT);    // stores per tile (always issued)
   static_assert(!ARGMAX || CB == 2, "the arg-max epilogue is written for the parity-split layout");
-  static_assert(SQ == 0 || (SQ == 16 && CB == 2 && !ARGMAX), "fused squeeze: 16 channels, parity-split layout, inference");
-  constexpr int NO = SQ ? SQ : N;                                                    // channels per pixel of the tensor this kernel writes
+  static_assert(SQ == 0 || (SQ == 16 && CB == 2), "fused squeeze: 16 channels, parity-split layout");
+  constexpr int NO = (SQ && !ARGMAX) ? SQ : N;                                       // channels per pixel of the tensor behind a.y
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
   // the patch origin (input row 4 PH ty - 1, column 4 PW tx - 4) is never negative relative to this base
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - (a.Win + 4)), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc((void*)((ARGMAX && SQ) ? a.ysq : a.y), 0, 0x7ffffff0, 0x00020000);
   // codes: one byte per element; idle lanes carry 2^29 (a quarter of the fp32 streams' idle offset), past this resource's range
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(ARGMAX ? (void*)a.amax : (void*)a.y), 0,
                                                                         ARGMAX ? a.B * a.Hp * a.Wp * N : 0x7ffffff0, 0x00020000);
@@ -629,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
   const bool out_lane = CB == 1 ? ((c & 1) == 0 && c < 2 * PW) : (c < PW);
   const int pcol = CB == 1 ? (c >> 1) : c;
   const int o_voff = out_lane ? (pcol * NO + 4 * g) * 4 : (int)OOB;
+  const int q_voff = out_lane ? (pcol * SQ + 4 * g) * 4 : (int)OOB;      // (ARGMAX + SQ) the lane's slot in a row of the squeeze output
 
   struct Tile { int ty, tx, inner; unsigned soff, osoff; };
   auto tile_at = [&](int t) {
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
     // ---- conv positions outside the feature map are -inf for the pool (border tiles only) ----
     const int cy0 = 2 * PH * cur.ty, cx0 = 2 * PW * cur.tx;
     const int py0 = PH * cur.ty, px0 = PW * cur.tx;
-    int voff = o_voff;
+    int voff = o_voff, qvoff = q_voff;
     if (!(cy0 + CH <= a.Ho && cx0 + 16 * CB <= a.Wo && px0 + PW <= a.Wp)) {      // uniform
       const float ninf = -__builtin_inff();
 #pragma unroll
@@ -723,6 +728,7 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
         }
       }
       voff = (out_lane && px0 + pcol < a.Wp) ? o_voff : (int)OOB;
+      qvoff = (out_lane && px0 + pcol < a.Wp) ? q_voff : (int)OOB;
     }
     // ---- pool in registers, bias + ReLU behind it, stores (always issued: rows / lanes without a pixel go out of range) ----
     if constexpr (ARGMAX) {
@@ -781,6 +787,11 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
           }
           asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
                        : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w));
+          if constexpr (SQ > 0) {
+            const f32x4 aw = *(const f32x4*)(sqA + (j * 64 + lane) * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sacc = mfma16(aw[t], h[t], sacc);
+          }
           store16(h, vrow + j * 64, soff);
           // (vrow >> 2: byte offset of the lane's four codes; an idle lane's 2^31 becomes 2^29, past the code resource's range)
           __builtin_amdgcn_raw_buffer_store_b32(codes, ares, (int)((unsigned)vrow >> 2) + j * 16, (int)((unsigned)soff >> 2), 0);
@@ -828,7 +839,16 @@ __global__ __launch_bounds__(256, 2) void stem_wave_kernel(StemWaveArgs a) {
         sacc += *(const f32x4*)(sqA + 1024 + 4 * g);
         asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
                      : "+v"(sacc.x), "+v"(sacc.y), "+v"(sacc.z), "+v"(sacc.w));
-        store16(sacc, vrow, soff);
+        if constexpr (ARGMAX) {
+          // the squeeze output is [B][Hp][Wp][SQ]: a quarter of the pooled tensor's offsets (N = 4 SQ)
+          const int qrow = (py0 + i < a.Hp) ? qvoff : (int)OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, sacc), qres, qrow, (int)((unsigned)soff >> 2), 0);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          store16(sacc, vrow, soff);
+        }
       }
     }
     if (!has_next) break;
@@ -892,7 +912,7 @@ extern "C" int sqd_stem_conv_relu_pool_fwd(const float* x, const float* w, const
   if (ksize == 3 && N == 64 && variant && (Win & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
       (long long)B * 3 * Hin * Win * 4 < (1ll << 31) && (long long)B * a.Hp * a.Wp * N * 4 < (1ll << 31)) {
     StemWaveArgs wa;
-    wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.amax = argmax; wa.wsq = nullptr; wa.bsq = nullptr; wa.B = B; wa.Hin = Hin; wa.Win = Win; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Hp = a.Hp; wa.Wp = a.Wp;
+    wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.amax = argmax; wa.wsq = nullptr; wa.bsq = nullptr; wa.ysq = nullptr; wa.B = B; wa.Hin = Hin; wa.Win = Win; wa.Ho = a.Ho; wa.Wo = a.Wo; wa.Hp = a.Hp; wa.Wp = a.Wp;
     // training forward: one pooled row per tile -- with two (variant 5) the arg-max epilogue's temporaries spill 42 registers, and
     // every reload queues behind the next patch's DMA in vmcnt order
     if (argmax) return variant == 5 ? launch_stem_wave<2, 2, true>(wa, s) : launch_stem_wave<1, 2, true>(wa, s);
@@ -912,12 +932,32 @@ extern "C" int sqd_stem_pool_squeeze_fwd(const float* x, const float* w, const f
   SQD_CHECK_ARG(((uintptr_t)y & 15) == 0 && ((uintptr_t)wsq & 15) == 0);
   if (!(ksize == 3 && N == 64 && nsq == 16 && (Win & 3) == 0 && ((uintptr_t)x & 15) == 0)) return SQD_ERR_UNSUPPORTED;
   StemWaveArgs wa;
-  wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.amax = nullptr; wa.wsq = wsq; wa.bsq = bsq; wa.B = B; wa.Hin = Hin; wa.Win = Win;
+  wa.x = x; wa.w = w; wa.bias = bias; wa.y = y; wa.amax = nullptr; wa.wsq = wsq; wa.bsq = bsq; wa.ysq = nullptr; wa.B = B; wa.Hin = Hin; wa.Win = Win;
   wa.Ho = (Hin + 2 - 3) / 2 + 1; wa.Wo = (Win + 2 - 3) / 2 + 1;
   SQD_CHECK_ARG(wa.Ho >= 3 && wa.Wo >= 3);
   wa.Hp = (wa.Ho - 3 + 1) / 2 + 1; wa.Wp = (wa.Wo - 3 + 1) / 2 + 1;
   if ((long long)B * 3 * Hin * Win * 4 >= (1ll << 31) || (long long)B * wa.Hp * wa.Wp * N * 4 >= (1ll << 31)) return SQD_ERR_UNSUPPORTED;
   return launch_stem_wave<2, 2, false, 16>(wa, (hipStream_t)stream);
+}
+
+// Training form of sqd_stem_pool_squeeze_fwd: the pooled tensor y_pooled [B,Hp,Wp,64] and its arg-max / ReLU codes (argmax, one byte
+// per element) are stored exactly as by sqd_stem_conv_relu_pool_fwd(argmax != NULL) -- the backward reads both -- and the first
+// Fire's squeeze output y_sq [B,Hp,Wp,16] comes out of the same launch.  Same shape limits; SQD_ERR_UNSUPPORTED otherwise.
+extern "C" int sqd_stem_pool_squeeze_train_fwd(const float* x, const float* w, const float* bias, const float* wsq, const float* bsq,
+                                               float* y_pooled, unsigned char* argmax, float* y_sq, int B, int Hin, int Win, int N,
+                                               int ksize, int nsq, void* stream) {
+  SQD_CHECK_ARG(x && w && wsq && y_pooled && argmax && y_sq && B > 0 && Hin > 0 && Win > 0);
+  SQD_CHECK_ARG(((uintptr_t)y_pooled & 15) == 0 && ((uintptr_t)y_sq & 15) == 0 && ((uintptr_t)wsq & 15) == 0 && ((uintptr_t)argmax & 3) == 0);
+  SQD_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0);
+  if (!(ksize == 3 && N == 64 && nsq == 16 && (Win & 3) == 0 && ((uintptr_t)x & 15) == 0)) return SQD_ERR_UNSUPPORTED;
+  StemWaveArgs wa;
+  wa.x = x; wa.w = w; wa.bias = bias; wa.y = y_pooled; wa.amax = argmax; wa.wsq = wsq; wa.bsq = bsq; wa.ysq = y_sq;
+  wa.B = B; wa.Hin = Hin; wa.Win = Win;
+  wa.Ho = (Hin + 2 - 3) / 2 + 1; wa.Wo = (Win + 2 - 3) / 2 + 1;
+  SQD_CHECK_ARG(wa.Ho >= 3 && wa.Wo >= 3);
+  wa.Hp = (wa.Ho - 3 + 1) / 2 + 1; wa.Wp = (wa.Wo - 3 + 1) / 2 + 1;
+  if ((long long)B * 3 * Hin * Win * 4 >= (1ll << 31) || (long long)B * wa.Hp * wa.Wp * N * 4 >= (1ll << 31)) return SQD_ERR_UNSUPPORTED;
+  return launch_stem_wave<1, 2, true, 16>(wa, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -421,8 +421,12 @@ static int launch_wino_bridge(WinoArgs a, hipStream_t stream) {
 // are stored to their window of the concatenated output instead of entering a squeeze.
 // NCH = C / 8 (1 or 2) is a template parameter and the (at most 4 + 2) channel passes are enumerated statically: with run-time
 // trip counts the compiler rotated the 64 transform registers and the accumulators through ~200 copies per group.
-template <int NSQ, bool SQZ, int NCH>
+// MODE 0: plain fused expand (stores only); 1: bridge (the expand output only enters the squeeze); 2: training bridge -- the expand
+// output is ALSO stored (a.sv: the tensor the backward reads as the next squeeze's input and for the ReLU masks), so the next
+// squeeze needs no launch of its own and does not re-read it.
+template <int NSQ, int MODE, int NCH>
 __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
+  constexpr bool SQZ = MODE != 0, STO = MODE != 1;
   constexpr int WV = 8, NTHR = WV * 64, RP = 113, RAW_IT = 4, NSTB = 4 * NSQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int P3 = a.nslices3, P = a.nslices;            // 16-wide passes: expand3x3, then expand1x1
@@ -537,7 +541,14 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
 #pragma unroll
   for (int px = 0; px < 4; ++px) o_offB[px] = (((2 * ty + (px >> 1)) * a.W + 2 * tx + (px & 1)) * a.y_pitch + 4 * g) * 4;
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff), 0, 0x7ffffff0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t yres1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + a.y_coff1), 0, 0x7ffffff0, 0x00020000);
+  // where the expand channels are stored (MODE 0: the output itself; MODE 2: the saved tensor beside the squeeze output)
+  float* const sto = MODE == 2 ? a.sv : a.y;
+  const int sto_pitch = MODE == 2 ? a.sv_pitch : a.y_pitch;
+  const __amdgpu_buffer_rsrc_t sres3 = __builtin_amdgcn_make_buffer_rsrc((void*)(sto + (MODE == 2 ? a.sv_coff : a.y_coff)), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sres1 = __builtin_amdgcn_make_buffer_rsrc((void*)(sto + (MODE == 2 ? a.sv_coff1 : a.y_coff1)), 0, 0x7ffffff0, 0x00020000);
+  int s_offB[4];
+#pragma unroll
+  for (int px = 0; px < 4; ++px) s_offB[px] = (((2 * ty + (px >> 1)) * a.W + 2 * tx + (px & 1)) * sto_pitch + 4 * g) * 4;
   // plain fused expand: store instructions of a whole group with every channel block present
   const int nst_full = ((a.N & 15) == 0 && (a.N1 & 31) == 0) ? 4 * ((a.N >> 4) + (a.N1 >> 4)) : -1;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -556,9 +567,11 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
     // the group's patch has landed (only a finished group's stores are younger)
     {
       const int sb = __builtin_amdgcn_readfirstlane(stores_behind);
-      if (SQZ && sb == NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTB) : "memory");
-      else if (!SQZ && sb == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      else if (!SQZ && sb >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (MODE == 1 && sb == NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTB) : "memory");
+      else if (MODE == 2 && sb == 32 + NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(32 + NSTB) : "memory");
+      else if (MODE == 2 && sb >= 16 + NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + NSTB) : "memory");
+      else if (MODE == 0 && sb == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (MODE == 0 && sb >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("" ::: "memory");
@@ -588,15 +601,15 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
     const GPos nxt = group_pos(ntile);
     dma_group(nxt);
 
-    const int ysoff_g = (int)(unsigned)(cur.p0 * a.y_pitch * 4);
+    const int ysoff_g = (int)(unsigned)(cur.p0 * sto_pitch * 4);
     const bool wholexy = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W;
-    // SQZ = false: channels [c0 + 4 g, +4) of window `res` for the tile's four pixels
+    // STO: channels [c0 + 4 g, +4) of window `res` for the tile's four pixels
     auto store_out = [&](__amdgpu_buffer_rsrc_t res, int c0, int nlim, const f32x4 (&ov)[4]) {
       if (!cur.valid || c0 + 4 * g >= nlim) return;
 #pragma unroll
       for (int px = 0; px < 4; ++px) {
         if (!wholexy && !(cur.y0 + 2 * ty + (px >> 1) < a.H && cur.x0 + 2 * tx + (px & 1) < a.W)) continue;
-        store16(ov[px], res, o_offB[px] + c0 * 4, ysoff_g);
+        store16(ov[px], res, s_offB[px] + c0 * 4, ysoff_g);
       }
     };
     auto squeeze_in = [&](int bi, const f32x4 (&ov)[4]) {
@@ -672,8 +685,8 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
             inv1([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
 #pragma unroll
             for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
+            if constexpr (STO) { const int s1 = pass - P3; store_out(sres1, 128 * (s1 >> 1) + (2 * r + (s1 & 1)) * 16, a.N1, ov); }
             if constexpr (SQZ) squeeze_in(bi0 + r, ov);
-            else { const int s1 = pass - P3; store_out(yres1, 128 * (s1 >> 1) + (2 * r + (s1 & 1)) * 16, a.N1, ov); }
           }
         } else {
           auto inv = [&](auto half, auto put) {
@@ -696,8 +709,8 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
           inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
 #pragma unroll
           for (int px = 0; px < 4; ++px) ov[px] = wino_relu4(ov[px], 0.f);
+          if constexpr (STO) store_out(sres3, pass * 16, a.N, ov);
           if constexpr (SQZ) squeeze_in(pass, ov);
-          else store_out(yres, pass * 16, a.N, ov);
         }
       };
       // (host-checked: at most 4 expand3x3 and 2 expand1x1 passes)
@@ -713,7 +726,9 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
         if (P > P3 + 1) run_pass(std::integral_constant<int, 1>{}, P3 + 1);
       }
     }
-    if constexpr (!SQZ) stores_behind = (cur.valid && wholexy && nst_full > 0) ? nst_full : 0;
+    int sto_behind = 0;
+    if constexpr (STO) sto_behind = (cur.valid && wholexy && nst_full > 0) ? nst_full : 0;
+    if constexpr (MODE == 0) stores_behind = sto_behind;
     // ---- the group's squeeze output: ReLU + store; the accumulators restart from the bias ----
     if (SQZ && cur.valid) {
       const int ysoff = (int)(unsigned)(cur.p0 * a.y_pitch * 4);
@@ -727,7 +742,8 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
           store16(wino_relu4(acc_sq[px][q], 0.f), yres, o_offB[px] + q * 64, ysoff);
         }
       }
-      stores_behind = whole ? NSTB : 0;
+      // (MODE 2: the counted wait needs BOTH store runs at their full count)
+      stores_behind = whole ? (MODE == 2 ? (sto_behind > 0 ? sto_behind + NSTB : 0) : NSTB) : 0;
     }
 #pragma unroll
     for (int px = 0; px < 4; ++px)
@@ -740,16 +756,17 @@ __device__ __forceinline__ void wino_bridge16_body(const WinoArgs& a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSQ, bool SQZ, int NCH>
+template <int NSQ, int MODE, int NCH>
 __global__ __launch_bounds__(512, 1) void fire_bridge16_kernel(WinoArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  wino_bridge16_body<NSQ, SQZ, NCH>(a);
+  wino_bridge16_body<NSQ, MODE, NCH>(a);
 #endif
 }
 
 // bias table / squeeze operand blocks of this form: 16-wide passes (see sqd_fire_bridge_fwd)
-template <int NSQ, bool SQZ, int NCH>
+template <int NSQ, int MODE, int NCH>
 static int launch_wino_bridge16_t(WinoArgs a, hipStream_t stream) {
+  constexpr bool SQZ = MODE != 0;
   constexpr int WV = 8, NTHR = WV * 64;
   const int nchunks = a.C >> 3;
   if (nchunks != NCH) return SQD_ERR_UNSUPPORTED;
@@ -763,8 +780,9 @@ static int launch_wino_bridge16_t(WinoArgs a, hipStream_t stream) {
   const size_t lds = (size_t)(2 * WV * 256 * 4 + first1 * nchunks * 2048 + P1 * nchunks * e1_stage + nblk * 4 * NSQ * 64 + (first1 + P1) * 64) * sizeof(float);
   (void)P3;
   if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
-  auto kern = fire_bridge16_kernel<NSQ, SQZ, NCH>;
+  auto kern = fire_bridge16_kernel<NSQ, MODE, NCH>;
   if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
+  if (MODE == 2 && (!a.sv || (long long)a.B * a.H * a.W * a.sv_pitch * 4 >= (1ll << 32) - (1ll << 30))) return SQD_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
@@ -783,9 +801,9 @@ static int launch_wino_bridge16_t(WinoArgs a, hipStream_t stream) {
   return sqd_launch_status();
 }
 
-template <int NSQ, bool SQZ = true>
+template <int NSQ, int MODE = 1>
 static int launch_wino_bridge16(WinoArgs a, hipStream_t stream) {
-  if ((a.C >> 3) == 1) return launch_wino_bridge16_t<NSQ, SQZ, 1>(a, stream);
-  if ((a.C >> 3) == 2) return launch_wino_bridge16_t<NSQ, SQZ, 2>(a, stream);
+  if ((a.C >> 3) == 1) return launch_wino_bridge16_t<NSQ, MODE, 1>(a, stream);
+  if ((a.C >> 3) == 2) return launch_wino_bridge16_t<NSQ, MODE, 2>(a, stream);
   return SQD_ERR_UNSUPPORTED;
 }

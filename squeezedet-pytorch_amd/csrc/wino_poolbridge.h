@@ -18,7 +18,15 @@
 //   * the expand ReLU runs behind the pool (it commutes with max), which also makes 0 the neutral element everywhere (DPP
 //     shifts with zero fill, pixels outside the map);
 //   * the pooled values leave the max in exactly the lane layout the squeeze product wants (lane = pooled pixel, 4 channels).
-template <int NSQ, int NCH>
+// SAVE (training forward): the pooled tensor (a.sv: expand1x1 window at sv_coff1, expand3x3 at sv_coff) and the pool's arg-max /
+// ReLU codes (a.sv_codes, one byte per pooled element: the FIRST window position 3 dy + dx holding the pooled value, 15 where it is
+// not > 0 -- maxpool_fwd_kernel<true, true>'s codes) are stored as well: they are all the backward reads of this stage (the
+// unpooled expand output is not needed: the codes carry its ReLU mask).  The code of a pooled element is assembled the way its
+// value is: first position among the tile's own four pixels and the right neighbour's left column holding THEIR maximum (compares
+// against that partial maximum), first among the row below (+ its right neighbour's corner), then whichever side holds the window
+// maximum, the upper side on ties (its positions come first).  The partial code of the group's second tile row is carried with its
+// partial maximum (four codes packed in one register per channel block).
+template <int NSQ, int NCH, bool SAVE = false>
 __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
   constexpr int WV = 8, NTHR = WV * 64, RP = 113, RAW_IT = 4, RSLOTS = 224;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -59,6 +67,11 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
   // output rows are addressed from one pooled row ABOVE the group's first (the carried row), so every lane offset is >= 0
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.y + a.y_coff - (long long)a.pb_wp * a.y_pitch), 0, 0x7ffffff0, 0x00020000);
+  // (SAVE) the pooled tensor and its codes, addressed the same way; the codes are one byte per element of the same geometry
+  const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((SAVE ? a.sv : a.y) - (SAVE ? (long long)a.pb_wp * a.sv_pitch : 0)), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t cres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(SAVE ? (void*)(a.sv_codes - (long long)a.pb_wp * a.sv_pitch) : (void*)a.y), 0, 0x7ffffff0, 0x00020000);
 
   // ---- operands into LDS, once ----
   {
@@ -116,12 +129,16 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
   f32x4 acc[16];
   f32x4 acc_sq[NSQ];
   f32x4 carry[8];                                      // partial pooled maxima of the group's second tile row, per channel block
+  unsigned carry_code[SAVE ? 8 : 1];                   // (SAVE) ... and the window positions holding them, four bytes per block
 #pragma unroll
   for (int k = 0; k < 8; ++k) carry[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < (SAVE ? 8 : 1); ++k) carry_code[k] = 0u;
   const float oneB = (g == 0) ? 1.f : 0.f;
   const int ty = lr >> 3, tx = lr & 7;
   // this lane's pooled pixel: row (2 r - 1) + (1 - ty) ... i.e. ty = 0 -> pooled row 2 r, ty = 1 -> the carried row 2 r - 1
   const int o_off = (((1 - ty) * a.pb_wp + tx) * a.y_pitch + 4 * g) * 4;
+  const int p_off = SAVE ? (((1 - ty) * a.pb_wp + tx) * a.sv_pitch + 4 * g) * 4 : 0;       // pooled tensor (bytes); codes: a quarter
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   const int rawL_off = (((g >> 1) * RP + (2 * (lr >> 3)) * 18 + 2 * (lr & 7)) * 4 + 2 * (g & 1));
   const int u_ln = g * 64 + lr * 4;
@@ -160,7 +177,8 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
       more = ntask < ntasks;
       if (more) { task_of(ntask, nb, ns, ng0, ng1); nr = ng0; } else { nr = r; }
     }
-    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSQ) : "memory");
+    // (SAVE: two more stores per channel block; the count is exact for the eight-block shape, anything else waits for everything)
+    if (stored && (!SAVE || nblk == 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSQ + (SAVE ? 16 : 0)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::: "memory");
     // ---- input transform of the whole group (both chunks) ----
@@ -189,8 +207,11 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
 #pragma unroll
     for (int q = 0; q < NSQ; ++q) acc_sq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool wholexy = cur.y0 + 4 <= a.H && cur.x0 + 16 <= a.W;
+    // the pooled pixel this lane finishes in this iteration (see the squeeze store below) and where it goes in the saved tensors
+    const bool emit_px = tx < 7 && 7 * ts + tx < a.pb_wp && 2 * r - ty < a.pb_hp && (ty ? (r > g0) : (r < g1));
+    const unsigned psoff = SAVE ? (unsigned)((((long long)tb * a.pb_hp + 2 * r) * a.pb_wp + 7 * ts) * a.sv_pitch * 4) : 0u;
     // one 16-channel block of the expand output for the tile's four pixels -> pooled -> into the squeeze
-    auto pool_in = [&](int bi, auto kslot_c, f32x4 (&ov)[4]) {
+    auto pool_in = [&](int bi, auto kslot_c, f32x4 (&ov)[4], int cbase, int climit) {
       constexpr int KS = decltype(kslot_c)::value;
       if (!wholexy) {
 #pragma unroll
@@ -234,7 +255,45 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
                    : "v"(Bt.x), "v"(Bt.y), "v"(Bt.z), "v"(Bt.w), "v"(base.x), "v"(base.y), "v"(base.z), "v"(base.w));
       // the expand ReLU is applied HERE, behind the pool (relu o max == max o relu; zero fills and masked pixels are neutral
       // under it): 4 instead of 16 maxima per channel block
-      pooled = wino_relu4(pooled, 0.f);
+      if constexpr (SAVE) {
+        unsigned codes = 0u, cApack = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float o0 = ov[0][e], o1 = ov[1][e], o2 = ov[2][e], o3 = ov[3][e];
+          float r0;                                            // the right neighbour's top-left pixel (position 2; its lower-left is position 5)
+          asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(r0) : "v"(o0));
+          const float Av = A[e], Bv = Bt[e];
+          unsigned cA = 5u;
+          cA = (o3 == Av) ? 4u : cA; cA = (o2 == Av) ? 3u : cA; cA = (r0 == Av) ? 2u : cA; cA = (o1 == Av) ? 1u : cA; cA = (o0 == Av) ? 0u : cA;
+          const unsigned cB = (o0 == Bv) ? 6u : ((o1 == Bv) ? 7u : 8u);
+          // the row neighbour's cB: lanes of the first tile row read lane + 8, of the second lane - 8 (bank_mask: who is written)
+          unsigned cBn;
+          asm volatile("s_nop 1\n\t"
+                       "v_mov_b32_dpp %0, %1 row_shl:8 row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+                       "v_mov_b32_dpp %0, %1 row_shr:8 row_mask:0xf bank_mask:0xc bound_ctrl:1" : "=&v"(cBn) : "v"(cB));
+          const unsigned cbase_e = ty ? ((carry_code[KS] >> (8 * e)) & 0xffu) : cA;
+          unsigned code = (base[e] == pooled[e]) ? cbase_e : cBn;
+          code = pooled[e] > 0.f ? code : 15u;
+          codes |= code << (8 * e);
+          cApack |= cA << (8 * e);
+          __builtin_amdgcn_sched_barrier(0);                   // one element at a time (register pressure)
+        }
+        carry_code[KS] = cApack;
+        pooled = wino_relu4(pooled, 0.f);
+        // always issued (the counted wait relies on it): lanes without a pixel or beyond the channel count go out of range
+        const bool st = emit_px && cbase + 4 * g < climit;
+        const int pv = st ? p_off + cbase * 4 : (int)OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pooled), pres, pv, (int)psoff, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_buffer_store_b32(codes, cres, st ? (p_off >> 2) + cbase : (int)OOB, (int)(psoff >> 2), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        pooled = wino_relu4(pooled, 0.f);
+      }
       carry[KS] = A;
       const float* const sA = sqAL + bi * (4 * NSQ * 64) + lane;
 #pragma unroll
@@ -299,10 +358,12 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
             };
             inv1([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
             inv1([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
-            if (rr == 0) pool_in(bi0 + rr, std::integral_constant<int, KS0>{}, ov);
-            else if (rr == 1) pool_in(bi0 + rr, std::integral_constant<int, KS0 + 1>{}, ov);
-            else if (rr == 2) pool_in(bi0 + rr, std::integral_constant<int, (KS0 + 2) & 7>{}, ov);
-            else pool_in(bi0 + rr, std::integral_constant<int, (KS0 + 3) & 7>{}, ov);
+            // (SAVE) channel of the block in the expand1x1 window of the saved tensor
+            const int s1 = pass - P3, c1 = a.sv_coff1 + 128 * (s1 >> 1) + (2 * rr + (s1 & 1)) * 16, l1 = a.sv_coff1 + a.N1;
+            if (rr == 0) pool_in(bi0 + rr, std::integral_constant<int, KS0>{}, ov, c1, l1);
+            else if (rr == 1) pool_in(bi0 + rr, std::integral_constant<int, KS0 + 1>{}, ov, c1, l1);
+            else if (rr == 2) pool_in(bi0 + rr, std::integral_constant<int, (KS0 + 2) & 7>{}, ov, c1, l1);
+            else pool_in(bi0 + rr, std::integral_constant<int, (KS0 + 3) & 7>{}, ov, c1, l1);
           }
         } else {
           auto inv = [&](auto half, auto put) {
@@ -323,7 +384,7 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
           f32x4 ov[4];
           inv([](const f32x4& v) { return (f32x2)v.lo; }, [&](int px, f32x2 y) { ov[px].lo = y; });
           inv([](const f32x4& v) { return (f32x2)v.hi; }, [&](int px, f32x2 y) { ov[px].hi = y; });
-          pool_in(pass, std::integral_constant<int, KS0>{}, ov);
+          pool_in(pass, std::integral_constant<int, KS0>{}, ov, a.sv_coff + 16 * pass, a.sv_coff + a.N);
         }
       };
       // the carry slots are compile-time register indices, so the (at most 8) channel blocks are enumerated statically:
@@ -363,14 +424,14 @@ __device__ __forceinline__ void wino_poolbridge16_body(const WinoArgs& a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSQ, int NCH>
+template <int NSQ, int NCH, bool SAVE>
 __global__ __launch_bounds__(512, 1) void fire_poolbridge16_kernel(WinoArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  wino_poolbridge16_body<NSQ, NCH>(a);
+  wino_poolbridge16_body<NSQ, NCH, SAVE>(a);
 #endif
 }
 
-template <int NSQ, int NCH>
+template <int NSQ, int NCH, bool SAVE>
 static int launch_wino_poolbridge16_t(WinoArgs a, int nseg, hipStream_t stream) {
   constexpr int WV = 8, NTHR = WV * 64, RSLOTS = 224;
   const int nchunks = a.C >> 3;
@@ -384,7 +445,8 @@ static int launch_wino_poolbridge16_t(WinoArgs a, int nseg, hipStream_t stream) 
   const int nblk = first1 + rb1 * P1;
   const size_t lds = (size_t)(2 * WV * RSLOTS * 4 + first1 * nchunks * 2048 + P1 * nchunks * e1_stage + nblk * 4 * NSQ * 64 + (first1 + P1) * 64 + NSQ * 16) * sizeof(float);
   if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
-  auto kern = fire_poolbridge16_kernel<NSQ, NCH>;
+  if (SAVE && (!a.sv || !a.sv_codes)) return SQD_ERR_BAD_ARG;
+  auto kern = fire_poolbridge16_kernel<NSQ, NCH, SAVE>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
@@ -406,9 +468,9 @@ static int launch_wino_poolbridge16_t(WinoArgs a, int nseg, hipStream_t stream) 
   return sqd_launch_status();
 }
 
-template <int NSQ>
+template <int NSQ, bool SAVE = false>
 static int launch_wino_poolbridge16(WinoArgs a, int nseg, hipStream_t stream) {
-  if ((a.C >> 3) == 1) return launch_wino_poolbridge16_t<NSQ, 1>(a, nseg, stream);
-  if ((a.C >> 3) == 2) return launch_wino_poolbridge16_t<NSQ, 2>(a, nseg, stream);
+  if ((a.C >> 3) == 1) return launch_wino_poolbridge16_t<NSQ, 1, SAVE>(a, nseg, stream);
+  if ((a.C >> 3) == 2) return launch_wino_poolbridge16_t<NSQ, 2, SAVE>(a, nseg, stream);
   return SQD_ERR_UNSUPPORTED;
 }

@@ -18,6 +18,8 @@ There is no CPU path: modules raise if the input is not on a GPU or the HIP libr
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -145,6 +147,7 @@ class SqueezeDetBase(nn.Module):
         self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
         self.fuse_expand_wino = True              # ... in Winograd form (ops.fire_wino) where the table has an X: row
         self.fuse_fire_bridge = True              # ... together with the NEXT Fire's squeeze (ops.fire_bridge) where it has a Y: row
+        self.fuse_train_forward = os.environ.get('SQD_FUSE_TRAIN_FWD', '1')[:1] != '0'    # training forward: the bridges in their storing forms
         # inference forward: pool 2 / 3 folded into the following squeeze (ops.pool_squeeze).  Off by default: measured equal
         # to the two separate kernels (0.174 vs 0.18 ms) -- both are bound by the 9x L2 read amplification of the window gather
         self.fuse_pool_squeeze = False
@@ -155,7 +158,6 @@ class SqueezeDetBase(nn.Module):
         # no mask tensor and no torch RNG kernel in the step.  fused_dropout = False draws the mask as a tensor (stand-alone kernel)
         self.fused_dropout = True
         self._drop = None                   # (torch.initial_seed() it was derived from, ops.DropState)
-        import os
         # forward (inference and training): squeeze + expand1x1 of a Fire in one launch (ops.fire_sq_e1) wherever they would be two plain
         # launches.  OFF: measured slower in the step (inference 1.553 -> 1.607 ms, training 5.49 -> 5.57 ms; per Fire 100 vs 88 us at
         # C512/768 -> 96 -> 384, 56 vs 52 at -> 64 -> 256, 37 vs 39 at -> 48 -> 192): a chain stage is 8 NT MFMAs per wave between two
@@ -212,18 +214,42 @@ class SqueezeDetBase(nn.Module):
         return p
 
     def fire_bridge_plan(self, idx, fire, nxt, cfg_id, pooled=False):
-        """Operands of the one-launch form of ``fire``'s expand pair + ``nxt``'s squeeze (ops.fire_bridge, inference forward);
-        rebuilt when any of the three modules' parameters change."""
+        """Operands of the one-launch form of ``fire``'s expand pair + ``nxt``'s squeeze (ops.fire_bridge / ops.fire_pool_bridge);
+        refreshed in place when any of the three modules' parameters change (``refresh_plans`` does all bridges with two launches)."""
         key = ('firebridge', idx, cfg_id, pooled)
         mods = (fire.expand1x1, fire.expand3x3, nxt.squeeze)
-        ver = tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()))
         hit = self._fused_plans.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+        if hit is not None:
+            if hit[0] != self._bridge_version(mods):
+                self._refresh_bridge_plans([key])
+            return self._fused_plans[key][1]
         p = ops.FireBridgePlan(fire.expand1x1.weight, fire.expand1x1.bias, fire.expand3x3.weight, fire.expand3x3.bias,
                                nxt.squeeze.weight, nxt.squeeze.bias, cfg_id, pooled=pooled)
-        self._fused_plans[key] = (ver, p)
+        self._fused_plans[key] = (self._bridge_version(mods), p, mods)
         return p
+
+    @staticmethod
+    def _bridge_version(mods):
+        return tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()))
+
+    def _refresh_bridge_plans(self, keys=None):
+        """Every cached Fire-bridge plan (or just ``keys``) whose parameters changed: operands rewritten in place, two launches."""
+        from . import plans as _plans
+        stale = []
+        for key, val in self._fused_plans.items():
+            if key[0] != 'firebridge' or (keys is not None and key not in keys):
+                continue
+            ver, plan, mods = val
+            now = self._bridge_version(mods)
+            if now != ver:
+                stale.append((key, now, plan, mods))
+        if not stale:
+            return
+        tables = _plans.refresh_bridge_plans([(plan, m[0].weight.detach(), m[0].bias.detach(), m[1].weight.detach(), m[1].bias.detach(),
+                                              m[2].weight.detach(), m[2].bias.detach()) for _k, _n, plan, m in stale])
+        self._pack_table_keepalive = (self._pack_table_keepalive or [])[-6:] + [tables]
+        for key, now, plan, mods in stale:
+            self._fused_plans[key] = (now, plan, mods)
 
     def wino_plan(self, name, mod, cfg_id, direction='fwd'):
         """Transformed-weight cache of the Winograd 3x3 kernel (ops.WinoPlan), re-transformed in place when the parameter
@@ -306,6 +332,7 @@ class SqueezeDetBase(nn.Module):
             if now != ver:
                 stale.append((plan, mod.weight)); dg.append(direction != 'fwd'); keys.append((key, now, mod))
         self._refresh_wino_plans()
+        self._refresh_bridge_plans()
         if not stale:
             return
         if self._pack_table_keepalive is not None and len(self._pack_table_keepalive) > 8:

@@ -302,8 +302,10 @@ def fire_wino(x, x_coff, plan, y, y_coff1, y_coff3):
     return y
 
 
-def fire_bridge(x, x_coff, plan, y, y_coff):
-    """y[..., y_coff:+Nsq] = relu(squeeze'(cat(relu(expand1x1(x)), relu(expand3x3(x))))) in ONE launch (inference)."""
+def fire_bridge(x, x_coff, plan, y, y_coff, save=None, save_coff1=0, save_coff3=None):
+    """y[..., y_coff:+Nsq] = relu(squeeze'(cat(relu(expand1x1(x)), relu(expand3x3(x))))) in ONE launch.  Inference: the concatenated
+    expand output is never written.  Training (``save``: [B,H,W,>=N1+N3]): it is stored too -- expand1x1 at ``save_coff1``, expand3x3 at
+    ``save_coff3`` (default: right behind the expand1x1 window) -- for the backward; only the small-C form (plan.cfg_id 12) has it."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
     B, H, W, xp = x.shape
     if tuple(y.shape[:3]) != (B, H, W) or plan.pooled:
@@ -311,24 +313,44 @@ def fire_bridge(x, x_coff, plan, y, y_coff):
     yp = y.shape[3]
     if x_coff < 0 or x_coff + plan.C > xp or y_coff < 0 or y_coff + plan.Nsq > yp:
         raise ValueError('fire_bridge: channel window out of range')
+    if save is not None:
+        _check_nhwc(save, 'save')
+        if save_coff3 is None:
+            save_coff3 = save_coff1 + plan.N1
+        sp = save.shape[3]
+        if tuple(save.shape[:3]) != (B, H, W) or min(save_coff1, save_coff3) < 0 or save_coff1 + plan.N1 > sp or save_coff3 + plan.N3 > sp:
+            raise ValueError('fire_bridge: save must be [B,H,W,.] with both expand windows inside')
+        if not (save_coff1 + plan.N1 <= save_coff3 or save_coff3 + plan.N3 <= save_coff1):
+            raise ValueError('fire_bridge: the two windows of save overlap')
+        if plan.cfg_id % 1000 != 12:
+            raise ValueError('fire_bridge: only the small-C form (cfg 12) stores the expand output')
     br = None
     if timing._timer is not None:
         npix = B * H * W
-        br = _Bracket('fire_bridge', f'fire C{plan.C} E{plan.N1}+{plan.N3} -> S{plan.Nsq} {H}x{W}',
+        br = _Bracket('fire_bridge_save' if save is not None else 'fire_bridge', f'fire C{plan.C} E{plan.N1}+{plan.N3} -> S{plan.Nsq} {H}x{W}',
                       2.0 * npix * (plan.C * (4 * plan.N3 + plan.N1) + (plan.N1 + plan.N3) * plan.Nsq),
-                      4.0 * (npix * (plan.C + plan.Nsq) + plan.C * (16 * plan.N3 + plan.N1) + (plan.N1 + plan.N3) * plan.Nsq))
-    rc = nat.lib().sqd_fire_bridge_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias_tab), nat.ptr(plan.sq_ops), nat.ptr(plan.sq_bias),
-                                       nat.ptr(y), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1, plan.Npad, plan.Nsq, yp, y_coff,
-                                       plan.cfg_id, nat.stream_handle(x.device))
-    nat.check(rc, 'sqd_fire_bridge_fwd')
+                      4.0 * (npix * (plan.C + plan.Nsq + (plan.N1 + plan.N3 if save is not None else 0))
+                             + plan.C * (16 * plan.N3 + plan.N1) + (plan.N1 + plan.N3) * plan.Nsq))
+    if save is not None:
+        rc = nat.lib().sqd_fire_bridge_save_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias_tab), nat.ptr(plan.sq_ops), nat.ptr(plan.sq_bias),
+                                                nat.ptr(y), nat.ptr(save), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1, plan.Npad, plan.Nsq,
+                                                yp, y_coff, sp, save_coff3, save_coff1, nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_fire_bridge_save_fwd')
+    else:
+        rc = nat.lib().sqd_fire_bridge_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias_tab), nat.ptr(plan.sq_ops), nat.ptr(plan.sq_bias),
+                                           nat.ptr(y), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1, plan.Npad, plan.Nsq, yp, y_coff,
+                                           plan.cfg_id, nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_fire_bridge_fwd')
     if br is not None:
         br.done()
     return y
 
 
-def fire_pool_bridge(x, x_coff, plan, y, y_coff, nseg=4):
-    """y[..., y_coff:+Nsq] = relu(squeeze'(maxpool3x3s2_ceil(cat(relu(expand1x1(x)), relu(expand3x3(x)))))) in ONE launch
-    (inference); y is [B, Hp, Wp, .] with (Hp, Wp) = pool_out_size(H, W).  ``plan``: FireBridgePlan(..., pooled=True)."""
+def fire_pool_bridge(x, x_coff, plan, y, y_coff, nseg=4, save=None, codes=None, save_coff1=0, save_coff3=None):
+    """y[..., y_coff:+Nsq] = relu(squeeze'(maxpool3x3s2_ceil(cat(relu(expand1x1(x)), relu(expand3x3(x)))))) in ONE launch; y is
+    [B, Hp, Wp, .] with (Hp, Wp) = pool_out_size(H, W).  ``plan``: FireBridgePlan(..., pooled=True).  Inference: neither the expand
+    output nor the pooled tensor is written.  Training (``save`` fp32 [B,Hp,Wp,>=N1+N3] and ``codes`` uint8 of the same shape): the
+    pooled tensor and the pool's arg-max / ReLU codes are stored too (everything the backward reads of this stage)."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')
     B, H, W, xp = x.shape
     Hp, Wp = pool_out_size(H, W)
@@ -337,16 +359,38 @@ def fire_pool_bridge(x, x_coff, plan, y, y_coff, nseg=4):
     yp = y.shape[3]
     if x_coff < 0 or x_coff + plan.C > xp or y_coff < 0 or y_coff + plan.Nsq > yp:
         raise ValueError('fire_pool_bridge: channel window out of range')
+    if (save is None) != (codes is None):
+        raise ValueError('fire_pool_bridge: save and codes go together')
+    if save is not None:
+        _check_nhwc(save, 'save')
+        if save_coff3 is None:
+            save_coff3 = save_coff1 + plan.N1
+        sp = save.shape[3]
+        if tuple(save.shape[:3]) != (B, Hp, Wp) or min(save_coff1, save_coff3) < 0 or save_coff1 + plan.N1 > sp or save_coff3 + plan.N3 > sp:
+            raise ValueError('fire_pool_bridge: save must be [B,Hp,Wp,.] with both expand windows inside')
+        if not (save_coff1 + plan.N1 <= save_coff3 or save_coff3 + plan.N3 <= save_coff1):
+            raise ValueError('fire_pool_bridge: the two windows of save overlap')
+        if tuple(codes.shape) != tuple(save.shape) or codes.dtype != torch.uint8 or not codes.is_contiguous() or codes.device != save.device:
+            raise ValueError('fire_pool_bridge: codes must be a contiguous uint8 tensor of save\'s shape')
     br = None
     if timing._timer is not None:
         npix = B * H * W
-        br = _Bracket('fire_pool_bridge', f'fire C{plan.C} E{plan.N1}+{plan.N3} -> pool -> S{plan.Nsq} {H}x{W}',
+        br = _Bracket('fire_pool_bridge_save' if save is not None else 'fire_pool_bridge',
+                      f'fire C{plan.C} E{plan.N1}+{plan.N3} -> pool -> S{plan.Nsq} {H}x{W}',
                       2.0 * (npix * plan.C * (4 * plan.N3 + plan.N1) + B * Hp * Wp * (plan.N1 + plan.N3) * plan.Nsq),
-                      4.0 * (npix * plan.C + B * Hp * Wp * plan.Nsq + plan.C * (16 * plan.N3 + plan.N1) + (plan.N1 + plan.N3) * plan.Nsq))
-    rc = nat.lib().sqd_fire_pool_bridge_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias_tab), nat.ptr(plan.sq_ops), nat.ptr(plan.sq_bias),
-                                            nat.ptr(y), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1, plan.Npad, plan.Nsq, Hp, Wp, yp, y_coff,
-                                            int(nseg), nat.stream_handle(x.device))
-    nat.check(rc, 'sqd_fire_pool_bridge_fwd')
+                      4.0 * (npix * plan.C + B * Hp * Wp * (plan.Nsq + (1.25 * (plan.N1 + plan.N3) if save is not None else 0))
+                             + plan.C * (16 * plan.N3 + plan.N1) + (plan.N1 + plan.N3) * plan.Nsq))
+    if save is not None:
+        rc = nat.lib().sqd_fire_pool_bridge_save_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias_tab), nat.ptr(plan.sq_ops), nat.ptr(plan.sq_bias),
+                                                     nat.ptr(y), nat.ptr(save), nat.ptr(codes), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1,
+                                                     plan.Npad, plan.Nsq, Hp, Wp, yp, y_coff, sp, save_coff3, save_coff1, int(nseg),
+                                                     nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_fire_pool_bridge_save_fwd')
+    else:
+        rc = nat.lib().sqd_fire_pool_bridge_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias_tab), nat.ptr(plan.sq_ops), nat.ptr(plan.sq_bias),
+                                                nat.ptr(y), B, H, W, plan.C, xp, x_coff, plan.N3, plan.N1, plan.Npad, plan.Nsq, Hp, Wp, yp, y_coff,
+                                                int(nseg), nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_fire_pool_bridge_fwd')
     if br is not None:
         br.done()
     return y
@@ -433,9 +477,11 @@ def stem_pool_squeeze_ok(image_shape, stem_weight_shape, squeeze_width):
     return (k, N, squeeze_width) == (3, 64, 16) and image_shape[3] % 4 == 0 and image_shape[2] >= 5 and image_shape[3] >= 5
 
 
-def stem_pool_squeeze(image, weight, bias, sq_weight, sq_bias):
-    """Inference: conv(3->64,3,s2)+ReLU+MaxPool(3,2,ceil) AND the first Fire's squeeze (1x1, 64->16, +ReLU) in one launch:
-    NCHW image -> NHWC squeeze output [B,Hp,Wp,16]; the pooled tensor is never written (src/model/squeezedet.py:34-37, :17-18)."""
+def stem_pool_squeeze(image, weight, bias, sq_weight, sq_bias, argmax=None):
+    """conv(3->64,3,s2)+ReLU+MaxPool(3,2,ceil) AND the first Fire's squeeze (1x1, 64->16, +ReLU) in one launch
+    (src/model/squeezedet.py:34-37, :17-18).  Inference (``argmax`` None): NCHW image -> NHWC squeeze output [B,Hp,Wp,16]; the pooled
+    tensor is never written.  Training (``argmax``: uint8 [B,Hp,Wp,64]): -> (squeeze output, pooled tensor); the pooled tensor and
+    its codes are stored for the backward as by ``stem_pool(argmax=)``."""
     if image.dim() != 4 or image.shape[1] != 3 or image.dtype != torch.float32 or not image.is_cuda:
         raise ValueError(f'stem_pool_squeeze: image must be fp32 CUDA NCHW with 3 channels, got {tuple(image.shape)}')
     image = image.contiguous()
@@ -446,13 +492,24 @@ def stem_pool_squeeze(image, weight, bias, sq_weight, sq_bias):
     B, _, H, W = image.shape
     Ho, Wo = stem_out_size(H, W, k)
     Hp, Wp = pool_out_size(Ho, Wo)
+    if argmax is not None and (tuple(argmax.shape) != (B, Hp, Wp, N) or argmax.dtype != torch.uint8 or not argmax.is_contiguous()):
+        raise ValueError('stem_pool_squeeze: bad argmax tensor')
     out = torch.empty(B, Hp, Wp, nsq, device=image.device, dtype=torch.float32)
     w = weight.detach().contiguous()
     b = None if bias is None else bias.detach().contiguous()
     ws = sq_weight.detach().contiguous()
     bs = None if sq_bias is None else sq_bias.detach().contiguous()
-    br = _Bracket(f'stem_pool_sq<{k}>', f'stem+pool+squeeze {H}x{W} S{nsq}', 2.0 * B * (Ho * Wo * N * 3 * k * k + Hp * Wp * N * nsq),
-                  4.0 * (B * 3 * H * W + B * Hp * Wp * nsq)) if timing._timer is not None else None
+    br = _Bracket(f'stem_pool_sq{"_train" if argmax is not None else ""}<{k}>', f'stem+pool+squeeze {H}x{W} S{nsq}',
+                  2.0 * B * (Ho * Wo * N * 3 * k * k + Hp * Wp * N * nsq),
+                  4.0 * (B * 3 * H * W + B * Hp * Wp * nsq + (B * Hp * Wp * N * 1.25 if argmax is not None else 0))) if timing._timer is not None else None
+    if argmax is not None:
+        pooled = torch.empty(B, Hp, Wp, N, device=image.device, dtype=torch.float32)
+        rc = nat.lib().sqd_stem_pool_squeeze_train_fwd(nat.ptr(image), nat.ptr(w), nat.ptr(b), nat.ptr(ws), nat.ptr(bs), nat.ptr(pooled),
+                                                       nat.ptr(argmax), nat.ptr(out), B, H, W, N, k, nsq, nat.stream_handle(image.device))
+        nat.check(rc, 'sqd_stem_pool_squeeze_train_fwd')
+        if br is not None:
+            br.done()
+        return out, pooled
     rc = nat.lib().sqd_stem_pool_squeeze_fwd(nat.ptr(image), nat.ptr(w), nat.ptr(b), nat.ptr(ws), nat.ptr(bs), nat.ptr(out), B, H, W, N, k,
                                              nsq, nat.stream_handle(image.device))
     nat.check(rc, 'sqd_stem_pool_squeeze_fwd')

@@ -121,9 +121,10 @@ def _wgrad(batch, H, W, N, C, taps):
 
 def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
                          use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True, fuse_sq_e1=False, dropout=True,
-                         fused_dropout=True):
-    """Launches of one training iteration's forward (activations saved, no inference-only fusion: ``autograd.py`` gates
-    the bridges and fused expands on ``not save``), multi-task loss forward / backward and the backbone backward, as
+                         fused_dropout=True, fuse_train_forward=True, fuse_fire_bridge=True, fuse_stem_squeeze=True):
+    """Launches of one training iteration's forward (activations saved; ``fuse_train_forward``: the stem + squeeze launch and the
+    two small-C bridges run in their STORING forms -- what the backward reads is written by the fused launch -- where the table has
+    their rows; the other inference-only fusions stay off), multi-task loss forward / backward and the backbone backward, as
     (kernel name, shape tag) in launch order.  The optimizer launch and torch's own elementwise kernels (dropout mask,
     ``loss.mean()``) are not KernelTimer-bracketed and not listed.  ``data_parallel_stages``: with a gradient exchange
     attached the slab reduction runs once per backward stage instead of once at the end.  ``fuse_squeeze_bwd`` =
@@ -138,8 +139,15 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
     plan = []
     fused_stem = layers[2][0] == 'pool'
     first = 2
+    bridged = False                                     # the next Fire's squeeze already ran inside the previous launch
     if fused_stem:
-        plan.append((f'stem_pool<{ks}>', f'stem+pool {input_size[0]}x{input_size[1]}'))
+        nxt = layers[3] if len(layers) > 3 else None
+        if (fuse_train_forward and fuse_stem_squeeze and nxt is not None and nxt[0] == 'fire'
+                and ops.stem_pool_squeeze_ok((batch, 3, input_size[0], input_size[1]), (layers[0][2], 3, ks, ks), nxt[2])):
+            plan.append((f'stem_pool_sq_train<{ks}>', f'stem+pool+squeeze {input_size[0]}x{input_size[1]} S{nxt[2]}'))
+            bridged = True
+        else:
+            plan.append((f'stem_pool<{ks}>', f'stem+pool {input_size[0]}x{input_size[1]}'))
         H, W = ops.pool_out_size(H, W)
         first = 3
     else:
@@ -149,22 +157,46 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
         l = layers[i]
         geo[i] = (H, W, C)
         if l[0] == 'pool':
-            plan.append(('maxpool_fwd', f'pool C{C} {H}x{W}'))
+            if not bridged:
+                plan.append(('maxpool_fwd', f'pool C{C} {H}x{W}'))
             H, W = ops.pool_out_size(H, W)
             continue
         _, cin, s, e1, e3 = l
         # (the last Fire carries the dropout in its expand epilogues: two plain launches)
         is_last = i == len(layers) - 1
+        nxt = layers[i + 1] if i + 1 < len(layers) else None
+        nxt2 = layers[i + 2] if i + 2 < len(layers) else None
+        npix = batch * H * W
+        zseg_t = ycfg_t = None
+        if fuse_train_forward and fuse_fire_bridge and use_winograd:
+            if nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire':
+                zseg_t = ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix)
+            if nxt is not None and nxt[0] == 'fire' and not (is_last and dropout):
+                ycfg_t = ops.choose_fire_bridge_cfg(s, e1, e3, nxt[2], npix)
+                if ycfg_t is not None and ycfg_t % 1000 != 12:
+                    ycfg_t = None
+        if zseg_t is not None or ycfg_t is not None:
+            if not bridged:
+                plan.append(_conv1x1(batch, H, W, cin, s))
+            if zseg_t is not None:
+                plan.append(('fire_pool_bridge_save', f'fire C{s} E{e1}+{e3} -> pool -> S{nxt2[2]} {H}x{W}'))
+            else:
+                plan.append(('fire_bridge_save', f'fire C{s} E{e1}+{e3} -> S{nxt[2]} {H}x{W}'))
+            bridged = True
+            C = e1 + e3
+            continue
         dcfg = None
         if is_last and dropout:
             dcfg = ops.conv_drop_cfg(s, e1, batch * H * W) if (fused_dropout and s % 8 == 0 and use_winograd) else None
             if dcfg is None:
                 plan.append(('dropout_mask', f'{batch * H * W * (e1 + e3)} elements'))
-        if fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1) and not (is_last and dropout):
+        if fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1) and not (is_last and dropout) and not bridged:
             plan.append((f'fire_sq_e1<{s // 16}>', f'sq+e1 C{cin} S{s} E{e1} {H}x{W}'))
             plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
         else:
-            plan.append(_conv1x1(batch, H, W, cin, s))
+            if not bridged:
+                plan.append(_conv1x1(batch, H, W, cin, s))
+            bridged = False
             if dcfg is not None:
                 plan.append((ops.cfg_kernel_name(dcfg), f'1tap C{s} N{e1} {H}x{W}'))
                 plan.append(('conv_wino_sk', f'9tap C{s} N{e3} {H}x{W}'))

@@ -238,8 +238,9 @@ class FireWinoPlan:
 
 class FireBridgePlan:
     """Operands of ``fire_bridge``: the Fire's expand pair transformed as in FireWinoPlan, the per-pass bias table, and the next
-    Fire's squeeze weights laid out as MFMA A operands (include/sqd_hip.h, sqd_fire_bridge_fwd)."""
-    __slots__ = ('cfg_id', 'C', 'N3', 'N1', 'Npad', 'Nsq', 'w', 'bias_tab', 'sq_ops', 'sq_bias', 'pooled')
+    Fire's squeeze weights laid out as MFMA A operands (include/sqd_hip.h, sqd_fire_bridge_fwd).  The buffers are allocated once;
+    ``refresh_bridge_plans`` rewrites them in place after the parameters changed (training: every step)."""
+    __slots__ = ('cfg_id', 'C', 'N3', 'N1', 'Npad', 'Nsq', 'w', 'aux', 'bias_tab', 'sq_ops', 'sq_bias', 'pooled', 'map_u', 'map_aux')
 
     def __init__(self, w1, b1, w3, b3, wsq, bsq, cfg_id, pooled=False):
         N3, C = w3.shape[0], w3.shape[1]
@@ -254,12 +255,25 @@ class FireBridgePlan:
         elif not fire_bridge_cfg_ok(cfg_id, C, N3, N1, Nsq):
             raise ValueError(f'fire_bridge: configuration {cfg_id} cannot run C={C} E={N1}+{N3} -> {Nsq}')
         self.pooled = pooled
-        dev = w3.device
         self.cfg_id, self.C, self.N3, self.N1, self.Nsq = cfg_id, C, N3, N1, Nsq
         P3, P1 = -(-N3 // 32), -(-N1 // 128)
         self.Npad = 32 * (P3 + P1)
-        self.w = torch.empty(C // 8, 16, self.Npad, 8, device=dev, dtype=torch.float32)
-        nat.check(nat.lib().sqd_pack_wino_fire(nat.ptr(w3.detach().contiguous()), nat.ptr(w1.detach().contiguous()), nat.ptr(self.w),
+        self.map_u = self.map_aux = None
+        u, so, bt, sb = self._build(w1, b1, w3, b3, wsq, bsq)
+        self.w = u
+        self.aux = torch.cat([so.reshape(-1), bt.reshape(-1), sb.reshape(-1)]).contiguous()       # one buffer: one gather record
+        n0, n1 = so.numel(), so.numel() + bt.numel()
+        self.sq_ops = self.aux[:n0].view(so.shape)
+        self.bias_tab = self.aux[n0:n1].view(bt.shape)
+        self.sq_bias = self.aux[n1:].view(sb.shape)
+
+    def _build(self, w1, b1, w3, b3, wsq, bsq):
+        """(u, sq_ops, bias_tab, sq_bias) of these parameter values."""
+        C, N3, N1, Nsq, cfg_id, pooled = self.C, self.N3, self.N1, self.Nsq, self.cfg_id, self.pooled
+        P3, P1 = -(-N3 // 32), -(-N1 // 128)
+        dev = w3.device
+        u = torch.empty(C // 8, 16, self.Npad, 8, device=dev, dtype=torch.float32)
+        nat.check(nat.lib().sqd_pack_wino_fire(nat.ptr(w3.detach().contiguous()), nat.ptr(w1.detach().contiguous()), nat.ptr(u),
                                                N3, N1, C, self.Npad, nat.stream_handle(dev)), 'sqd_pack_wino_fire')
         # cat channel of every 16-channel block, in pass order: expand3x3 slices (cat offset N1), then expand1x1 slices
         narrow = cfg_id % 1000 == 12                 # 16-wide passes: 1 block per expand3x3 pass, 4 per expand1x1 pass
@@ -276,7 +290,7 @@ class FireBridgePlan:
         wz = torch.zeros(16 * nq, N1 + N3, device=dev, dtype=torch.float32)
         wz[:Nsq] = wsq.detach().reshape(Nsq, N1 + N3)
         g = wz[:, chs.reshape(-1)].view(nq, 16, nblk, 4, 4) * ok.view(1, 1, nblk, 4, 4)                        # [q][lr][blk][g][t]
-        self.sq_ops = g.permute(2, 4, 0, 3, 1).contiguous()                                                   # [blk][t][q][g][lr]
+        sq_ops = g.permute(2, 4, 0, 3, 1).contiguous()                                                        # [blk][t][q][g][lr]
         bcat = torch.cat([torch.zeros(N1, device=dev) if b1 is None else b1.detach().float(),
                           torch.zeros(N3, device=dev) if b3 is None else b3.detach().float()])
         bvals = bcat[chs.reshape(-1)].view(nblk, 16) * ok
@@ -289,8 +303,67 @@ class FireBridgePlan:
             bt = torch.zeros(P3 + P1, 8, 16, device=dev, dtype=torch.float32)
             bt[:P3, :2] = bvals[:2 * P3].view(P3, 2, 16)
             bt[P3:] = bvals[2 * P3:].view(P1, 8, 16)
-        self.bias_tab = bt.contiguous()
-        self.sq_bias = (torch.zeros(Nsq, device=dev) if bsq is None else bsq.detach().float()).contiguous()
+        sq_bias = (torch.zeros(Nsq, device=dev) if bsq is None else bsq.detach().float()).contiguous()
+        return u, sq_ops, bt.contiguous(), sq_bias
+
+    def make_maps(self):
+        """Index maps of the in-place refresh (sqd_gather_pack_batched), derived ONCE by pushing coded parameter values through
+        ``_build``: every operand element besides the expand3x3 transform is a copy (or +-0.25 times a copy) of one parameter element
+        at a position that depends on the shapes only.  Sources: 0 = next squeeze weight / expand1x1 weight (u), 1 = expand1x1 bias,
+        2 = expand3x3 bias, 3 = next squeeze bias."""
+        if self.map_aux is not None:
+            return
+        C, N3, N1, Nsq = self.C, self.N3, self.N1, self.Nsq
+        dev = self.w.device
+        assert max(N1 * C, Nsq * (N1 + N3)) < (1 << 22)
+        code = lambda n, base=0: torch.arange(1 + base, n + 1 + base, device=dev, dtype=torch.float32)
+        w1c = code(N1 * C).view(N1, C, 1, 1)
+        wsc = code(Nsq * (N1 + N3)).view(Nsq, N1 + N3, 1, 1)
+        z3 = torch.zeros(N3, C, 3, 3, device=dev)
+        u, so, bt, sb = self._build(w1c, code(N1), z3, code(N3, N1), wsc, code(Nsq))
+        # u: only the virtual (expand1x1) channels belong to the gather; the expand3x3 part is the batched Winograd transform's
+        uq = torch.round(u * 4.0).to(torch.int64)                                       # +-(element + 1), 0 where padded
+        mu = torch.where(uq == 0, torch.full_like(uq, -1), (uq.abs() - 1) | torch.where(uq > 0, 1 << 28, 2 << 28))
+        virt = torch.zeros(self.Npad // 16, dtype=torch.bool, device=dev)
+        virt[-(-N3 // 32) * 2:] = True
+        mu = torch.where(virt.view(1, 1, -1, 1, 1, 1, 1), mu.view(C // 8, 8, self.Npad // 16, 4, 16, 2, 2), torch.full_like(mu, -2).view(C // 8, 8, self.Npad // 16, 4, 16, 2, 2))
+        self.map_u = mu.reshape(-1).to(torch.int32).contiguous()
+        so_i = torch.round(so).to(torch.int64)
+        m_so = torch.where(so_i == 0, torch.full_like(so_i, -1), so_i - 1)              # source 0
+        bt_i = torch.round(bt).to(torch.int64)
+        m_bt = torch.where(bt_i == 0, torch.full_like(bt_i, -1),
+                           torch.where(bt_i <= N1, (bt_i - 1) | (1 << 26), (bt_i - 1 - N1) | (2 << 26)))
+        m_sb = (torch.round(sb).to(torch.int64) - 1) | (3 << 26)
+        self.map_aux = torch.cat([m_so.reshape(-1), m_bt.reshape(-1), m_sb.reshape(-1)]).to(torch.int32).contiguous()
+        assert self.map_aux.numel() == self.aux.numel() and self.map_u.numel() == self.w.numel()
+
+
+def refresh_bridge_plans(items):
+    """In-place refresh of Fire-bridge operands after their parameters changed: ``items`` = [(FireBridgePlan, w1, b1, w3, b3, wsq, bsq)].
+    Two launches whatever the number of bridges: the batched Winograd transform (expand3x3 parts) and the batched gather (the rest)."""
+    if not items:
+        return None
+    wrows, grows = [], []
+    for plan, w1, b1, w3, b3, wsq, bsq in items:
+        plan.make_maps()
+        for t in (w1, b1, w3, b3, wsq, bsq):
+            if t is None or not t.is_contiguous() or t.dtype != torch.float32:
+                raise ValueError('refresh_bridge_plans: parameters must be contiguous fp32 tensors (biases included)')
+        wrows.append([w3.data_ptr(), plan.w.data_ptr(), plan.N3, plan.C, plan.Npad, 0, (plan.C // 8) * plan.Npad * 8])
+        grows.append([plan.w.data_ptr(), plan.map_u.data_ptr(), plan.w.numel(), w1.data_ptr(), 0, 0, 0])
+        grows.append([plan.aux.data_ptr(), plan.map_aux.data_ptr(), plan.aux.numel(), wsq.data_ptr(), b1.data_ptr(), b3.data_ptr(), bsq.data_ptr()])
+    dev = items[0][0].w.device
+    key = ('bridge', str(dev), tuple(tuple(r) for r in wrows), tuple(tuple(r) for r in grows))
+    tables = _PACK_TABLES.get(key)
+    if tables is None:
+        if len(_PACK_TABLES) > 16:
+            _PACK_TABLES.clear()
+        tables = (torch.tensor(wrows, dtype=torch.int64).to(dev), torch.tensor(grows, dtype=torch.int64).to(dev))
+        _PACK_TABLES[key] = tables
+    s = nat.stream_handle(dev)
+    nat.check(nat.lib().sqd_pack_wino_weights_batched(nat.ptr(tables[0]), len(wrows), 16, s), 'sqd_pack_wino_weights_batched')
+    nat.check(nat.lib().sqd_gather_pack_batched(nat.ptr(tables[1]), len(grows), 16, s), 'sqd_gather_pack_batched')
+    return tables
 
 
 _WGR_OUT = 64               # outputs per workgroup of the slab-reduction kernels (csrc/wgrad.hip WGR_OUT)

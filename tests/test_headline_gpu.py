@@ -42,14 +42,14 @@ class LaunchLog:
         def fire_expand(x, x_coff, fplan, y, y_coff):
             self.calls.append(('fused', 9, fplan.C, fplan.E, x.shape[0] * x.shape[1] * x.shape[2], fplan.cfg_id))
             return real_fused(x, x_coff, fplan, y, y_coff)
-        def fire_bridge(x, x_coff, plan, y, y_coff):
+        def fire_bridge(x, x_coff, plan, y, y_coff, **kw):
             self.calls.append(('bridge', 9, plan.C, (plan.N1, plan.N3, plan.Nsq), x.shape[0] * x.shape[1] * x.shape[2], plan.cfg_id))
-            return real_bridge(x, x_coff, plan, y, y_coff)
+            return real_bridge(x, x_coff, plan, y, y_coff, **kw)
         real_pool_bridge = ops.fire_pool_bridge
 
-        def fire_pool_bridge(x, x_coff, plan, y, y_coff, nseg=4):
+        def fire_pool_bridge(x, x_coff, plan, y, y_coff, nseg=4, **kw):
             self.calls.append(('poolbridge', 9, plan.C, (plan.N1, plan.N3, plan.Nsq), x.shape[0] * x.shape[1] * x.shape[2], nseg))
-            return real_pool_bridge(x, x_coff, plan, y, y_coff, nseg=nseg)
+            return real_pool_bridge(x, x_coff, plan, y, y_coff, nseg=nseg, **kw)
         monkeypatch.setattr(ops, 'fire_bridge', fire_bridge)
         monkeypatch.setattr(ops, 'fire_pool_bridge', fire_pool_bridge)
         monkeypatch.setattr(ops, 'conv', conv)
@@ -211,7 +211,7 @@ def _check_sgd_update(named_params, old_sd, new_ref, grads_ref, lr, tight=('base
     return worst
 
 
-def _training_step_vs_oracle(arch, bs, monkeypatch, expect_3x3):
+def _training_step_vs_oracle(arch, bs, monkeypatch, expect_3x3, expect_bridges=0):
     from squeezedet_pytorch_amd.model import SqueezeDetWithLoss
     from test_training_gpu import _check_grads_flip_aware
     cfg = sqd.make_cfg(arch=arch, dropout_prob=0.0, device='cuda')
@@ -228,7 +228,8 @@ def _training_step_vs_oracle(arch, bs, monkeypatch, expect_3x3):
     opt.zero_grad()
     loss.backward()
     # forward 11 + data gradients 10 expand3x3 + ConvDet = 22 3x3 launches, all on exact table rows
-    log.assert_exact_table_hits(expect_3x3=expect_3x3, allow_fused=(arch != 'squeezedet'), wino_only=(arch == 'squeezedet'))
+    log.assert_exact_table_hits(expect_3x3=expect_3x3, allow_fused=(arch != 'squeezedet'), wino_only=(arch == 'squeezedet'),
+                                expect_bridges=expect_bridges)
     _flat_views_intact(m)
     new_p, _, grads, total, loss_o, stats_o = oracle.train_step_reference(sd, None, x, gt, cfg.anchors, SIZE, arch=arch)
     np.testing.assert_allclose(loss_vec.detach().cpu().numpy(), loss_o.numpy(), rtol=1e-4)
@@ -247,7 +248,8 @@ def _training_step_vs_oracle(arch, bs, monkeypatch, expect_3x3):
 def test_squeezedet_bs20_training_step_vs_oracle(monkeypatch):
     """BASELINE config 3: one bs=20 training iteration (fwd, loss.mean(), backward, clip 5.0, SGD) vs the oracle's CPU
     autograd run of the same step, dropout off (RNG cannot match)."""
-    _training_step_vs_oracle('squeezedet', 20, monkeypatch, expect_3x3=22)
+    # (the forward of fire2 and fire3 runs as the two storing bridges: expand pair [+ pool] + the next squeeze in one launch each)
+    _training_step_vs_oracle('squeezedet', 20, monkeypatch, expect_3x3=22, expect_bridges=2)
 
 
 def test_squeezedetplus_bs16_training_step_vs_oracle(monkeypatch):

@@ -213,6 +213,31 @@ def test_stem_pool_squeeze_one_launch(H, W):
     assert not ops.stem_pool_squeeze_ok((2, 3, 50, 70), w.shape, 16) and not ops.stem_pool_squeeze_ok(x.shape, w.shape, 32)
 
 
+@pytest.mark.parametrize("H,W", [(64, 96), (50, 68), (37, 44), (12, 16), (9, 8), (384, 1248)])
+def test_stem_pool_squeeze_training_form(H, W):
+    """Training form of the stem + squeeze launch (sqd_stem_pool_squeeze_train_fwd): the pooled tensor and the arg-max / ReLU codes
+    are BIT-identical to the stem launch the training forward used before (ops.stem_pool(argmax=)), and the squeeze output equals
+    the reference's modules in fp32 (src/model/squeezedet.py:34-37, :17-18)."""
+    ops = _ops()
+    B = 1 if H == 384 else 2
+    x = _rand(B, 3, H, W, seed=27)
+    w = _rand(64, 3, 3, 3, seed=28, scale=(2.0 / 27) ** 0.5); b = _rand(64, seed=29, scale=0.1)
+    ws = _rand(16, 64, 1, 1, seed=30, scale=(2.0 / 64) ** 0.5); bs = _rand(16, seed=31, scale=0.1)
+    pooled = F.max_pool2d(F.relu(F.conv2d(x, w, b, stride=2, padding=1)), 3, 2, ceil_mode=True)
+    ref = _nhwc(F.relu(F.conv2d(pooled, ws, bs)))
+    Hp, Wp = pooled.shape[2], pooled.shape[3]
+    am0 = torch.full((B, Hp, Wp, 64), 77, dtype=torch.uint8, device='cuda')
+    p0 = ops.stem_pool(x.cuda(), w.cuda(), b.cuda(), argmax=am0)
+    am1 = torch.full((B, Hp, Wp, 64), 78, dtype=torch.uint8, device='cuda')
+    y, p1 = ops.stem_pool_squeeze(x.cuda(), w.cuda(), b.cuda(), ws.cuda(), bs.cuda(), argmax=am1)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1) and torch.equal(am0, am1)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert (y.cpu() - ref).abs().max().item() <= _tol(ref)
+    with pytest.raises(ValueError):
+        ops.stem_pool_squeeze(x.cuda(), w.cuda(), b.cuda(), ws.cuda(), bs.cuda(), argmax=am1[:, :-1])
+
+
 def test_fused_stem_pool_kitti_size_both_paths_agree():
     ops = _ops()
     x = _rand(3, 3, 384, 1248, seed=31).cuda()
@@ -477,6 +502,66 @@ def test_fire_bridge_one_launch(C, E1, E3, S, B, H, W):
     assert ran >= 1
 
 
+@pytest.mark.parametrize("C,E1,E3,S,B,H,W", [
+    (16, 64, 64, 16, 2, 12, 20), (16, 64, 64, 16, 6, 96, 312), (8, 32, 40, 12, 1, 5, 17), (8, 96, 48, 16, 2, 11, 23), (8, 32, 32, 32, 2, 10, 21),
+    (16, 128, 32, 24, 3, 13, 50), (16, 48, 32, 32, 2, 7, 40), (8, 80, 20, 28, 2, 9, 33), (16, 64, 64, 16, 1, 4, 16), (16, 64, 64, 16, 1, 3, 15),
+])
+def test_fire_bridge_storing_form(C, E1, E3, S, B, H, W):
+    """Training form of the Fire -> Fire bridge (sqd_fire_bridge_save_fwd): the squeeze output AND the concatenated expand output of
+    ONE launch == the reference's modules in fp32 (src/model/squeezedet.py:18-22 twice); the stored expand output is bit-identical to
+    the plain fused-expand launch of the same kernel family (sqd_fire_wino_fwd cfg 12), the squeeze output bit-identical to the
+    inference bridge; odd sizes, partial channel blocks, bytes outside the three windows untouched."""
+    ops = _ops()
+    x = F.relu(_rand(B, C, H, W, seed=71))
+    w1 = _rand(E1, C, 1, 1, seed=72, scale=(2.0 / C) ** 0.5); b1 = _rand(E1, seed=73, scale=0.1)
+    w3 = _rand(E3, C, 3, 3, seed=74, scale=(2.0 / (C * 9)) ** 0.5); b3 = _rand(E3, seed=75, scale=0.1)
+    ws = _rand(S, E1 + E3, 1, 1, seed=76, scale=(2.0 / (E1 + E3)) ** 0.5); bs = _rand(S, seed=77, scale=0.1)
+    mid = torch.cat([F.relu(F.conv2d(x, w1, b1)), F.relu(F.conv2d(x, w3, b3, padding=1))], 1)
+    ref = _nhwc(F.relu(F.conv2d(mid, ws, bs)))
+    mid = _nhwc(mid)
+    xg = _nhwc(x).cuda()
+    assert ops.fire_bridge_cfg_ok(12, C, E3, E1, S)
+    plan = ops.FireBridgePlan(w1.cuda(), b1.cuda(), w3.cuda(), b3.cuda(), ws.cuda(), bs.cuda(), 12)
+    y = torch.full((B, H, W, S + 8), -7.0, device='cuda')
+    sv = torch.full((B, H, W, E1 + E3 + 12), -5.0, device='cuda')
+    ops.fire_bridge(xg, 0, plan, y, 4, save=sv, save_coff1=4, save_coff3=8 + E1)
+    y_inf = torch.full((B, H, W, S + 8), -7.0, device='cuda')
+    ops.fire_bridge(xg, 0, plan, y_inf, 4)
+    torch.cuda.synchronize()
+    yc, sc = y.cpu(), sv.cpu()
+    assert (yc[..., 4:4 + S] - ref).abs().max().item() <= _tol(ref)
+    assert torch.equal(yc, y_inf.cpu())
+    assert (sc[..., 4:4 + E1] - mid[..., :E1]).abs().max().item() <= _tol(mid)
+    assert (sc[..., 8 + E1:8 + E1 + E3] - mid[..., E1:]).abs().max().item() <= _tol(mid)
+    assert bool((sc[..., :4] == -5.0).all()) and bool((sc[..., 4 + E1:8 + E1] == -5.0).all()) and bool((sc[..., 8 + E1 + E3:] == -5.0).all())
+    with pytest.raises(ValueError):
+        ops.fire_bridge(xg, 0, plan, y, 4, save=sv, save_coff1=4, save_coff3=4 + E1 - 4)          # overlapping windows
+    with pytest.raises(ValueError):
+        ops.fire_bridge(xg, 0, plan, y, 4, save=sv[:, :, :-1], save_coff1=0)
+
+
+@pytest.mark.parametrize("C,E1,E3,S,cfg,pooled", [(16, 64, 64, 16, 12, False), (16, 64, 64, 32, 12, True), (8, 32, 40, 12, 12, False),
+                                                 (8, 80, 20, 28, 12, False), (32, 128, 128, 32, 6, False), (16, 64, 64, 16, 10, False)])
+def test_fire_bridge_plan_refresh_in_place(C, E1, E3, S, cfg, pooled):
+    """After an optimizer step the bridges' operands are rewritten IN PLACE by two batched launches (plans.refresh_bridge_plans: the
+    Winograd transform of the expand3x3 part + one scaled gather for everything else): bit-identical to a plan built from scratch on
+    the new parameter values, same buffers."""
+    from squeezedet_pytorch_amd import plans
+    ops = _ops()
+    mk = lambda seed: [t.cuda() for t in (_rand(E1, C, 1, 1, seed=seed), _rand(E1, seed=seed + 1), _rand(E3, C, 3, 3, seed=seed + 2),
+                                          _rand(E3, seed=seed + 3), _rand(S, E1 + E3, 1, 1, seed=seed + 4), _rand(S, seed=seed + 5))]
+    old, new = mk(100), mk(200)
+    plan = ops.FireBridgePlan(*old, cfg, pooled=pooled)
+    ptrs = (plan.w.data_ptr(), plan.sq_ops.data_ptr(), plan.bias_tab.data_ptr(), plan.sq_bias.data_ptr())
+    fresh = ops.FireBridgePlan(*new, cfg, pooled=pooled)
+    assert not torch.equal(plan.w, fresh.w)
+    plans.refresh_bridge_plans([(plan, *new)])
+    torch.cuda.synchronize()
+    for name in ('w', 'sq_ops', 'bias_tab', 'sq_bias'):
+        assert torch.equal(getattr(plan, name), getattr(fresh, name)), name
+    assert ptrs == (plan.w.data_ptr(), plan.sq_ops.data_ptr(), plan.bias_tab.data_ptr(), plan.sq_bias.data_ptr())
+
+
 @pytest.mark.parametrize("C,E1,E3,S,B,H,W,nseg", [
     (16, 64, 64, 32, 1, 8, 32, 1), (16, 64, 64, 32, 1, 8, 32, 2), (16, 64, 64, 32, 2, 9, 37, 1), (8, 32, 40, 12, 1, 5, 17, 1),
     (16, 48, 64, 16, 2, 12, 30, 3), (16, 64, 32, 24, 3, 13, 50, 2), (8, 16, 16, 32, 1, 24, 14, 6), (16, 64, 64, 32, 3, 96, 312, 4),
@@ -508,6 +593,72 @@ def test_fire_pool_bridge_one_launch(C, E1, E3, S, B, H, W, nseg):
     with pytest.raises(ValueError):
         ops.fire_bridge(_nhwc(x).cuda(), 0, plan, torch.empty(B, H, W, S, device='cuda'), 0)      # a pooled plan is not a plain bridge plan
     assert not ops.fire_pool_bridge_ok(32, E3, E1, S) and not ops.fire_pool_bridge_ok(C, E3, 128, S)
+
+
+@pytest.mark.parametrize("C,E1,E3,S,B,H,W,nseg", [
+    (16, 64, 64, 32, 1, 8, 32, 1), (16, 64, 64, 32, 1, 8, 32, 2), (16, 64, 64, 32, 2, 9, 37, 1), (8, 32, 40, 12, 1, 5, 17, 1),
+    (16, 48, 64, 16, 2, 12, 30, 3), (16, 64, 32, 24, 3, 13, 50, 2), (8, 16, 16, 32, 1, 24, 14, 6), (16, 64, 64, 32, 3, 96, 312, 4),
+    (8, 16, 8, 4, 1, 3, 3, 1), (16, 64, 64, 32, 1, 31, 45, 5), (16, 64, 64, 32, 2, 7, 100, 9), (16, 64, 64, 32, 4, 96, 312, 24),
+])
+def test_fire_pool_bridge_storing_form(C, E1, E3, S, B, H, W, nseg):
+    """Training form of the Fire -> pool -> Fire bridge (sqd_fire_pool_bridge_save_fwd).  The squeeze output is bit-identical to the
+    inference bridge; the stored pooled tensor and the arg-max / ReLU codes are BIT-identical to the max-pool kernel of the unfused
+    training forward (ops.maxpool(relu_codes=True)) applied to the expand output of the same kernel family (ops.fire_wino cfg 12: the
+    same matrix-core summation order), i.e. first window position holding the maximum, 15 where it is not > 0, clipped windows at
+    the right / bottom edge, segments and carried rows included; the pooled values also equal the reference's modules in fp32
+    (src/model/squeezedet.py:18-22, 47-52); bytes outside the windows untouched."""
+    ops = _ops()
+    x = F.relu(_rand(B, C, H, W, seed=61))
+    w1 = _rand(E1, C, 1, 1, seed=62, scale=(2.0 / C) ** 0.5); b1 = _rand(E1, seed=63, scale=0.1)
+    w3 = _rand(E3, C, 3, 3, seed=64, scale=(2.0 / (C * 9)) ** 0.5); b3 = _rand(E3, seed=65, scale=0.1)
+    ws = _rand(S, E1 + E3, 1, 1, seed=66, scale=(2.0 / (E1 + E3)) ** 0.5); bs = _rand(S, seed=67, scale=0.1)
+    mid = torch.cat([F.relu(F.conv2d(x, w1, b1)), F.relu(F.conv2d(x, w3, b3, padding=1))], 1)
+    pref = _nhwc(F.max_pool2d(mid, 3, 2, ceil_mode=True))
+    plan = ops.FireBridgePlan(w1.cuda(), b1.cuda(), w3.cuda(), b3.cuda(), ws.cuda(), bs.cuda(), 12, pooled=True)
+    Hp, Wp = ops.pool_out_size(H, W)
+    xg = _nhwc(x).cuda()
+    y = torch.full((B, Hp, Wp, S + 8), -7.0, device='cuda')
+    sv = torch.full((B, Hp, Wp, E1 + E3 + 8), -5.0, device='cuda')
+    cd = torch.full((B, Hp, Wp, E1 + E3 + 8), 99, dtype=torch.uint8, device='cuda')
+    ops.fire_pool_bridge(xg, 0, plan, y, 4, nseg=nseg, save=sv, codes=cd, save_coff1=4, save_coff3=4 + E1)
+    y_inf = torch.full((B, Hp, Wp, S + 8), -7.0, device='cuda')
+    ops.fire_pool_bridge(xg, 0, plan, y_inf, 4, nseg=nseg)
+    # the unfused training forward on the same expand arithmetic
+    out = torch.empty(B, H, W, E1 + E3, device='cuda')
+    ops.fire_wino(xg, 0, ops.FireWinoPlan(w1.cuda(), b1.cuda(), w3.cuda(), b3.cuda(), 12), out, 0, E1)
+    am = torch.empty(B, Hp, Wp, E1 + E3, dtype=torch.uint8, device='cuda')
+    pooled = ops.maxpool(out, argmax=am, relu_codes=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_inf)
+    assert torch.equal(sv[..., 4:4 + E1 + E3], pooled)
+    assert torch.equal(cd[..., 4:4 + E1 + E3], am)
+    assert (sv[..., 4:4 + E1 + E3].cpu() - pref).abs().max().item() <= _tol(pref)
+    assert bool((sv[..., :4] == -5.0).all()) and bool((sv[..., 4 + E1 + E3:] == -5.0).all())
+    assert bool((cd[..., :4] == 99).all()) and bool((cd[..., 4 + E1 + E3:] == 99).all())
+    with pytest.raises(ValueError):
+        ops.fire_pool_bridge(xg, 0, plan, y, 4, nseg=nseg, save=sv)                                   # save without codes
+
+
+def test_fire_pool_bridge_codes_on_exact_ties():
+    """Every window position equal (zero weights, the outputs are the biases): the code is the FIRST position (0) where the bias is
+    positive and 15 where it is not -- the tie rule of MaxPool2d's CPU scan that the backward relies on."""
+    ops = _ops()
+    C, E1, E3, S, B, H, W = 16, 64, 64, 32, 2, 13, 31
+    x = F.relu(_rand(B, C, H, W, seed=81))
+    z1, z3 = torch.zeros(E1, C, 1, 1), torch.zeros(E3, C, 3, 3)
+    b1 = _rand(E1, seed=82); b3 = _rand(E3, seed=83)
+    ws = _rand(S, E1 + E3, 1, 1, seed=84); bs = _rand(S, seed=85)
+    plan = ops.FireBridgePlan(z1.cuda(), b1.cuda(), z3.cuda(), b3.cuda(), ws.cuda(), bs.cuda(), 12, pooled=True)
+    Hp, Wp = ops.pool_out_size(H, W)
+    y = torch.empty(B, Hp, Wp, S, device='cuda')
+    sv = torch.empty(B, Hp, Wp, E1 + E3, device='cuda')
+    cd = torch.empty(B, Hp, Wp, E1 + E3, dtype=torch.uint8, device='cuda')
+    ops.fire_pool_bridge(_nhwc(x).cuda(), 0, plan, y, 0, nseg=2, save=sv, codes=cd)
+    torch.cuda.synchronize()
+    bias = torch.cat([b1, b3])
+    want = torch.where(bias > 0, torch.zeros(E1 + E3, dtype=torch.uint8), torch.full((E1 + E3,), 15, dtype=torch.uint8))
+    assert torch.equal(cd.cpu(), want.view(1, 1, 1, -1).expand(B, Hp, Wp, -1))
+    assert torch.equal(sv.cpu(), F.relu(bias).view(1, 1, 1, -1).expand(B, Hp, Wp, -1))
 
 
 @pytest.mark.parametrize("C,E1,E3,B,H,W", [
