@@ -24,9 +24,12 @@ def short_name(k):
     if m: return f"conv_ws<{m.group(1)},{m.group(2)}>"
     m = re.match(r"conv_wino_pipe_kernel<(\d+), (\d+), (true|false)", short)
     if m: return f"conv_wino_{'us' if m.group(3) == 'true' else 'dp'}<{m.group(1)},{m.group(2)}>"
+    m = re.match(r"fire_poolbridge16_kernel<\d+, \d+, (true|false)>", short)           # <NSQ, NCH, SAVE>: SAVE = the training form (round 4)
+    if m: return "fire_pool_bridge_save" if m.group(1) == "true" else "fire_pool_bridge"
     if short.startswith("fire_poolbridge16_kernel"): return "fire_pool_bridge"
-    m = re.match(r"fire_bridge(16)?_kernel<[^>]*?(true|false)?>", short)
-    if m: return "fire_wino16" if (m.group(1) and m.group(2) == "false") else "fire_bridge"
+    m = re.match(r"fire_bridge16_kernel<\d+, (\d+), \d+>", short)                      # <NSQ, MODE, NCH>: 0 = plain fused expand, 1 = bridge, 2 = storing bridge
+    if m: return {"0": "fire_wino16", "1": "fire_bridge", "2": "fire_bridge_save"}[m.group(1)]
+    if short.startswith("fire_bridge_kernel<"): return "fire_bridge"
     m = re.match(r"(maxpool_fwd|maxpool_bwd)_kernel", short)
     if m: return m.group(1)
     m = re.match(r"wino_wgrad_kernel<", short)
@@ -34,7 +37,8 @@ def short_name(k):
     m = re.match(r"conv_wgrad_kernel<(\d+), \d+, \d+, \d+(, (true|false))?>", short)
     if m: return "squeeze_bwd" if m.group(3) == "true" else f"conv_wgrad<{m.group(1)}>"
     m = re.match(r"stem_wave_kernel<\d+, \d+, (true|false), (\d+)>", short)           # the wave-autonomous 3x3 stem (round 3): same bench name as the
-    if m: return "stem_pool_sq<3>" if m.group(2) != "0" else "stem_pool<3>"           # workgroup kernel; SQ > 0 = with the first Fire's squeeze
+    if m:                                                                             # workgroup kernel; SQ > 0 = with the first Fire's squeeze
+        return ("stem_pool_sq_train<3>" if m.group(1) == "true" else "stem_pool_sq<3>") if m.group(2) != "0" else "stem_pool<3>"
     if short.startswith("stem_wgrad_gather_kernel<"): return "stem_wgrad_pooled<3>"     # ... and so does the gather form of its weight gradient
     m = re.match(r"stem_wgrad_pooled_kernel<(\d+),", short)
     if m: return f"stem_wgrad_pooled<{m.group(1)}>"

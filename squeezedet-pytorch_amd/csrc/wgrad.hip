@@ -31,6 +31,7 @@ struct WgradArgs {
   // [N][C] (OIHW, 1x1), the data-gradient output window and whether x's ReLU mask applies to it
   const float* w; float* dx;
   int dx_pitch, dx_coff, dx_mask;
+  int dg_vmcnt0;        // A/B switch (SQD_SQBWD_VMCNT0=1): the block barrier waits for EVERYTHING instead of the counted wait
 };
 
 // LDS tiles are pixel-major rows of exactly TN*16 (dY) / TC*16 (X) floats, filled by LDS-DMA
@@ -202,8 +203,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   // DG: the data-gradient stores go through a buffer resource and are ALWAYS issued (a lane without a pixel / channel carries an
   // out-of-range offset: the hardware drops it), DG_ST per wave and block, so the block barrier can wait with a COUNTED vmcnt that
-  // covers the older LDS-DMA of this block but leaves the previous block's stores in flight (vector-memory operations retire in
-  // issue order); a vmcnt(0) there exposed the write latency of every block.
+  // covers the older LDS-DMA of this block but leaves the previous block's stores in flight; a vmcnt(0) there exposed the write
+  // latency of every block.  This relies on (i) vmcnt counting loads, stores and LDS-DMA TOGETHER and retiring them in issue order on
+  // gfx9-family parts (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N)": "Loads, stores, atomics and LDS-DMA count together, in issue
+  // order (flat_* excepted)" -- no flat instruction is used here; the same model LLVM's SIInsertWaitcnts uses for gfx9), and (ii) the
+  // compiler placing no vector-memory instruction of its own -- a scratch reload -- between the stores and the wait:
+  // tests/test_build_spills.py asserts zero spills / zero scratch for every DG instantiation.  SQD_SQBWD_VMCNT0=1 switches the
+  // wait to vmcnt(0) for A/B parity runs (tests/test_training_gpu.py).
   constexpr int DG_ST = DG ? ((TH * TC + 3) / 4) : 0;
   typedef unsigned int wg_u32x4_t __attribute__((ext_vector_type(4)));
   __amdgpu_buffer_rsrc_t dxres;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   if (pb < a.nblocks) dma_block(pb, 0);
   for (; pb < a.nblocks; pb += (int)gridDim.x) {
     if (DG) {
-      if (first_block) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (first_block || a.dg_vmcnt0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DG_ST) : "memory");
       first_block = false;
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -462,7 +468,7 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
   a.N = N; a.dy_pitch = dy_pitch; a.dy_coff = dy_coff; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.total_px = (long long)B * H * W;
   a.slab_stride = (long long)N * taps * C + N;
-  a.w = nullptr; a.dx = nullptr; a.dx_pitch = a.dx_coff = a.dx_mask = 0;
+  a.w = nullptr; a.dx = nullptr; a.dx_pitch = a.dx_coff = a.dx_mask = 0; a.dg_vmcnt0 = 0;
   hipStream_t s = (hipStream_t)stream;
   const int tn = N >= 64 ? 4 : sqd_cdiv(N, 16);
   int rc = SQD_ERR_UNSUPPORTED;
@@ -527,6 +533,7 @@ extern "C" int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_o
   a.total_px = (long long)B * H * W;
   a.slab_stride = (long long)N * C + N;
   a.w = w_oihw; a.dx = dx; a.dx_pitch = dx_pitch; a.dx_coff = dx_coff; a.dx_mask = relu_mask;
+  { const char* e = getenv("SQD_SQBWD_VMCNT0"); a.dg_vmcnt0 = (e && e[0] == '1') ? 1 : 0; }
   hipStream_t s = (hipStream_t)stream;
   const int tn = N > 96 ? 8 : (N > 64 ? 6 : sqd_cdiv(N, 16));
   const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);

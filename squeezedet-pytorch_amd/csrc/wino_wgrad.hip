@@ -36,6 +36,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_ww_t;
 template <int TN, int TC>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(TN >= 4 && (TC == 1 || TC == 2), "the bank swizzle swaps 16-channel blocks pairwise inside the first four");
   constexpr int CHD = TN * 16, CHX = TC * 16;
   constexpr int DQ = TN * 4, XQ = TC * 4;                  // 16-byte slots per pixel
   constexpr int DSLOTS = 64 * DQ, D_IT = DSLOTS / 256;
@@ -56,8 +57,12 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 #pragma unroll
   for (int it = 0; it < D_IT; ++it) {
     const int slot = it * 256 + tid;
-    const int px = slot / DQ, chq = slot - px * DQ;
+    const int px = slot / DQ, chs = slot - px * DQ;
     const int row = px >> 4, col = px & 15;
+    // bank swizzle: a lane quad g reads pixel columns 4g .. 4g + 3, and four columns are a multiple of 32 words apart, so the two
+    // quads of a 32-lane LDS group would hit the same 16 banks (2-way conflict on every ds_read_b32 of the transform).  Pixels of odd
+    // column quads therefore hold their first four 16-channel blocks pairwise swapped (slot chs holds channel quad chs ^ 4)
+    const int chq = (chs < 16) ? (chs ^ (((col >> 2) & 1) << 2)) : chs;
     d_key[it] = (n0 + 4 * chq < a.N) ? (row << 8 | col) : -1;        // channels past N (partial last block) stay zero
     d_offB[it] = ((row * a.W + col) * a.dy_pitch + 4 * chq) * 4;
   }
@@ -65,9 +70,10 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
     const int slot = it * 256 + tid;
-    const int px = slot / XQ, chq = slot - px * XQ;
-    const bool real = px < 108 && c0 + 4 * chq < a.C;       // channels past C (partial last block) stay zero
+    const int px = slot / XQ, chs = slot - px * XQ;
     const int r = px / 18, c = px - r * 18;
+    const int chq = (TC == 2) ? (chs ^ (((c >> 2) & 1) << 2)) : chs;      // (the same swizzle on the patch: its two 16-channel blocks)
+    const bool real = px < 108 && c0 + 4 * chq < a.C;       // channels past C (partial last block) stay zero
     x_key[it] = real ? (r << 8 | c) : -1;
     x_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * chq) * 4 : 0;
   }
@@ -132,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
   // lane bases (floats): dY element (px, ch) at px*CHD + ch, X element at px*CHX + ch; the quad's 4 pixel columns 4g..
   const int dL0 = (r0 * 16 + 4 * g) * CHD + lr, dL1 = (1 * 16 + 4 * g) * CHD + lr;
   const int xL1 = (i1 * 18 + 4 * g) * CHX + lr, xL2 = (i2 * 18 + 4 * g) * CHX + lr;
+  const int gsw = (g & 1) * 16;                               // the lane quad's swizzle (floats): block b of its pixels sits at (16 b) ^ gsw
 
   f32x4 acc[4][TN][TC], accb[TN];
 #pragma unroll
@@ -162,8 +169,10 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
       f32x2 tt[6];                                           // row-transformed patch columns 0..5 of the quad, pair over ty
 #pragma unroll
       for (int jj = 0; jj < 6; ++jj) {
-        const f32x2 d1 = {xP1[(0 * 18 + jj) * CHX + cbk * 16], xP1[(2 * 18 + jj) * CHX + cbk * 16]};
-        const f32x2 d2 = {xP2[(0 * 18 + jj) * CHX + cbk * 16], xP2[(2 * 18 + jj) * CHX + cbk * 16]};
+        // (patch column 4g + jj: columns 4, 5 of the quad belong to the next column quad)
+        const int xo = (TC == 2) ? ((cbk * 16) ^ gsw ^ ((jj >> 2) << 4)) : cbk * 16;
+        const f32x2 d1 = {xP1[(0 * 18 + jj) * CHX + xo], xP1[(2 * 18 + jj) * CHX + xo]};
+        const f32x2 d2 = {xP2[(0 * 18 + jj) * CHX + xo], xP2[(2 * 18 + jj) * CHX + xo]};
         tt[jj] = __builtin_elementwise_fma(sx2, d2, d1);
       }
 #pragma unroll
@@ -183,8 +192,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
         f32x2 rp[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const f32x2 y0 = {dP0[(2 * txl + j) * CHD + nb * 16], dP0[(2 * 16 + 2 * txl + j) * CHD + nb * 16]};
-          const f32x2 y1 = {dP1[(2 * txl + j) * CHD + nb * 16], dP1[(2 * 16 + 2 * txl + j) * CHD + nb * 16]};
+          const int yo = (nb < 4) ? ((nb * 16) ^ gsw) : nb * 16;
+          const f32x2 y0 = {dP0[(2 * txl + j) * CHD + yo], dP0[(2 * 16 + 2 * txl + j) * CHD + yo]};
+          const f32x2 y1 = {dP1[(2 * txl + j) * CHD + yo], dP1[(2 * 16 + 2 * txl + j) * CHD + yo]};
           rp[j] = __builtin_elementwise_fma(sd2, y1, y0);
         }
         const f32x2 m0 = rp[0], m1 = rp[0] + rp[1], m2 = rp[0] - rp[1], m3 = rp[1];

@@ -556,12 +556,21 @@ def maxpool_bwd(dy, argmax, in_hw, out=None, relu_src=None):
         out = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
     if relu_src is not None and (tuple(relu_src.shape) != (B, H, W, C) or not relu_src.is_contiguous()):
         raise ValueError('maxpool_bwd: relu_src must match the pool input')
+    if not (dy.is_contiguous() and argmax.is_contiguous() and out.is_contiguous()):
+        raise ValueError('maxpool_bwd: dy, argmax and out must be contiguous')
     br = _Bracket('maxpool_bwd', f'poolbwd C{C} {H}x{W}', 0.0, 4.0 * B * C * (H * W * (2 if relu_src is not None else 1) + Ho * Wo * 1.25)) if timing._timer is not None else None
-    rc = nat.lib().sqd_maxpool3x3s2_ceil_bwd(nat.ptr(dy), nat.ptr(argmax), nat.ptr(out), nat.ptr(relu_src), B, H, W, C,
-                                             nat.stream_handle(dy.device))
+    # the kernel's grid carries (image, row pair) in blockIdx.y (<= 65535): larger batches go in slices of whole images
+    per = max(1, 65535 // ((H + 1) // 2))
+    if (H + 1) // 2 > 65535:
+        raise ValueError(f'maxpool_bwd: {H} input rows exceed the kernel\'s grid (at most {2 * 65535})')
+    for b0 in range(0, B, per):
+        b1 = min(B, b0 + per)
+        rc = nat.lib().sqd_maxpool3x3s2_ceil_bwd(nat.ptr(dy[b0:b1]), nat.ptr(argmax[b0:b1]), nat.ptr(out[b0:b1]),
+                                                 nat.ptr(relu_src[b0:b1]) if relu_src is not None else None, b1 - b0, H, W, C,
+                                                 nat.stream_handle(dy.device))
+        nat.check(rc, 'sqd_maxpool3x3s2_ceil_bwd')
     if br is not None:
         br.done()
-    nat.check(rc, 'sqd_maxpool3x3s2_ceil_bwd')
     return out
 
 

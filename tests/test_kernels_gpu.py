@@ -119,6 +119,24 @@ def test_maxpool_fwd_bwd(C, H, W):
     assert (dx.cpu() - _nhwc(x.grad)).abs().max().item() <= 1e-6
 
 
+def test_maxpool_bwd_batches_beyond_one_grid():
+    """The backward kernel's grid carries (image, row pair) in blockIdx.y (<= 65535 per launch): ops.maxpool_bwd slices larger batches
+    into launches of whole images instead of refusing them (B * ceil(H / 2) = 40000 * 2 here); bit-equal to the per-slice result of
+    autograd."""
+    ops = _ops()
+    B, C, H, W = 40000, 4, 4, 5
+    x = _rand(B, C, H, W, seed=18).requires_grad_(True)
+    ref = F.max_pool2d(x, 3, 2, ceil_mode=True)
+    dy = _rand(*ref.shape, seed=19)
+    ref.backward(dy)
+    xg = _nhwc(x.detach()).cuda()
+    am = torch.empty(*_nhwc(ref.detach()).shape, dtype=torch.uint8, device='cuda')
+    half = B // 2
+    ops.maxpool(xg[:half], argmax=am[:half]); ops.maxpool(xg[half:], argmax=am[half:])
+    dx = ops.maxpool_bwd(_nhwc(dy).cuda(), am, (H, W))
+    assert (dx.cpu() - _nhwc(x.grad)).abs().max().item() <= 1e-6
+
+
 @pytest.mark.parametrize("C,H,W", [(64, 32, 48), (128, 17, 23), (8, 4, 4), (128, 96, 312)])
 def test_maxpool_relu_codes_carry_the_mask(C, H, W):
     """Training path: the pool input is a ReLU output.  ``maxpool(relu_codes=True)`` writes code 15 where the pooled value is not
