@@ -33,6 +33,25 @@ struct WwArgs {
 };
 typedef __attribute__((address_space(3))) void* lds_ptr_ww_t;
 
+// Diagnostic build only (-DSQD_WW_STAMP, scratch/diag/ww_stamp.sh; never in libsqdhip.so): s_memtime stamps around the segments of the
+// group loop, summed per wave in scalar registers and stored once to a debug buffer of their own (cdna_hip_programming.md, "In-kernel
+// stamps"): [workgroup][wave][8] = {wait + barrier, DMA issue, V transform, dM transforms + MFMAs, epilogue, whole kernel, groups, 0}.
+#ifdef SQD_WW_STAMP
+__device__ unsigned long long* sqd_ww_dbg = nullptr;
+extern "C" int sqd_ww_set_debug(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(sqd_ww_dbg), &p, sizeof(p)) == hipSuccess ? SQD_OK : SQD_ERR_LAUNCH;
+}
+#define WW_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WW_STAMP(t) do { } while (0)
+#endif
+
+// Residency: two workgroups per CU.  The stamped timeline (scratch/diag/run_ww_stamp.py, profiles/r04t_ww_stamp.log) shows a wave spending
+// ~40 % of a group's period outside its MFMAs: 11-22 % issuing the next group's eight LDS-DMA instructions (accepted at ~230 cycles
+// each when the four waves of a workgroup issue together: the CU takes in ~11-28 B/clk by LDS-DMA, MI355X_MICROARCH.md "ldsdma-fill" /
+// "LDS-DMA piece issue cost"), 7-11 % in the V transform, 7-10 % at the wait + barrier; the epilogue is 8-16 % of a wave's time where a
+// workgroup only sees ~10 groups.  A THIRD workgroup per CU for the 64 x 16 form (<= 168 registers, 48 KB of LDS: it fits) was
+// measured neutral (profiles/r04u_ww_occupancy3.log): three workgroups' tiles exceed what the CU's LDS-DMA path takes in per period.
 template <int TN, int TC>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -151,11 +170,18 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
   for (int i = 0; i < TN; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int buf = 0;
+#ifdef SQD_WW_STAMP
+  unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, t_begin = 0, sum_wait = 0, sum_issue = 0, sum_v = 0, sum_mm = 0, ngr = 0;
+  WW_STAMP(t_begin);
+#endif
   issue(s, 0);
   for (int q = s; q < a.ngroups; q += a.S) {
+    WW_STAMP(ta);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the group's DMA has landed ...
     __syncthreads();                                         // ... and is published; the other buffer is free again
+    WW_STAMP(tb);
     if (q + a.S < a.ngroups) issue(q + a.S, buf ^ 1);
+    WW_STAMP(tc);
     const float* const dP0 = dyB + buf * DSLOTS * 4 + dL0;
     const float* const dP1 = dyB + buf * DSLOTS * 4 + dL1;
     const float* const xP1 = xB + buf * XSLOTS * 4 + xL1;
@@ -183,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
         else          { bfr[cbk][0].hi = v0; bfr[cbk][1].hi = v1; bfr[cbk][2].hi = v2; bfr[cbk][3].hi = v3; }
       }
     }
+    WW_STAMP(td);
     // ---- per output-channel block: dM = A dY A^T, row xi, then the MFMAs over (nu, cb, k-step) ----
 #pragma unroll
     for (int nb = 0; nb < TN; ++nb) {
@@ -212,8 +239,16 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
         for (int t = 0; t < 4; ++t) accb[nb] = mfma16(afr[1][t], 1.0f, accb[nb]);
       }
     }
+    WW_STAMP(te);
+#ifdef SQD_WW_STAMP
+    sum_wait += tb - ta; sum_issue += tc - tb; sum_v += td - tc; sum_mm += te - td; ngr += 1;
+#endif
     buf ^= 1;
   }
+#ifdef SQD_WW_STAMP
+  unsigned long long t_loop_end = 0;
+  WW_STAMP(t_loop_end);
+#endif
 
   // ---- dg = G^T dU G: nu sum in registers, xi sum across the waves through LDS (fixed order) ----
   float* const sl = a.slab + (long long)s * a.slab_stride;
@@ -257,6 +292,17 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
       for (int i = 0; i < 4; ++i) sl[nw + n0 + nb * 16 + 4 * g + i] = v[i];
     }
   }
+#ifdef SQD_WW_STAMP
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long t_end = 0;
+    WW_STAMP(t_end);
+    if (sqd_ww_dbg && lane == 0) {
+      unsigned long long* d = sqd_ww_dbg + ((long long)blockIdx.x * 4 + xi) * 8;
+      d[0] = sum_wait; d[1] = sum_issue; d[2] = sum_v; d[3] = sum_mm; d[4] = t_end - t_loop_end; d[5] = t_end - t_begin; d[6] = ngr; d[7] = t_begin;
+    }
+  }
+#endif
 #endif
 }
 
