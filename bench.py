@@ -627,9 +627,10 @@ def main():
                          else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on {where}'),
             'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
             'layers': {f'{k} | {tag}': round(t[1] * 1e3, 1) for k, v in summ.items() for tag, t in v['tags'].items()},      # us per step
-            'whole_network': {'tflops': round(value * gf / 1e3, 2),
-                              'frac_of_fp32_mfma_peak': round(value / joined * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
-                              'note': 'direct-form flops of the network; layers run by the Winograd kernel execute 2.25x fewer'},
+            'whole_network': {'direct_form_tflops': round(value * gf / 1e3, 2),
+                              'direct_form_tflops_over_fp32_mfma_peak': round(value / joined * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              'note': 'NOT a utilisation: direct-form flops of the network / step time / peak; the layers run by the Winograd '
+                                      'kernels execute 2.25x fewer multiply-adds (the achieved fraction of the matrix pipe is roofline.frac)'},
         }
         if not args.no_pipeline and args.arch == 'squeezedet':
             try:

@@ -48,3 +48,24 @@ def test_stem_family_randomised_sweep(capsys, monkeypatch):
     finally:
         sys.argv = argv
     assert "cases ok" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_storing_bridges_randomised_sweep(capsys):
+    """tools/fuzz_bridge.py, fixed seed, short budget: the storing forms of the fused launches of the training forward (Fire -> Fire
+    bridge, Fire -> pool -> Fire bridge with pooled tensor + arg-max / ReLU codes, stem + squeeze) bit for bit against the launches
+    they replace, and the in-place refresh of the bridges' operands against a fresh packing, on random shapes / windows / segments."""
+    argv = sys.argv
+    sys.argv = ["fuzz_bridge.py", "12", "20261005"]
+    try:
+        cwd = os.getcwd()
+        os.chdir(ROOT)
+        try:
+            runpy.run_path(os.path.join(ROOT, "tools", "fuzz_bridge.py"), run_name="__main__")
+        except SystemExit as e:
+            assert not e.code, capsys.readouterr().out
+        finally:
+            os.chdir(cwd)
+    finally:
+        sys.argv = argv
+    assert "OK {" in capsys.readouterr().out
