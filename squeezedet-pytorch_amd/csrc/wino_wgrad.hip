@@ -47,11 +47,11 @@ extern "C" int sqd_ww_set_debug(unsigned long long* p) {
 #endif
 
 // Residency: two workgroups per CU.  The stamped timeline (scratch/diag/run_ww_stamp.py, profiles/r04t_ww_stamp.log) shows a wave spending
-// ~40 % of a group's period outside its MFMAs: 11-22 % issuing the next group's eight LDS-DMA instructions (accepted at ~230 cycles
-// each when the four waves of a workgroup issue together: the CU takes in ~11-28 B/clk by LDS-DMA, MI355X_MICROARCH.md "ldsdma-fill" /
-// "LDS-DMA piece issue cost"), 7-11 % in the V transform, 7-10 % at the wait + barrier; the epilogue is 8-16 % of a wave's time where a
-// workgroup only sees ~10 groups.  A THIRD workgroup per CU for the 64 x 16 form (<= 168 registers, 48 KB of LDS: it fits) was
-// measured neutral (profiles/r04u_ww_occupancy3.log): three workgroups' tiles exceed what the CU's LDS-DMA path takes in per period.
+// ~40 % of a group's period outside its MFMAs: 10-22 % issuing the next group's eight LDS-DMA pieces in one burst behind the barrier
+// (~230 cycles per piece when the four waves issue together; 38 cycles per piece when spread over MFMAs in isolation:
+// profiles/r04zz_stage_issue_microbench.log), 7-11 % in the V transform, 7-10 % at the wait + barrier; the epilogue is 8-16 % of a wave's
+// time where a workgroup only sees ~10 groups.  A THIRD workgroup per CU for the 64 x 16 form (<= 168 registers, 48 KB of LDS: it fits)
+// was measured neutral (profiles/r04u_ww_occupancy3.log).
 template <int TN, int TC>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -266,6 +266,8 @@ class FireBridgePlan:
         self.sq_ops = self.aux[:n0].view(so.shape)
         self.bias_tab = self.aux[n0:n1].view(bt.shape)
         self.sq_bias = self.aux[n1:].view(sb.shape)
+        if b1 is not None and b3 is not None and bsq is not None:
+            self.make_maps()           # (here, not at the first refresh: that one may run inside a hipGraph capture, where host-built tensors are illegal)
 
     def _build(self, w1, b1, w3, b3, wsq, bsq):
         """(u, sq_ops, bias_tab, sq_bias) of these parameter values."""
