@@ -12,7 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int FORM, int M, int P>
+template <int FORM, int M, int P, int PAT = 0, int NLDS = 0>
 __global__ __launch_bounds__(256, 2) void k(float* out, long long* clk, int iters, const float* gin, int window_floats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256, 2) void k(float* out, long long* clk, int iter
   f32x4 st[FORM == 2 ? P : 1];
   for (int i = 0; i < (FORM == 2 ? P : 1); ++i) st[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   unsigned base = ((blockIdx.x * 4 + wave) * 64 * 1024) % (unsigned)(window_floats * 4 - 64 * 1024 * 4);
-  const int voff = lane * 16;
+  // PAT 0: 1 KB contiguous per piece; PAT 1: four 256-byte runs 3 KB apart (a 64-channel window of a 768-channel NHWC tensor);
+  // PAT 2: sixteen 64-byte runs 512 B apart (a 16-channel window of a 128-channel tensor)
+  const int voff = PAT == 0 ? lane * 16 : (PAT == 1 ? (lane >> 4) * 3072 + (lane & 15) * 16 : (lane >> 2) * 512 + (lane & 3) * 16);
   __syncthreads();
   const long long t0 = wall_clock64();
   for (int it = 0; it < iters; ++it) {
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(256, 2) void k(float* out, long long* clk, int iter
         if (FORM == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(res, (lds_ptr_t)(my + (buf * P + p) * 256), 16, voff, (int)(soff + p * 1024), 0, 0);
         if (FORM == 2) st[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res, voff, (int)(soff + p * 1024), 0));
       }
-      const float bb = (FORM != 0 && (m & 15) == 0) ? my[((buf ^ 1) * P) * 256 + lane] : b;      // (the staged data is consumed: one LDS read per 16 MFMAs)
+      float bb = (FORM != 0 && (m & 15) == 0) ? my[((buf ^ 1) * P) * 256 + lane] : b;      // (the staged data is consumed: one LDS read per 16 MFMAs)
+      if (NLDS > 0 && (m % (M / NLDS)) == 1) bb += my[((buf ^ 1) * P) * 256 + ((lane + m) & 255)];      // extra ds_read_b32 traffic: NLDS per iteration
       acc[m & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc[m & 15], 0, 0, 0);
     }
   }
@@ -62,11 +65,11 @@ __global__ __launch_bounds__(256, 2) void k(float* out, long long* clk, int iter
 }
 
 static float* gin; static const int WINDOW = 2 * 1024 * 1024;   // floats (8 MB)
-template <int FORM, int M, int P>
+template <int FORM, int M, int P, int PAT = 0, int NLDS = 0>
 static double run(const char* name, int wgs_per_cu, int iters) {
   float* out; long long* clk; hipMalloc(&out, 8); const int nwg = 256 * wgs_per_cu; hipMalloc(&clk, nwg * 4 * 8);
   const size_t lds = (size_t)4 * 2 * P * 1024;
-  auto kern = k<FORM, M, P>;
+  auto kern = k<FORM, M, P, PAT, NLDS>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   double best = 1e30;
   for (int rep = 0; rep < 3; ++rep) {
@@ -94,6 +97,11 @@ int main() {
     run<2, 32, 4>("register staging, short stage", w, it);
     run<1, 32, 8>("LDS-DMA spread, 8 pieces per 32 MFMAs", w, it);
     run<2, 32, 8>("register staging, 8 pieces per 32 MFMAs", w, it);
+    run<1, 64, 8, 1>("LDS-DMA spread, 4 x 256 B runs per piece", w, it);
+    run<1, 64, 8, 2>("LDS-DMA spread, 16 x 64 B runs per piece", w, it);
+    run<1, 64, 8, 0, 32>("LDS-DMA spread + 32 ds_read_b32", w, it);
+    run<1, 64, 8, 1, 64>("LDS-DMA 4 x 256 B + 64 ds_read_b32", w, it);
+    run<3, 64, 8, 1, 64>("LDS-DMA burst 4 x 256 B + 64 ds_read_b32", w, it);
   }
   return 0;
 }

@@ -2,6 +2,8 @@
 // the direct kernels of wgrad.hip.  Built without the SI load/store optimiser (Makefile): it would pair the transform's
 // ds_read_b32 by address adjacency, not by the (tile row 0, tile row 1) register pairs the packed arithmetic works on.
 #include "sqd_common.h"
+#include <utility>
+#include <type_traits>
 
 extern "C" int sqd_wgrad_reduce_launch(const float* slab, float* dw, float* db, int S, long long slab_stride, int N, int C, int taps,
                                        void* stream);
@@ -32,6 +34,11 @@ struct WwArgs {
   long long slab_stride;
 };
 typedef __attribute__((address_space(3))) void* lds_ptr_ww_t;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ww_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); ww_static_for<I + 1, N>(f); }
+}
 
 // Diagnostic build only (-DSQD_WW_STAMP, scratch/diag/ww_stamp.sh; never in libsqdhip.so): s_memtime stamps around the segments of the
 // group loop, summed per wave in scalar registers and stored once to a debug buffer of their own (cdna_hip_programming.md, "In-kernel
@@ -68,7 +75,21 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int xi = __builtin_amdgcn_readfirstlane(wv);
+  // Which (split, channel-block pair) this workgroup owns.  All block pairs of ONE split read the same pixel groups (the dY tile is
+  // re-read by every input-channel block, the X patch by every output-channel block), so they should share an XCD's L2: positions are
+  // split-major and the workgroups of an XCD own a contiguous run of positions (sqd_xcd_contiguous) -- each pixel group then
+  // crosses the fabric into one L2 instead of into several, and the re-reads come back at L2-hit latency.  SQD_WW_XCD=0: the old
+  // block-pair-major order (A/B builds).
+#ifndef SQD_WW_XCD
+#define SQD_WW_XCD 1
+#endif
+#if SQD_WW_XCD
+  const int ntile = (int)gridDim.x / a.S;
+  const int pos = sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int s = pos / ntile, bg = pos - s * ntile;
+#else
   const int s = (int)blockIdx.x % a.S, bg = (int)blockIdx.x / a.S;
+#endif
   const int ng = bg / a.ncg, cg = bg - ng * a.ncg;
   const int n0 = ng * CHD, c0 = cg * CHX;
 
@@ -107,40 +128,48 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
       (void*)(a.x + a.x_coff + c0 - (long long)(a.W + 1) * a.x_pitch), 0, 0x7ffffff0, 0x00020000);
   const int wv_s = xi;
 
-  auto issue = [&](int q, int buf) {                         // DMA of group q into buffer buf (all wave-uniform but the offsets)
+  // DMA of a group into a buffer, one 1 KB piece (a wave instruction) at a time: pieces 0 .. D_IT - 1 are the dY tile, D_IT .. NPIECE - 1
+  // the X patch.  Everything but the lane offsets is wave-uniform.  The pieces of the NEXT group are issued between the MFMA blocks of
+  // the current one (the other buffer is free from the barrier on): issued as one burst behind the barrier they cost the wave ~230
+  // cycles each (profiles/r04t_ww_stamp.log), spread over matrix work ~40 (profiles/r04zz_stage_issue_microbench.log).
+  constexpr int NPIECE = D_IT + X_IT;
+  struct GroupDma { int y0, x0; unsigned soffD, soffX; bool inner; };
+  auto group_dma = [&](int q) {
+    GroupDma gd;
     const int gxi = q % a.gxn; int t = q / a.gxn;
     const int gyi = t % a.gyn; const int b = t / a.gyn;
-    const int y0 = gyi * 4, x0 = gxi * 16;
-    const long long p0 = ((long long)b * a.H + y0) * a.W + x0;
-    const unsigned soffD = (unsigned)(p0 * a.dy_pitch * 4), soffX = (unsigned)(p0 * a.x_pitch * 4);
+    gd.y0 = gyi * 4; gd.x0 = gxi * 16;
+    const long long p0 = ((long long)b * a.H + gd.y0) * a.W + gd.x0;
+    gd.soffD = (unsigned)(p0 * a.dy_pitch * 4); gd.soffX = (unsigned)(p0 * a.x_pitch * 4);
     // interior groups (the whole 6x18 patch inside the image) and full channel blocks: the precomputed offsets as they
     // are -- no per-lane validity arithmetic (uniform branch)
-    const bool inner = y0 >= 1 && y0 + 5 <= a.H && x0 >= 1 && x0 + 17 <= a.W && full_blocks;
-    if (inner) {
-#pragma unroll
-      for (int it = 0; it < D_IT; ++it)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(dres, (lds_ptr_ww_t)(dyB + (buf * DSLOTS + it * 256 + wv_s * 64) * 4), 16,
-                                                 d_offB[it], (int)soffD, 0, 0);
-#pragma unroll
-      for (int it = 0; it < X_IT; ++it)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_ww_t)(xB + (buf * XSLOTS + it * 256 + wv_s * 64) * 4), 16,
-                                                 x_offI[it], (int)soffX, 0, 0);
-      return;
+    gd.inner = gd.y0 >= 1 && gd.y0 + 5 <= a.H && gd.x0 >= 1 && gd.x0 + 17 <= a.W && full_blocks;
+    return gd;
+  };
+  auto issue_piece = [&](const GroupDma& gd, int buf, auto piece_c) {
+    constexpr int PIECE = decltype(piece_c)::value;
+    if constexpr (PIECE < D_IT) {
+      constexpr int it = PIECE;
+      int off = d_offB[it];
+      if (!gd.inner) {
+        const int key = d_key[it];
+        const bool ok = key >= 0 && gd.y0 + (key >> 8) < a.H && gd.x0 + (key & 255) < a.W;
+        off = ok ? off : (int)OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dres, (lds_ptr_ww_t)(dyB + (buf * DSLOTS + it * 256 + wv_s * 64) * 4), 16, off, (int)gd.soffD, 0, 0);
+    } else if constexpr (PIECE < NPIECE) {
+      constexpr int it = PIECE - D_IT;
+      int off = x_offI[it];
+      if (!gd.inner) {
+        const int key = x_key[it];
+        const bool ok = key >= 0 && (unsigned)(gd.y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(gd.x0 + (key & 255) - 1) < (unsigned)a.W;
+        off = ok ? x_offB[it] : (int)OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_ww_t)(xB + (buf * XSLOTS + it * 256 + wv_s * 64) * 4), 16, off, (int)gd.soffX, 0, 0);
     }
-#pragma unroll
-    for (int it = 0; it < D_IT; ++it) {
-      const int key = d_key[it];
-      const bool ok = key >= 0 && y0 + (key >> 8) < a.H && x0 + (key & 255) < a.W;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dres, (lds_ptr_ww_t)(dyB + (buf * DSLOTS + it * 256 + wv_s * 64) * 4), 16,
-                                               ok ? d_offB[it] : (int)OOB, (int)soffD, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < X_IT; ++it) {
-      const int key = x_key[it];
-      const bool ok = key >= 0 && (unsigned)(y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(x0 + (key & 255) - 1) < (unsigned)a.W;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_ww_t)(xB + (buf * XSLOTS + it * 256 + wv_s * 64) * 4), 16,
-                                               ok ? x_offB[it] : (int)OOB, (int)soffX, 0, 0);
-    }
+  };
+  auto issue_all = [&](const GroupDma& gd, int buf) {        // (the prologue: the first group of the workgroup)
+    ww_static_for<0, NPIECE>([&](auto pc) { issue_piece(gd, buf, pc); });
   };
 
   // Wave-uniform row transforms, each ONE packed fma per register pair (every VALU instruction stalls the MFMA stream):
@@ -174,13 +203,14 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
   unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, t_begin = 0, sum_wait = 0, sum_issue = 0, sum_v = 0, sum_mm = 0, ngr = 0;
   WW_STAMP(t_begin);
 #endif
-  issue(s, 0);
+  issue_all(group_dma(s), 0);
   for (int q = s; q < a.ngroups; q += a.S) {
     WW_STAMP(ta);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the group's DMA has landed ...
     __syncthreads();                                         // ... and is published; the other buffer is free again
     WW_STAMP(tb);
-    if (q + a.S < a.ngroups) issue(q + a.S, buf ^ 1);
+    const bool more = q + a.S < a.ngroups;
+    const GroupDma nxt = group_dma(more ? q + a.S : q);
     WW_STAMP(tc);
     const float* const dP0 = dyB + buf * DSLOTS * 4 + dL0;
     const float* const dP1 = dyB + buf * DSLOTS * 4 + dL1;
@@ -228,12 +258,19 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
         if (txl == 0) { afr[0].lo = m0; afr[1].lo = m1; afr[2].lo = m2; afr[3].lo = m3; }
         else          { afr[0].hi = m0; afr[1].hi = m1; afr[2].hi = m2; afr[3].hi = m3; }
       }
+      // the next group's DMA pieces ride between the MFMA blocks: piece p in front of block floor(p * 4 TN / NPIECE) of the 4 TN blocks
 #pragma unroll
-      for (int nu = 0; nu < 4; ++nu)
+      for (int nu = 0; nu < 4; ++nu) {
+        // (nb, nu are fully unrolled: the comparison folds to a constant per piece)
+        ww_static_for<0, NPIECE>([&](auto pc) {
+          constexpr int PP = decltype(pc)::value;
+          if ((PP * 4 * TN) / NPIECE == nb * 4 + nu && more) issue_piece(nxt, buf ^ 1, pc);
+        });
 #pragma unroll
         for (int cbk = 0; cbk < TC; ++cbk)
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[nu][nb][cbk] = mfma16(afr[nu][t], bfr[cbk][nu][t], acc[nu][nb][cbk]);
+      }
       if (xi == 1) {                                         // bias gradient: position (1,1) of A dY A^T is the tile sum
 #pragma unroll
         for (int t = 0; t < 4; ++t) accb[nb] = mfma16(afr[1][t], 1.0f, accb[nb]);
