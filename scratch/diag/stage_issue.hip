@@ -71,17 +71,17 @@ static double run(const char* name, int wgs_per_cu, int iters) {
   const size_t lds = (size_t)4 * 2 * P * 1024;
   auto kern = k<FORM, M, P, PAT, NLDS>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  double best = 1e30;
+  double best = 1e30; long long lo = 0, hi = 0;
   for (int rep = 0; rep < 3; ++rep) {
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, 0, out, clk, iters, gin, WINDOW);
     hipDeviceSynchronize();
     std::vector<long long> h(nwg * 4); hipMemcpy(h.data(), clk, nwg * 4 * 8, hipMemcpyDeviceToHost);
     double avg = 0; for (auto x : h) avg += x; avg /= h.size();
-    best = std::min(best, avg);
+    if (avg < best) { best = avg; lo = *std::min_element(h.begin(), h.end()); hi = *std::max_element(h.begin(), h.end()); }
   }
   const double ns_it = best * 10.0 / iters;     // wall_clock64: 100 MHz
-  printf("%-44s M=%3d P=%d wgs/CU=%d: %8.1f ns per iteration = %6.0f cycles at 2.4 GHz (MFMA-only ideal %d x %d = %d)\n", name, M, P, wgs_per_cu, ns_it,
-         ns_it * 2.4, M, 32 * wgs_per_cu, M * 32 * wgs_per_cu);
+  printf("%-44s M=%3d P=%d wgs/CU=%d: %8.1f ns per iteration = %6.0f cycles at 2.4 GHz (MFMA-only ideal %d x %d = %d)  [per wave min %.1f max %.1f ns]\n", name, M, P, wgs_per_cu, ns_it,
+         ns_it * 2.4, M, 32 * wgs_per_cu, M * 32 * wgs_per_cu, lo * 10.0 / iters, hi * 10.0 / iters);
   hipFree(out); hipFree(clk);
   return ns_it;
 }
