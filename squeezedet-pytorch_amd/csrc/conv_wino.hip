@@ -91,6 +91,15 @@ struct WinoArgs {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w_t;
 
+// Diagnostic build only (-DSQD_WINO_STAMP, scratch/diag/wino_stamp.sh; never in libsqdhip.so): every workgroup of conv_wino_kernel
+// records {HW_ID, XCC_ID, start, end (100 MHz clock), tiles done} -- which workgroups of a two-per-CU launch finish early.
+#ifdef SQD_WINO_STAMP
+__device__ long long* sqd_wino_dbg = nullptr;
+extern "C" int sqd_wino_set_debug(long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(sqd_wino_dbg), &p, sizeof(p)) == hipSuccess ? SQD_OK : SQD_ERR_LAUNCH;
+}
+#endif
+
 __device__ __forceinline__ f32x4 wino_relu4(f32x4 v, float lo) {
   asm volatile("v_max_f32 %0, %4, %0\n\tv_max_f32 %1, %4, %1\n\tv_max_f32 %2, %4, %2\n\tv_max_f32 %3, %4, %3"
                : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : "s"(lo));
@@ -134,6 +143,10 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
   int tile = ((int)blockIdx.x & 7) * (a.gx >> 3) + wgq / a.nslices;
   if (tile >= ntiles) return;
   const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+#ifdef SQD_WINO_STAMP
+  const long long stamp_t0 = wall_clock64();
+  long long stamp_tiles = 0;
+#endif
 
   // ---- per-lane DMA slots ----
   // Both DMA streams go through buffer resources: address = resource base + wave-uniform SGPR offset (group origin /
@@ -433,12 +446,24 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
       }
       ubuf ^= 1;
     }
+#ifdef SQD_WINO_STAMP
+    stamp_tiles += 1;
+#endif
     if (!more) break;
     tile += tstride;
     cur = nxt;
   }
   if (pending) flush(ptp);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SQD_WINO_STAMP
+  if (sqd_wino_dbg && tid == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    long long* d = sqd_wino_dbg + (long long)blockIdx.x * 8;
+    d[0] = hw; d[1] = xcc; d[2] = stamp_t0; d[3] = wall_clock64(); d[4] = stamp_tiles; d[5] = n0;
+  }
+#endif
 #endif
 }
 
