@@ -58,7 +58,9 @@ extern "C" int sqd_ww_set_debug(unsigned long long* p) {
 // (~230 cycles per piece when the four waves issue together; 38 cycles per piece when spread over MFMAs in isolation:
 // profiles/r04zz_stage_issue_microbench.log), 7-11 % in the V transform, 7-10 % at the wait + barrier; the epilogue is 8-16 % of a wave's
 // time where a workgroup only sees ~10 groups.  A THIRD workgroup per CU for the 64 x 16 form (<= 168 registers, 48 KB of LDS: it fits)
-// was measured neutral (profiles/r04u_ww_occupancy3.log).
+// was measured neutral (profiles/r04u_ww_occupancy3.log); an eight-wave form (two positions per wave, half the accumulators, FOUR waves per
+// SIMD at 126 registers for the 64 x 16 tile) was 5-8 % SLOWER than this kernel and spills for the wider tiles
+// (profiles/r04_wino_wgrad_eight_waves.log; the code is in the history at commit 'Final evidence set r04z'): more waves do not help.
 template <int TN, int TC>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -343,275 +345,6 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// Eight-wave form (round 4): the same workgroup tile and staging, but the 16 transform positions are split over EIGHT waves -- wave
-// (xi, h) owns positions (xi, 2h) and (xi, 2h + 1) -- so a wave carries half the accumulators (2 x TN x TC x 4 registers) and a
-// workgroup's two residents per CU put FOUR waves on every SIMD instead of two.  Why: the stamped timeline of the four-wave form
-// (profiles/r04t_ww_stamp.log) shows ~40 % of a wave's group period in chains the sibling wave does not cover (DMA issue, ds_read_b32 ->
-// packed add -> MFMA of the two transforms, wait + barrier); the registers were what kept a third and fourth wave off the SIMD.  The DMA
-// issue is shared by eight waves (half the pieces per wave).  Epilogue: every wave writes the three column-transformed partial
-// rows of ITS two positions; the finishing waves add the two halves of a row in a fixed order, then combine the rows as before.
-// ---------------------------------------------------------------------------------------------
-template <int TN, int TC>
-__global__ __launch_bounds__(512, 4) void wino_wgrad8_kernel(WwArgs a) {      // (second argument: waves per SIMD)
-#if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(TN >= 4 && (TC == 1 || TC == 2), "the bank swizzle swaps 16-channel blocks pairwise inside the first four");
-  constexpr int NTHR = 512;
-  constexpr int CHD = TN * 16, CHX = TC * 16;
-  constexpr int DQ = TN * 4, XQ = TC * 4;                  // 16-byte slots per pixel
-  constexpr int DREAL = 64 * DQ, D_IT = (DREAL + NTHR - 1) / NTHR, DSLOTS = D_IT * NTHR;
-  constexpr int XREAL = 108 * XQ, X_IT = (XREAL + NTHR - 1) / NTHR, XSLOTS = X_IT * NTHR;
-  constexpr unsigned OOB = 0x80000000u;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const dyB = smem;                                  // [2][DSLOTS][4]: dY tile, pixel-major [64 px][CHD]
-  float* const xB = smem + 2 * DSLOTS * 4;                  // [2][XSLOTS][4]: X patch [108 px][CHX]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int lr = lane & 15, g = lane >> 4;
-  const int wv_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xi = wv_s & 3, hh = wv_s >> 2;                  // Winograd row, half of its four column positions
-  const int ntile = (int)gridDim.x / a.S;
-  const int pos = sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-  const int s = pos / ntile, bg = pos - s * ntile;
-  const int ng = bg / a.ncg, cg = bg - ng * a.ncg;
-  const int n0 = ng * CHD, c0 = cg * CHX;
-
-  int d_offB[D_IT], d_key[D_IT];
-#pragma unroll
-  for (int it = 0; it < D_IT; ++it) {
-    const int slot = it * NTHR + tid;
-    const int px = slot / DQ, chs = slot - px * DQ;
-    const int row = px >> 4, col = px & 15;
-    const int chq = (chs < 16) ? (chs ^ (((col >> 2) & 1) << 2)) : chs;       // (bank swizzle: see wino_wgrad_kernel)
-    d_key[it] = (px < 64 && n0 + 4 * chq < a.N) ? (row << 8 | col) : -1;
-    d_offB[it] = px < 64 ? ((row * a.W + col) * a.dy_pitch + 4 * chq) * 4 : 0;
-  }
-  int x_offB[X_IT], x_key[X_IT];
-#pragma unroll
-  for (int it = 0; it < X_IT; ++it) {
-    const int slot = it * NTHR + tid;
-    const int px = slot / XQ, chs = slot - px * XQ;
-    const int r = px / 18, c = px - r * 18;
-    const int chq = (TC == 2) ? (chs ^ (((c >> 2) & 1) << 2)) : chs;
-    const bool real = px < 108 && c0 + 4 * chq < a.C;
-    x_key[it] = real ? (r << 8 | c) : -1;
-    x_offB[it] = real ? ((r * a.W + c) * a.x_pitch + 4 * chq) * 4 : 0;
-  }
-  int x_offI[X_IT], d_offI[D_IT];
-#pragma unroll
-  for (int it = 0; it < X_IT; ++it) x_offI[it] = x_key[it] >= 0 ? x_offB[it] : (int)OOB;
-#pragma unroll
-  for (int it = 0; it < D_IT; ++it) d_offI[it] = d_key[it] >= 0 ? d_offB[it] : (int)OOB;
-  const bool full_blocks = n0 + CHD <= a.N;
-  const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + a.dy_coff + n0), 0, 0x7ffffff0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.x + a.x_coff + c0 - (long long)(a.W + 1) * a.x_pitch), 0, 0x7ffffff0, 0x00020000);
-
-  constexpr int NPIECE = D_IT + X_IT;
-  struct GroupDma { int y0, x0; unsigned soffD, soffX; bool inner; };
-  auto group_dma = [&](int q) {
-    GroupDma gd;
-    const int gxi = q % a.gxn; int t = q / a.gxn;
-    const int gyi = t % a.gyn; const int b = t / a.gyn;
-    gd.y0 = gyi * 4; gd.x0 = gxi * 16;
-    const long long p0 = ((long long)b * a.H + gd.y0) * a.W + gd.x0;
-    gd.soffD = (unsigned)(p0 * a.dy_pitch * 4); gd.soffX = (unsigned)(p0 * a.x_pitch * 4);
-    gd.inner = gd.y0 >= 1 && gd.y0 + 5 <= a.H && gd.x0 >= 1 && gd.x0 + 17 <= a.W && full_blocks;
-    return gd;
-  };
-  auto issue_piece = [&](const GroupDma& gd, int buf, auto piece_c) {
-    constexpr int PIECE = decltype(piece_c)::value;
-    if constexpr (PIECE < D_IT) {
-      constexpr int it = PIECE;
-      int off = d_offI[it];
-      if (!gd.inner) {
-        const int key = d_key[it];
-        const bool ok = key >= 0 && gd.y0 + (key >> 8) < a.H && gd.x0 + (key & 255) < a.W;
-        off = ok ? d_offB[it] : (int)OOB;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dres, (lds_ptr_ww_t)(dyB + (buf * DSLOTS + it * NTHR + wv_s * 64) * 4), 16, off, (int)gd.soffD, 0, 0);
-    } else if constexpr (PIECE < NPIECE) {
-      constexpr int it = PIECE - D_IT;
-      int off = x_offI[it];
-      if (!gd.inner) {
-        const int key = x_key[it];
-        const bool ok = key >= 0 && (unsigned)(gd.y0 + (key >> 8) - 1) < (unsigned)a.H && (unsigned)(gd.x0 + (key & 255) - 1) < (unsigned)a.W;
-        off = ok ? x_offB[it] : (int)OOB;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_ptr_ww_t)(xB + (buf * XSLOTS + it * NTHR + wv_s * 64) * 4), 16, off, (int)gd.soffX, 0, 0);
-    }
-  };
-
-  // row transforms (wave-uniform coefficients), as in wino_wgrad_kernel
-  const int i1 = (xi == 0) ? 0 : 1, i2 = (xi == 3) ? 3 : 2;
-  const float sx = (xi == 1) ? 1.f : -1.f;
-  const float sd = (xi == 0 || xi == 3) ? 0.f : ((xi == 1) ? 1.f : -1.f);
-  const int r0 = (xi == 3) ? 1 : 0;
-  const float row_sign = ((xi == 2) ? -1.f : 1.f) * ((xi == 3) ? -1.f : 1.f);
-  const f32x2 sx2 = {sx, sx}, sd2 = {sd, sd};
-  const int dL0 = (r0 * 16 + 4 * g) * CHD + lr, dL1 = (1 * 16 + 4 * g) * CHD + lr;
-  const int xL1 = (i1 * 18 + 4 * g) * CHX + lr, xL2 = (i2 * 18 + 4 * g) * CHX + lr;
-  const int gsw = (g & 1) * 16;
-
-  f32x4 acc[2][TN][TC], accb[TN];
-#pragma unroll
-  for (int nu = 0; nu < 2; ++nu)
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TC; ++j) acc[nu][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < TN; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  int buf = 0;
-  {
-    const GroupDma gd0 = group_dma(s);
-    ww_static_for<0, NPIECE>([&](auto pc) { issue_piece(gd0, 0, pc); });
-  }
-  // one group of this wave's two positions; HALF = hh as a compile-time constant (register arrays are indexed statically)
-  auto group_body = [&](auto half_c) {
-    constexpr int HALF = decltype(half_c)::value;
-    const float* const dP0 = dyB + buf * DSLOTS * 4 + dL0;
-    const float* const dP1 = dyB + buf * DSLOTS * 4 + dL1;
-    const float* const xP1 = xB + buf * XSLOTS * 4 + xL1;
-    const float* const xP2 = xB + buf * XSLOTS * 4 + xL2;
-    f32x4 bfr[TC][2];
-#pragma unroll
-    for (int cbk = 0; cbk < TC; ++cbk) {
-      f32x2 tt[6];
-#pragma unroll
-      for (int jj = 0; jj < 6; ++jj) {
-        const int xo = (TC == 2) ? ((cbk * 16) ^ gsw ^ ((jj >> 2) << 4)) : cbk * 16;
-        const f32x2 d1 = {xP1[(0 * 18 + jj) * CHX + xo], xP1[(2 * 18 + jj) * CHX + xo]};
-        const f32x2 d2 = {xP2[(0 * 18 + jj) * CHX + xo], xP2[(2 * 18 + jj) * CHX + xo]};
-        tt[jj] = __builtin_elementwise_fma(sx2, d2, d1);
-      }
-#pragma unroll
-      for (int txl = 0; txl < 2; ++txl) {
-        const int j0 = 2 * txl;
-        // positions (xi, 0), (xi, 1) for HALF 0; (xi, 2), (xi, 3) for HALF 1 (column 3 carries dM's sign)
-        const f32x2 va = HALF == 0 ? tt[j0] - tt[j0 + 2] : tt[j0 + 2] - tt[j0 + 1];
-        const f32x2 vb = HALF == 0 ? tt[j0 + 1] + tt[j0 + 2] : tt[j0 + 3] - tt[j0 + 1];
-        if (txl == 0) { bfr[cbk][0].lo = va; bfr[cbk][1].lo = vb; }
-        else          { bfr[cbk][0].hi = va; bfr[cbk][1].hi = vb; }
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < TN; ++nb) {
-      __builtin_amdgcn_sched_barrier(0);                     // (one block's transform at a time: with four waves per SIMD the budget is 128 registers)
-      f32x4 afr[2];
-#pragma unroll
-      for (int txl = 0; txl < 2; ++txl) {
-        f32x2 rp[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int yo = (nb < 4) ? ((nb * 16) ^ gsw) : nb * 16;
-          const f32x2 y0 = {dP0[(2 * txl + j) * CHD + yo], dP0[(2 * 16 + 2 * txl + j) * CHD + yo]};
-          const f32x2 y1 = {dP1[(2 * txl + j) * CHD + yo], dP1[(2 * 16 + 2 * txl + j) * CHD + yo]};
-          rp[j] = __builtin_elementwise_fma(sd2, y1, y0);
-        }
-        const f32x2 ma = HALF == 0 ? rp[0] : rp[0] - rp[1];
-        const f32x2 mb = HALF == 0 ? rp[0] + rp[1] : rp[1];
-        if (txl == 0) { afr[0].lo = ma; afr[1].lo = mb; }
-        else          { afr[0].hi = ma; afr[1].hi = mb; }
-      }
-#pragma unroll
-      for (int nu = 0; nu < 2; ++nu) {
-#pragma unroll
-        for (int cbk = 0; cbk < TC; ++cbk)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[nu][nb][cbk] = mfma16(afr[nu][t], bfr[cbk][nu][t], acc[nu][nb][cbk]);
-      }
-      if (HALF == 0 && xi == 1) {                            // bias gradient: position (1, 1) of A dY A^T is the tile sum
-#pragma unroll
-        for (int t = 0; t < 4; ++t) accb[nb] = mfma16(afr[1][t], 1.0f, accb[nb]);
-      }
-    }
-  };
-  for (int q = s; q < a.ngroups; q += a.S) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (q + a.S < a.ngroups) {                               // the next group's pieces: half as many per wave as in the four-wave form
-      const GroupDma nxt = group_dma(q + a.S);
-      ww_static_for<0, NPIECE>([&](auto pc) { issue_piece(nxt, buf ^ 1, pc); });
-    }
-    if (hh == 0) group_body(std::integral_constant<int, 0>{});
-    else group_body(std::integral_constant<int, 1>{});
-    buf ^= 1;
-  }
-
-  // ---- dg = G^T dU G.  Column transform of this wave's two positions (its share of the three kernel columns), through LDS; the
-  // finishing waves add the two halves of a row (half 0 first), then combine the four rows as in the four-wave form ----
-  float* const sl = a.slab + (long long)s * a.slab_stride;
-  f32x4* const wL = (f32x4*)smem;                            // [8 waves][3][TC][64 lanes] (+ bias row)
-  f32x4* const bL = wL + 8 * 3 * TC * 64;
-  const long long nw = (long long)a.N * 9 * a.C;
-#pragma unroll
-  for (int nb = 0; nb < TN; ++nb) {
-    __syncthreads();
-#pragma unroll
-    for (int cbk = 0; cbk < TC; ++cbk) {
-      const f32x4 ua = row_sign * acc[0][nb][cbk], ub = row_sign * acc[1][nb][cbk];
-      // columns of G^T (.) G: s3 = 0: u0 + (u1 + u2) / 2; 1: (u1 - u2) / 2; 2: (u1 + u2) / 2 + u3
-      f32x4 p0, p1, p2;
-      if (hh == 0) { p0 = ua + 0.5f * ub; p1 = 0.5f * ub; p2 = 0.5f * ub; }           // ua = u0, ub = u1
-      else         { p0 = 0.5f * ua; p1 = -0.5f * ua; p2 = 0.5f * ua + ub; }          // ua = u2, ub = u3
-      wL[((wv_s * 3 + 0) * TC + cbk) * 64 + lane] = p0;
-      wL[((wv_s * 3 + 1) * TC + cbk) * 64 + lane] = p1;
-      wL[((wv_s * 3 + 2) * TC + cbk) * 64 + lane] = p2;
-    }
-    if (xi == 1 && hh == 0) bL[lane] = accb[nb];
-    __syncthreads();
-    if (xi < 3) {                                            // waves (r = xi, hh) finish kernel row r; the halves share the input-channel blocks
-#pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3)
-#pragma unroll
-        for (int cbk = 0; cbk < TC; ++cbk) {
-          if ((TC == 2 ? cbk : s3 & 1) != hh && !(TC == 1 && s3 == 2 && hh == 0)) continue;      // TC = 2: block cbk to half cbk; TC = 1: columns 0, 2 to half 0, column 1 to half 1
-          f32x4 w[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            w[r] = wL[((r * 3 + s3) * TC + cbk) * 64 + lane] + wL[(((r + 4) * 3 + s3) * TC + cbk) * 64 + lane];
-          f32x4 v;
-          if (xi == 0) v = w[0] + 0.5f * (w[1] + w[2]);
-          else if (xi == 1) v = 0.5f * (w[1] - w[2]);
-          else v = 0.5f * (w[1] + w[2]) + w[3];
-          const int c = c0 + cbk * 16 + lr, n = n0 + nb * 16 + 4 * g;
-          if (c < a.C && n < a.N) {
-            const int tap = xi * 3 + s3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sl[((long long)(n + i) * 9 + tap) * a.C + c] = v[i];
-          }
-        }
-    } else if (hh == 0 && cg == 0 && lr == 0 && n0 + nb * 16 + 4 * g < a.N) {
-      const f32x4 v = bL[lane];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sl[nw + n0 + nb * 16 + 4 * g + i] = v[i];
-    }
-  }
-#endif
-}
-
-template <int TN, int TC>
-static int launch_wino_wgrad8(WwArgs a, hipStream_t stream) {
-  constexpr int NTHR = 512;
-  constexpr int DSLOTS = (64 * TN * 4 + NTHR - 1) / NTHR * NTHR, XSLOTS = (108 * TC * 4 + NTHR - 1) / NTHR * NTHR;
-  constexpr size_t lds = (size_t)2 * (DSLOTS + XSLOTS) * 16;
-  static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  static_assert((size_t)(8 * 3 * TC + 1) * 64 * 16 <= lds, "epilogue exchange fits the staging buffers");
-  auto kern = wino_wgrad8_kernel<TN, TC>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
-    attr_done = true;
-  }
-  a.ncg = sqd_cdiv(a.C, TC * 16);
-  const int groups = sqd_cdiv(a.N, TN * 16) * a.ncg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * a.S)), dim3(NTHR), lds, stream, a);
-  return sqd_launch_status();
-}
-
 template <int TN, int TC>
 static int launch_wino_wgrad(WwArgs a, hipStream_t stream) {
   constexpr int DSLOTS = 64 * TN * 4, XSLOTS = (108 * TC * 4 + 255) / 256 * 256;
@@ -635,9 +368,6 @@ static int launch_wino_wgrad(WwArgs a, hipStream_t stream) {
 // N % 64 == 0 or N <= 80, C % 4 == 0, S <= number of 4x16-pixel groups.  Returns SQD_ERR_UNSUPPORTED otherwise.
 extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
                                    int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, int tc, void* stream) {
-  // tc: input-channel blocks of 16 per workgroup (1 | 2); + 10 = the eight-wave form (two positions per wave, four waves per SIMD)
-  const bool eight = tc >= 10;
-  if (eight) tc -= 10;
   SQD_CHECK_ARG(dy && x && slab && B > 0 && H > 0 && W > 0 && N > 0 && C > 0 && S > 0 && S <= 65535 && (tc == 1 || tc == 2));
   SQD_CHECK_ARG((N & 3) == 0 && (C & 3) == 0 && (dy_pitch & 3) == 0 && (dy_coff & 3) == 0 && (x_pitch & 3) == 0 && (x_coff & 3) == 0);
   SQD_CHECK_ARG(dy_coff + N <= dy_pitch && x_coff + C <= x_pitch);
@@ -652,13 +382,8 @@ extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab,
   if (px * dy_pitch * 4 >= (3ll << 30) || px * x_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;   // 32-bit SGPR byte offsets
   hipStream_t s = (hipStream_t)stream;
   // N <= 80 (ConvDet: 72): one 5-block output-channel group (x 16 or 32 input channels); else 64-channel groups
-  int rc;
-  if (eight)
-    rc = (N % 64) ? ((tc <= 1 || C <= 16) ? launch_wino_wgrad8<5, 1>(a, s) : launch_wino_wgrad8<5, 2>(a, s))
-                  : ((tc <= 1 || C <= 16) ? launch_wino_wgrad8<4, 1>(a, s) : launch_wino_wgrad8<4, 2>(a, s));
-  else
-    rc = (N % 64) ? ((tc <= 1 || C <= 16) ? launch_wino_wgrad<5, 1>(a, s) : launch_wino_wgrad<5, 2>(a, s))
-                  : ((tc <= 1 || C <= 16) ? launch_wino_wgrad<4, 1>(a, s) : launch_wino_wgrad<4, 2>(a, s));
+  const int rc = (N % 64) ? ((tc <= 1 || C <= 16) ? launch_wino_wgrad<5, 1>(a, s) : launch_wino_wgrad<5, 2>(a, s))
+                          : ((tc <= 1 || C <= 16) ? launch_wino_wgrad<4, 1>(a, s) : launch_wino_wgrad<4, 2>(a, s));
   if (rc != SQD_OK || !dw) return rc;
   return sqd_wgrad_reduce_launch(slab, dw, db, S, a.slab_stride, N, C, 9, stream);
 }

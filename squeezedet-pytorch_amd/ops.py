@@ -18,7 +18,7 @@ from . import timing
 from .timing import KernelTimer, set_timer, _Bracket  # noqa: F401
 from . import tiles
 from .tiles import *  # noqa: F401,F403
-from .tiles import (_tuning, _nearest_tuned, _CFG_DMA, _wino_wgrad_tc, _wino_wgrad_form)  # noqa: F401
+from .tiles import (_tuning, _nearest_tuned, _CFG_DMA, _wino_wgrad_tc)  # noqa: F401
 from . import plans
 from .plans import (ConvPlan, repack_batched, dgrad_weight, FusedExpandPlan, WinoPlan, repack_wino_batched, FireWinoPlan,  # noqa: F401
                     FireBridgePlan, WgradBatch, wino_sk_schedule, wino_sk_host_schedule)
@@ -730,7 +730,7 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
         br = _Bracket('conv_wgrad_wino', f'wgrad 9tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * 4,
                       4.0 * (B * H * W * (C + N) + 2 * S * stride)) if timing._timer is not None else None
         rc = nat.lib().sqd_conv_wgrad_wino(nat.ptr(dy), nat.ptr(x), nat.ptr(slab), nat.ptr(dw), nat.ptr(db), B, H, W, N, dyp, dy_coff,
-                                           C, xp, x_coff, S, _wino_wgrad_form(N, C), nat.stream_handle(dy.device))
+                                           C, xp, x_coff, S, _wino_wgrad_tc(N, C), nat.stream_handle(dy.device))
         nat.check(rc, 'sqd_conv_wgrad_wino')
     else:
         br = _Bracket(f'conv_wgrad<{taps}>', f'wgrad {taps}tap C{C} N{N} {H}x{W}', 2.0 * B * H * W * N * C * taps,

@@ -326,16 +326,6 @@ def _wgrad_wide():
     return os.environ.get('SQD_WGRAD_WIDE', '1')[:1] != '0'
 
 
-def _wino_wgrad_form(N, C):
-    """``tc`` argument of sqd_conv_wgrad_wino: input-channel blocks per workgroup, + 10 for the eight-wave form (SQD_WW8: '1' = every
-    layer, 't1' = only where tc == 1, the instantiations that fit 128 registers)."""
-    import os
-    tc = _wino_wgrad_tc(N, C)
-    e = os.environ.get('SQD_WW8', '0')
-    eight = e == '1' or (e == 't1' and tc == 1 and N % 64 == 0)
-    return tc + (10 if eight else 0)
-
-
 def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False):
     """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab.
     ``fused_dgrad``: the layer runs ``ops.squeeze_bwd`` (weight + data gradient in one launch: all N in one group, 64-channel in-tiles).
