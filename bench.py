@@ -427,128 +427,109 @@ def main():
     result = {}
     hip_pred = hip_det = train_probe = None
 
-    # ---------------- end-to-end leg (reported beside the main line, never `value`) ----------------
-    def pipeline_leg(det, model):
+    # ---------------- end-to-end legs (reported beside the main line, never `value`) ----------------
+    def pipeline_leg(det):
         """What the reference's only published figure measures (README 117 FPS on V100: ``detect_dataset``,
-        src/engine/detector.py:52-85 = data loading + network + per-image NMS + D2H), minus disk and JPEG decode: per batch a
-        pinned uint8 HWC buffer of B KITTI-sized (375x1242) images -> H2D on a copy stream -> ``preprocess_kernel`` (whiten +
-        cv2-style bilinear resize + CHW) -> backbone -> fused detect -> D2H of the compact results into pinned memory.  Two slots:
-        batch i+1 uploads while batch i computes.  Timed like the main leg (barrier + synchronize both sides, K batches)."""
-        import ctypes
+        src/engine/detector.py:52-85 = data loading + network + per-image NMS + D2H), minus disk and JPEG decode, through the
+        package's own executor (``Detector.stream`` = lanes.DetectStream): per batch B KITTI-sized (375x1242) uint8 HWC images that
+        sit in a pinned staging buffer (``Staging.view``: a decoder would write them there) -> ONE H2D copy on the copy stream ->
+        ``preprocess_kernel`` + the lane's captured step (backbone -> fused detect) -> ONE D2H copy of the packed results into
+        pinned memory -> unpacked on the host.  Timed like the main leg (barrier + synchronize both sides, K batches)."""
         import numpy as np
-        from squeezedet_pytorch_amd import _native as nat
-        from squeezedet_pytorch_amd.preprocess import KITTI_RGB_MEAN, KITTI_RGB_STD
         H0, W0 = 375, 1242
-        Hn, Wn = cfg.input_size
-        per = H0 * W0 * 3
-        total = B * per
+        ex = det.stream(lanes=max(1, args.inflight), graph=not args.no_graph)
         rs = np.random.RandomState(7 + rank)
-        mean = (ctypes.c_float * 3)(*KITTI_RGB_MEAN.tolist()); std = (ctypes.c_float * 3)(*KITTI_RGB_STD.tolist())
-        d_off = (torch.arange(B, dtype=torch.int64) * per).to(dev)
-        d_sizes = torch.tensor([[H0, W0]] * B, dtype=torch.int32).to(dev)
-        copy_stream, back_stream, main = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
-        K = cfg.keep_top_k
-        slots = []
-        for _ in range(2):
-            host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
-            host.numpy()[:] = rs.randint(0, 256, total, dtype=np.uint8)
-            out, flat = ops.det_buffers_packed(B, K, dev, cfg.num_anchors)        # five result tensors, ONE allocation: one D2H copy
-            slots.append(dict(host=host, src=torch.empty(total, dtype=torch.uint8, device=dev),
-                              img=torch.empty(B, 3, Hn, Wn, device=dev), sc=torch.empty(B, 2, device=dev), out=out, flat=flat,
-                              res=torch.empty(flat.shape, dtype=torch.uint8, pin_memory=True),
-                              uploaded=torch.cuda.Event(), consumed=torch.cuda.Event(), done=torch.cuda.Event(),
-                              copied=torch.cuda.Event(), graph=None,
-                              comp=(torch.cuda.Stream() if args.inflight >= 2 else main)))      # a compute stream per slot: two batches in flight
-        d2h_bytes = slots[0]['flat'].numel()
+        pix = [rs.randint(0, 256, (H0, W0, 3), dtype=np.uint8) for _ in range(4)]
 
-        def compute(sl):
-            rc = nat.lib().sqd_preprocess_u8_fwd(nat.ptr(sl['src']), nat.ptr(d_off), nat.ptr(d_sizes), nat.ptr(sl['img']), nat.ptr(sl['sc']),
-                                                 mean, std, B, Hn, Wn, nat.stream_handle(dev))
-            nat.check(rc, 'sqd_preprocess_u8_fwd')
-            det.detect_device(sl['img'], scales=sl['sc'], out=sl['out'])
-
-        def upload(sl):
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(sl['consumed'])            # the previous batch in this slot has been pre-processed
-                sl['src'].copy_(sl['host'], non_blocking=True)
-                sl['uploaded'].record(copy_stream)
-
-        def one(i):
-            sl = slots[i & 1]
-            comp = sl['comp']
-            comp.wait_event(sl['uploaded'])
-            comp.wait_event(sl['copied'])                        # the results this slot produced two batches ago have left
-            with torch.cuda.stream(comp):
-                if sl['graph'] is not None:
-                    sl['graph'].replay()
-                else:
-                    compute(sl)
-            sl['consumed'].record(comp)
-            upload(slots[(i + 1) & 1])                           # next batch's upload overlaps this batch's compute
-            with torch.cuda.stream(back_stream):                 # compact results -> pinned host memory on a stream of their own:
-                back_stream.wait_event(sl['consumed'])           # neither the compute stream nor the uploads wait for the copy
-                sl['res'].copy_(sl['flat'], non_blocking=True)
-                sl['copied'].record(back_stream)
-        for sl in slots:
-            sl['comp'].wait_stream(main)
-            sl['consumed'].record(sl['comp'])
-            sl['copied'].record(sl['comp'])
-        upload(slots[0])
-        for i in range(4):
-            one(i)
-        torch.cuda.synchronize()
-        how = 'eager launches'
-        if not args.no_graph:
-            try:
-                side = torch.cuda.Stream()
-                for sl in slots:
-                    side.wait_stream(sl['comp'])
-                    with torch.cuda.stream(side):
-                        g = torch.cuda.CUDAGraph()
-                        mode = {'capture_error_mode': 'thread_local'} if dist is not None else {}
-                        with torch.cuda.graph(g, stream=side, **mode):
-                            compute(sl)
-                    sl['comp'].wait_stream(side)
-                    sl['graph'] = g
-                how = 'hipGraph replay of preprocess + net + detect per slot; copies eager on their streams'
-            except Exception as e:  # noqa: BLE001
-                print(f'[bench] pipeline step not captured ({type(e).__name__}: {e}); eager launches', file=sys.stderr)
-                for sl in slots:
-                    sl['graph'] = None
-            torch.cuda.synchronize()
-        for i in range(4):
-            one(i)
+        def one(fill):
+            st = ex.stage(B)
+            for b in range(B):
+                v = st.view(b, H0, W0)
+                if fill:
+                    v[:] = pix[b % len(pix)]
+            ex.submit(st)
+            while ex.pending() > 2 * len(ex._lanes) - 1:
+                ex.fetch()
+        for i in range(max(8, 3 * len(ex._host))):          # fills every staging buffer of the ring, captures every lane
+            one(fill=i < len(ex._host))
+        last = ex.drain()[-1][1]
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            one(i)
+        for _ in range(args.steps):
+            one(False)
+        ex.drain()
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         ms = elapsed / args.steps * 1e3
+        total = ex._host[0]['hdr'] + B * ex._host[0]['slot']
         # the upload alone (same pinned buffer, same copy stream, nothing else running): is the leg bound by the host link?
-        torch.cuda.synchronize()
         ncopy = max(4, min(args.steps, 20))
-        with torch.cuda.stream(copy_stream):
+        dst = torch.empty(total, dtype=torch.uint8, device=dev)
+        with torch.cuda.stream(ex._copy):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(copy_stream)
+            e0.record(ex._copy)
             for i in range(ncopy):
-                slots[i & 1]['src'].copy_(slots[i & 1]['host'], non_blocking=True)
-            e1.record(copy_stream)
+                dst.copy_(ex._host[i % len(ex._host)]['t'][:total], non_blocking=True)
+            e1.record(ex._copy)
         torch.cuda.synchronize()
         h2d_alone_ms = e0.elapsed_time(e1) / ncopy
-        # sanity: the last batch's results arrived on the host and agree with the device buffers
-        last = slots[(args.steps - 1) & 1]
-        ok = bool(torch.equal(last['res'], last['flat'].cpu())) and int(last['out'][0].sum()) > 0
+        how = (f'lanes.DetectStream, {len(ex._lanes)} lanes: preprocess_kernel (eager) + hipGraph replay of net + detect per lane, copies on their own streams'
+               if ex.replayed_batches and not ex.degraded else 'lanes.DetectStream, eager launches')
         return {'value': round(B * joined * args.steps / elapsed, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4),
-                'h2d_bytes_per_step': total, 'd2h_bytes_per_step': d2h_bytes,
+                'h2d_bytes_per_step': total, 'd2h_bytes_per_step': int(ops.det_packed_layout(B, cfg.keep_top_k)[1]),
                 'pcie_h2d_gbs_implied': round(total / (ms / 1e3) / 1e9, 2),
                 'h2d_alone': {'ms_per_batch': round(h2d_alone_ms, 4), 'gbs': round(total / (h2d_alone_ms / 1e3) / 1e9, 2),
                               'note': 'the same pinned uint8 batch uploaded back to back with nothing else running: the floor the '
                                       'host link sets for ms_per_step of this leg'},
-                'timed_with': how, 'results_on_host_ok': ok,
-                'what': f'per batch: pinned uint8 {B}x{H0}x{W0}x3 -> H2D (copy stream) -> preprocess_kernel -> backbone -> fused detect -> '
-                        f'D2H of (count, class_ids, scores, boxes, anchor_idx) as ONE copy into pinned memory on a third stream; two slots, '
-                        f'upload of batch i+1 overlaps compute of batch i; excludes disk read and JPEG decode; NOT part of `value`'}
+                'timed_with': how, 'degraded': bool(ex.degraded or (not args.no_graph and not ex.replayed_batches)),
+                'results_on_host_ok': bool(int(last.count.sum()) > 0),
+                'what': f'Detector.stream(): per batch pinned uint8 {B}x{H0}x{W0}x3 (+ header) -> one H2D copy -> preprocess_kernel -> captured lane step '
+                        f'(backbone -> fused detect) -> one D2H copy of (count, class_ids, scores, boxes, anchor_idx) '
+                        f'-> host arrays; {len(ex._lanes)} lanes, results fetched late; excludes disk read, JPEG decode and the packing '
+                        f'copy (pixels are produced in place in the pinned buffer); NOT part of `value`'}
+
+    def dataset_leg(det):
+        """``Detector.detect_dataset`` itself (the reference's published driver, src/engine/detector.py:52-85) on synthetic uint8
+        "files" held in memory: ``cfg.num_workers`` loader threads hand out KITTI-sized arrays and pack them into the pinned staging
+        buffers, the main thread runs the lanes and builds the per-image result dicts.  Includes everything but disk and decode."""
+        import contextlib
+        import io
+        import numpy as np
+        H0, W0 = 375, 1242
+        rs = np.random.RandomState(11 + rank)
+        pix = [rs.randint(0, 256, (H0, W0, 3), dtype=np.uint8) for _ in range(8)]
+
+        class InMemory:
+            rgb_mean = rgb_std = None
+
+            def __init__(self, n):
+                self.n = n
+
+            def __len__(self):
+                return self.n
+
+            def load_image(self, i):
+                return pix[i % len(pix)], f'{i:06d}'
+        nb = max(8, min(args.steps, 60))
+        old = (cfg.batch_size, getattr(cfg, 'num_workers', 4), getattr(cfg, 'print_interval', 10))
+        cfg.batch_size, cfg.num_workers, cfg.print_interval = B, min(8, max(1, (os.cpu_count() or 2) // 2)), 1 << 30
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                det.detect_dataset(InMemory(4 * B))                       # warm: captures the lanes at this batch size
+                barrier()
+                t0 = time.perf_counter()
+                res = det.detect_dataset(InMemory(nb * B))
+                barrier()
+            elapsed = max_over_ranks(time.perf_counter() - t0)
+        finally:
+            workers = cfg.num_workers
+            cfg.batch_size, cfg.num_workers, cfg.print_interval = old
+        ex = det.stream()
+        return {'value': round(nb * B * joined / elapsed, 1), 'unit': 'images/sec', 'ms_per_batch': round(elapsed / nb * 1e3, 4),
+                'batches': nb, 'loader_threads': workers, 'results': len(res), 'detections': int(sum(len(r.get('scores', ())) for r in res)),
+                'degraded': bool(ex.degraded),
+                'what': f'Detector.detect_dataset over {nb * B} in-memory uint8 {H0}x{W0} images, bs={B}: loader threads pack into pinned '
+                        f'staging, lanes replay captured steps, per-image result dicts built on the host; excludes disk + JPEG decode'}
 
     # ---------------- inference ----------------
     def bench_infer():
@@ -567,61 +548,59 @@ def main():
         summ, nprof = event_profile(infer_step, run)
         serial_ms = elapsed / args.steps * 1e3
         inflight = 1
+        degraded = (how != 'hipGraph replay' and not args.no_graph)          # the serial step fell back to eager launches
         if args.inflight >= 2 and how == 'hipGraph replay':
-            # Steps in flight: the K timed steps are the same K passes over the resident batch, but step i + 1 is enqueued on another
-            # stream than step i (its own captured graph, activations and result buffers), so it starts while step i drains -- the
-            # last round of every persistent kernel and the 20-to-160-workgroup detect launch leave most of the chip idle.  A caller
-            # with a queue of batches (Detector.detect_dataset, the pipeline leg) runs exactly like this.
+            # Steps in flight, through the package's own executor (Detector.stream() = lanes.DetectStream, the mode detect_dataset
+            # runs in): the K timed steps are the same K passes over the resident batch, but step i + 1 goes to another lane than
+            # step i (its own stream, captured graph, activations and packed result buffer), so it starts while step i drains -- the
+            # last round of every persistent kernel and the 160-workgroup detect launch leave most of the chip idle.  Every step's
+            # compact results are copied to pinned memory and unpacked on the host inside the timed region.
             try:
-                lanes = []
-                for _ in range(args.inflight):
-                    st = torch.cuda.Stream()
-                    ob = ops._det_buffers(B, cfg.keep_top_k, dev, cfg.num_anchors)
-                    st.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(st):
-                        det.detect_device(x, out=ob)
-                        st.synchronize()
-                        g = torch.cuda.CUDAGraph()
-                        mode = {'capture_error_mode': 'thread_local'} if (dist is not None and not os.environ.get('SQD_BENCH_GLOBAL_CAPTURE')) else {}
-                        with torch.cuda.graph(g, stream=st, **mode):
-                            det.detect_device(x, out=ob)
-                    lanes.append((st, g, ob))
-                torch.cuda.synchronize()
+                ex = det.stream(lanes=args.inflight)
 
                 def run_lanes(n):
-                    for i in range(n):
-                        st, g, _ = lanes[i % len(lanes)]
-                        with torch.cuda.stream(st):
-                            g.replay()
-                run_lanes(2 * len(lanes))
+                    last = None
+                    for _ in range(n):
+                        ex.submit_device(x)
+                        while ex.pending() > 2 * args.inflight - 1:
+                            last = ex.fetch()[1]
+                    for _t, last in ex.drain():
+                        pass
+                    return last
+                run_lanes(3 * args.inflight + 2)                       # eager first use, capture, a few replays per lane
                 barrier()
                 t0 = time.perf_counter()
-                run_lanes(args.steps)
+                last = run_lanes(args.steps)
                 barrier()
                 e2 = max_over_ranks(time.perf_counter() - t0)
                 t0 = time.perf_counter()
                 run_lanes(args.steps)
                 barrier()
                 r2 = max_over_ranks(time.perf_counter() - t0)
-                same = all(torch.equal(a, b) for a, b in zip(lanes[0][2][:5], out_bufs[:5])) and \
-                    all(torch.equal(a, b) for a, b in zip(lanes[0][2][:5], lanes[-1][2][:5]))
-                if not same:
+                want = [t.cpu().numpy() for t in out_bufs[:5]]
+                got = (last.count, last.class_ids, last.scores, last.boxes, last.anchor_idx)
+                if not all((a == b).all() for a, b in zip(got, want)):
                     raise RuntimeError('the lanes of the in-flight run disagree with the serial step')
-                elapsed, repeat, inflight = e2, r2, len(lanes)
-                how = f'hipGraph replay, {inflight} steps in flight (one stream per lane)'
-                del lanes
-            except Exception as e:  # noqa: BLE001 -- the serial measurement stands
+                if ex.degraded or ex.captures < args.inflight:
+                    raise RuntimeError('a lane did not capture its step')
+                elapsed, repeat, inflight = e2, r2, args.inflight
+                how = (f'Detector.stream(): lanes.DetectStream, {inflight} lanes, one captured hipGraph per lane, packed results copied to '
+                       f'pinned memory and unpacked per step')
+            except Exception as e:  # noqa: BLE001 -- the serial measurement stands, flagged
                 print(f'[bench] in-flight run failed ({type(e).__name__}: {e}); reporting the serial replays', file=sys.stderr)
                 torch.cuda.synchronize()
+                degraded = True
         ms = elapsed / args.steps * 1e3
         roof, kernels = roofline_of(summ, serial_ms, nprof)      # (kernel shares are of the serial step: in flight they overlap)
         value = B * joined * args.steps / elapsed
         gf = FWD_GFLOP_PER_IMAGE[args.arch]
         where = '1 MI355X' if joined == 1 else f'each of {joined} MI355X (independent replicas, no data-path collective)'
         result['infer'] = {
-            'value': round(value, 1), 'ms_per_step': round(ms, 4), 'timed_with': how,
+            'value': round(value, 1), 'ms_per_step': round(ms, 4), 'timed_with': how, 'degraded': bool(degraded),
             'repeat_window_ms_per_step': round(repeat / args.steps * 1e3, 4),
             'steps_in_flight': inflight, 'serial_ms_per_step': round(serial_ms, 4),      # (back-to-back replays on ONE stream)
+            'value_serial': round(B * joined / (serial_ms / 1e3), 1),                    # the bs=B step rate (what rounds 1-3 reported as value)
+            f'value_inflight{inflight}': round(value, 1),
             'eager_steps_launched': eager_steps[0],      # (profiling scripts divide launch counts by this; with --no-graph = every step)
             'workload': (f'SqueezeDet KITTI 1248x384 bs={B} inference on {where} (Fire+ConvDet HIP kernels, fused NMS)' if args.arch == 'squeezedet'
                          else f'SqueezeDet+ wider Fire modules at 1248x384 bs={B} inference on {where}'),
@@ -634,10 +613,16 @@ def main():
         }
         if not args.no_pipeline and args.arch == 'squeezedet':
             try:
-                result['infer']['pipeline'] = pipeline_leg(det, model)
+                result['infer']['pipeline'] = pipeline_leg(det)
             except Exception as e:  # noqa: BLE001 -- the end-to-end leg is a reported extra: its failure must not cost the main line
                 print(f'[bench] pipeline leg failed ({type(e).__name__}: {e})', file=sys.stderr)
                 result['infer']['pipeline'] = None
+                torch.cuda.synchronize()
+            try:
+                result['infer']['detect_dataset'] = dataset_leg(det)
+            except Exception as e:  # noqa: BLE001
+                print(f'[bench] detect_dataset leg failed ({type(e).__name__}: {e})', file=sys.stderr)
+                result['infer']['detect_dataset'] = None
                 torch.cuda.synchronize()
         if rank == 0 and joined == 1 and not args.no_cpu_baseline:
             # outputs of the step that was timed, for the parity check of the CPU leg: the detections the last replay left
@@ -651,6 +636,7 @@ def main():
         if os.environ.get('SQD_BENCH_KEEP_GRAPH'):       # diagnostics: leave the captured step alive next to the training half
             result['_keep'] = (model, det, run)
             return
+        det.__dict__.pop('_streams', None)
         del model, det, run, infer_step
         import gc
         gc.collect()
@@ -674,6 +660,7 @@ def main():
         def step():
             eager_steps[0] += 1
             return inner()
+        wanted_graph = (dist is None or args.backend == 'nccl') and not args.no_graph
         try:
             elapsed, repeat, how, run = measure(step, capture=(dist is None or args.backend == 'nccl'))
         except Exception as e:  # noqa: BLE001
@@ -699,6 +686,7 @@ def main():
                 print(f'[bench trace r{rank}] gradient exchange host time, last step: ' + ', '.join(f'{n} {t * 1e3:.2f} ms' for n, t in tr[-4:]), file=sys.stderr)
         result['train'] = {
             'value': round(B * joined * args.steps / elapsed, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4), 'timed_with': how,
+            'degraded': bool(wanted_graph and how != 'hipGraph replay'),       # a capture that failed: eager launches were timed instead
             'repeat_window_ms_per_step': round(repeat / args.steps * 1e3, 4),
             'eager_steps_launched': eager_steps[0],
             'workload': describe, 'roofline': roof, 'kernels_event_profile': kernels, 'layer_families': layer_families_of(summ),
@@ -739,13 +727,15 @@ def main():
             'roofline': head['roofline'], 'cpu_baseline': cpu, 'parity': parity,
             'whole_network': head.get('whole_network'), 'timed_with': head['timed_with'],
             'repeat_window_ms_per_step': head['repeat_window_ms_per_step'],
-            **({'steps_in_flight': head['steps_in_flight'], 'serial_ms_per_step': head['serial_ms_per_step']} if 'steps_in_flight' in head else {}),
+            **({k: head[k] for k in head if k in ('steps_in_flight', 'serial_ms_per_step', 'value_serial', 'degraded') or k.startswith('value_inflight')}),
             'layer_families': head['layer_families'], 'kernels_event_profile': head['kernels_event_profile'],
         }
         if 'eager_steps_launched' in head:
             line['eager_steps_launched'] = head['eager_steps_launched']
         if head.get('pipeline') is not None:
             line['pipeline'] = head['pipeline']
+        if head.get('detect_dataset') is not None:
+            line['detect_dataset'] = head['detect_dataset']
         if args.layers:
             line['layers'] = layer_detail
         if args.mode == 'both':

@@ -276,6 +276,11 @@ int sqd_conv_drop_fwd(const float* x, const float* w_packed, const float* bias, 
 int sqd_dropout_mask_fwd(const unsigned long long* state, int keep16, float scale, float* mask, long long n4, void* stream);
 int sqd_dropout_advance(unsigned long long* state, void* stream);
 
+/* One wave that idles for `us` microseconds (0 <= us <= 20000) on `stream`.  No reference counterpart: the lane executor of the
+ * inference driver (Detector.detect_dataset, src/engine/detector.py:52-85; lanes.py here) uses it once to detect which of its
+ * streams share a hardware queue (work queued behind the spin on another stream = aliased). */
+int sqd_spin_us(int us, void* stream);
+
 /* Fused MaxPool2d(3, 2, ceil_mode) + Fire squeeze 1x1 + ReLU, inference forward (src/model/squeezedet.py:39,42 followed
  * by :12,18): y[..., y_coff : y_coff+N] = ReLU(conv1x1(pool(x[..., x_coff : x_coff+C])) + bias); the pooled tensor is never
  * materialised.  x NHWC [B][H][W][x_pitch], y NHWC [B][Ho][Wo][y_pitch]; w_packed = sqd_pack_conv_weight output for a 1x1

@@ -65,6 +65,7 @@ _SIGNATURES = {
     'sqd_conv_drop_fwd': [c_p] * 4 + [c_i] * 11 + [c_p, c_i, c_f, c_i, c_p],
     'sqd_dropout_mask_fwd': [c_p, c_i, c_f, c_p, ctypes.c_longlong, c_p],
     'sqd_dropout_advance': [c_p, c_p],
+    'sqd_spin_us': [c_i, c_p],
     'sqd_pack_wino_weight': [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_pack_wino_weights_batched': [c_p, c_i, c_i, c_p],
     'sqd_pack_wino_fire': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],

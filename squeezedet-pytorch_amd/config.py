@@ -27,6 +27,7 @@ def make_cfg(arch='squeezedet', input_size=KITTI_INPUT_SIZE, anchors_seed=KITTI_
         negative_score_loss_weight=100., bbox_loss_weight=6.,
         nms_thresh=0.4, score_thresh=0.3, keep_top_k=64,
         gpus=[0], chunk_sizes=[20], num_iters=-1, print_interval=10, debug=0, num_workers=4, forbid_resize=False,
+        inflight=2,                  # batches in flight on the device in Detector.stream / detect_dataset (lanes.DetectStream)
         input_size=tuple(input_size), num_classes=num_classes, class_names=tuple(class_names),
         anchors=anchors, anchors_per_grid=int(np.asarray(anchors_seed).shape[0]),
         num_anchors=int(anchors.shape[0]), grid_size=grid_size, device=device,

@@ -28,3 +28,25 @@ extern "C" int sqd_dropout_advance(unsigned long long* state, void* stream) {
   hipLaunchKernelGGL(dropout_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
   return sqd_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A kernel that does nothing for `us` microseconds (one wave polling the constant-rate wall clock).  Used by the lane executor
+// (lanes.py) to find out, once, which of its HIP streams share a hardware queue: work on two streams that alias one queue is
+// serialised by the queue's in-order barrier packets, which costs the inference driver (reference: src/engine/detector.py:52-85)
+// its copy / compute overlap.  Every wave leaves after at most 20 ms.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int sqd_spin_us(int us, void* stream) {
+  SQD_CHECK_ARG(us >= 0 && us <= 20000);
+  int dev = 0, khz = 100000;                                         // wall_clock64 ticks at a constant 100 MHz on gfx9
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, dev) == hipSuccess && v > 0) khz = v;
+  }
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)us * khz / 1000);
+  return sqd_launch_status();
+}

@@ -1,7 +1,8 @@
 """``Detector`` with the reference's interface (src/engine/detector.py:14-122): ``detect(batch)``
 returns one dict per image (numpy arrays, boxes mapped back to original-image coordinates),
 ``filter(det)`` filters one image's dense detections, ``detect_dataset(dataset)`` is the reference's inference driver
-(:52-85) on the GPU input pipeline, ``DataWrapper`` its annotation-free dataset view (:125-145).
+(:52-85) on the GPU input pipeline and the lane executor (``stream`` / ``detect_stream``, lanes.py), ``DataWrapper`` its
+annotation-free dataset view (:125-145).
 
 Where the reference loops over the batch in Python with >= 10 host syncs per image (boolean-mask
 indexing, ``torch.sum(..) == 0``, per-image ``.cpu()``), this runs ONE fused kernel for the whole
@@ -104,13 +105,42 @@ class Detector(object):
                             'anchor_idx': idx[b, :n].astype(np.int64), 'image_meta': m})
         return results
 
+    # ---- the inference driver's execution mode: lanes of captured steps (lanes.DetectStream) ----
+    def stream(self, lanes=None, graph=True, rgb_mean=None, rgb_std=None):
+        """The (cached) ``lanes.DetectStream`` of this detector: ``lanes`` batches in flight on the device, each lane replaying a
+        captured hipGraph of preprocess -> backbone -> fused detect; uint8 upload on a copy stream, ONE packed result copy per
+        batch into pinned memory, results handed out late.  ``cfg.inflight`` (default 2) is the default lane count."""
+        from .lanes import DetectStream
+        lanes = int(lanes if lanes is not None else getattr(self.cfg, 'inflight', 2))
+        key = (lanes, bool(graph), None if rgb_mean is None else tuple(np.asarray(rgb_mean, np.float32).reshape(-1).tolist()),
+               None if rgb_std is None else tuple(np.asarray(rgb_std, np.float32).reshape(-1).tolist()),
+               bool(getattr(self.cfg, 'forbid_resize', False)), int(getattr(self.cfg, 'batch_size', 20)))
+        cache = self.__dict__.setdefault('_streams', {})
+        ex = cache.get(key)
+        if ex is None:
+            if len(cache) > 4:
+                cache.clear()
+            ex = cache[key] = DetectStream(self, lanes=lanes, graph=graph, rgb_mean=rgb_mean, rgb_std=rgb_std)
+        return ex
+
+    def detect_stream(self, batches, lanes=None, rgb_mean=None, rgb_std=None):
+        """Generator: an iterable of batches (lists of uint8 HWC RGB images of any sizes, or ``(images, image_ids)`` pairs) -> per
+        batch, in order, the list of per-image result dicts ``detect_images`` would return -- bit for bit -- while the batches
+        overlap on the device (see ``stream``).  Results trail the input by up to ``2 * lanes - 1`` batches."""
+        ex = self.stream(lanes=lanes, rgb_mean=rgb_mean, rgb_std=rgb_std)
+        if ex.pending():
+            raise RuntimeError('detect_stream: the detector\'s stream still holds un-fetched batches')
+        return ex.run(batches)
+
     def detect_dataset(self, dataset):
         """The reference's inference driver (src/engine/detector.py:52-85: DataLoader over ``DataWrapper(dataset)`` -> ``detect`` per
-        batch -> timing lines -> list of per-image results), on the GPU input pipeline: ``dataset.load_image(i)`` -> raw image ->
-        uint8 upload -> ``preprocess_kernel`` -> backbone -> fused detect (``detect_images``); the images of batch i + 1 are loaded
-        by ``cfg.num_workers`` threads while batch i is on the GPU.  Images whose pixels are not uint8-representable (a dataset that
-        hands out pre-whitened floats) take the reference's own route instead: ``dataset.preprocess`` on the host, then ``detect``.
-        Same printed lines and the same result dicts (``image_meta['index']`` = dataset index) as the reference."""
+        batch -> timing lines -> list of per-image results) in this package's execution mode (``stream``): ``cfg.num_workers``
+        threads load ``dataset.load_image(i)`` one batch ahead AND pack the raw pixels straight into the pinned staging buffer of
+        the batch; the main thread only enqueues (one H2D copy, one captured step on the next lane, one D2H copy) and collects the
+        results of batches that have finished, ``cfg.inflight`` (default 2) batches overlapping on the device.  Images whose pixels
+        are not uint8-representable (a dataset that hands out pre-whitened floats) take the reference's own route instead:
+        ``dataset.preprocess`` on the host, then ``detect``.  Same printed lines and the same result dicts
+        (``image_meta['index']`` = dataset index) as the reference; identical, bit for bit, to ``detect_images`` batch by batch."""
         cfg = self.cfg
         n = len(dataset)
         bs = max(1, int(getattr(cfg, 'batch_size', 1)))
@@ -119,37 +149,63 @@ class Detector(object):
         t_start = time.time()
         results = []
         data_s = net_s = 0.0
+        workers = int(getattr(cfg, 'num_workers', 4))
+        ex = self.stream(rgb_mean=getattr(dataset, 'rgb_mean', None), rgb_std=getattr(dataset, 'rgb_std', None)) if batches else None
+        if ex is not None and ex.pending():
+            raise RuntimeError('detect_dataset: the detector\'s stream still holds un-fetched batches')
+
+        def load_into(st, b, i):
+            im, iid = dataset.load_image(i)
+            return im, iid, st.put(b, im)
+
+        def collect_results(force=False):
+            while ex.pending() and (force or ex.pending() > 2 * len(ex._lanes) - 1 or ex.oldest_ready()):
+                _t, r = ex.fetch()
+                out = r.per_image()
+                for d, i in zip(out, r.tag):
+                    d['image_meta']['index'] = i
+                results.extend(out)
+
         # One future per IMAGE, submitted straight to the pool (a per-batch task that itself waits on the pool's workers deadlocks a
         # one-worker pool); num_workers = 0 (the reference's "load in the main process") loads inline.
-        workers = int(getattr(cfg, 'num_workers', 4))
-        mean, std = getattr(dataset, 'rgb_mean', None), getattr(dataset, 'rgb_std', None)
         with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
-            if workers > 0:
-                submit = lambda idxs: [pool.submit(dataset.load_image, i) for i in idxs]       # noqa: E731
-                collect = lambda futs: [f.result() for f in futs]                              # noqa: E731  [(image, image_id), ...]
-            else:
-                submit = lambda idxs: idxs                                                     # noqa: E731
-                collect = lambda idxs: [dataset.load_image(i) for i in idxs]                   # noqa: E731
-            pending = submit(batches[0]) if batches else None
-            for it, idxs in enumerate(batches):
-                t0 = time.time()
-                loaded = collect(pending)
-                pending = submit(batches[it + 1]) if it + 1 < len(batches) else None
-                data_s = time.time() - t0
-                t0 = time.time()
-                raw = [np.asarray(im) for im, _ in loaded]
-                ids = [iid for _, iid in loaded]
-                as_u8 = [im if im.dtype == np.uint8 else im.astype(np.uint8) for im in raw]
-                if all(im.ndim == 3 and im.shape[2] == 3 and (im.dtype == np.uint8 or np.array_equal(u8, im)) for im, u8 in zip(raw, as_u8)):
-                    out = self.detect_images(as_u8, image_ids=ids, rgb_mean=mean, rgb_std=std)
-                    for r, i in zip(out, idxs):
-                        r['image_meta']['index'] = i
-                else:
-                    out = self.detect(_host_batch(dataset, raw, ids, idxs, cfg.device))
-                results.extend(out)
-                net_s = time.time() - t0
-                if it % every == 0:
-                    print('eval: [{0}/{1}] | data {2:.3f}s | net {3:.3f}s'.format(it, len(batches), data_s, net_s))
+            def begin(idxs):
+                st = ex.stage(len(idxs))
+                if workers > 0:
+                    return st, [pool.submit(load_into, st, b, i) for b, i in enumerate(idxs)]
+                return st, idxs
+
+            def finish(st, pend):
+                if workers > 0:
+                    return [f.result() for f in pend]
+                return [load_into(st, b, i) for b, i in enumerate(pend)]
+            pending = begin(batches[0]) if batches else None
+            try:
+                for it, idxs in enumerate(batches):
+                    t0 = time.time()
+                    st, pend = pending
+                    loaded = finish(st, pend)                          # [(image, image_id, packed), ...]
+                    pending = begin(batches[it + 1]) if it + 1 < len(batches) else None
+                    data_s = time.time() - t0
+                    t0 = time.time()
+                    ids = [iid for _, iid, _ in loaded]
+                    if all(ok for _, _, ok in loaded):
+                        ex.submit(st, image_ids=ids, tag=idxs)
+                    else:
+                        ex.discard(st)
+                        collect_results(force=True)                    # keep the dataset order
+                        results.extend(self.detect(_host_batch(dataset, [np.asarray(im) for im, _, _ in loaded], ids, idxs, cfg.device)))
+                    collect_results()
+                    net_s = time.time() - t0
+                    if it % every == 0:
+                        print('eval: [{0}/{1}] | data {2:.3f}s | net {3:.3f}s'.format(it, len(batches), data_s, net_s))
+            except BaseException:
+                if ex is not None:                                 # leave the cached executor reusable: nothing open, nothing queued
+                    ex._open.clear()
+                    ex.drain()
+                raise
+            if ex is not None:
+                collect_results(force=True)
         total = time.time() - t_start
         tpi = total / max(n, 1)
         print('Elapsed {:.2f}min ({:.1f}ms/image, {:.1f}frames/s)'.format(total / 60., tpi * 1000., 1. / max(tpi, 1e-12)))

@@ -259,10 +259,11 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=No
                 raise ValueError(f'conv_wino: {nm} must have the shape of y')
     if plan.cfg_id % 1000 == tiles.WINO_SK_CFG:
         sk = wino_sk_schedule(B * -(-H // 4) * -(-W // 16), plan.N, plan.C, x.device)
+        sk_ws, sk_cnt = sk.workspace()               # (per launch stream: concurrent lanes must not share slabs / tickets)
         rc = nat.lib().sqd_conv_wino_sk_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), nat.ptr(ymask), nat.ptr(ymul),
                                             float(yscale), B, H, W, plan.C, xp, x_coff, plan.N, plan.Npad, yp, y_coff, int(relu),
-                                            int(accumulate), nat.ptr(sk.seg_off), nat.ptr(sk.segs), sk.G, sk.nslabs, nat.ptr(sk.ws),
-                                            nat.ptr(sk.cnt), nat.ptr(drop.state) if drop is not None else None,
+                                            int(accumulate), nat.ptr(sk.seg_off), nat.ptr(sk.segs), sk.G, sk.nslabs, nat.ptr(sk_ws),
+                                            nat.ptr(sk_cnt), nat.ptr(drop.state) if drop is not None else None,
                                             drop.keep16 if drop is not None else 0, float(drop.scale) if drop is not None else 0.0,
                                             nat.ptr(drop_advance.state) if drop_advance is not None else None, nat.stream_handle(x.device))
         nat.check(rc, 'sqd_conv_wino_sk_fwd')
@@ -623,19 +624,25 @@ def _det_buffers(B, K, device, A=None):
     return bufs
 
 
+def det_packed_layout(B, K):
+    """Byte layout of the packed result buffer: [(offset, elements, dtype, shape)] for (count, class_ids, scores, boxes, anchor_idx)
+    -- 16-byte aligned sections -- and the total size.  The host reads a copied buffer back through the same table (lanes.py)."""
+    sizes = [(B, torch.int32), (B * K, torch.int64), (B * K, torch.float32), (B * K * 4, torch.float32), (B * K, torch.int32)]
+    shapes = [(B,), (B, K), (B, K), (B, K, 4), (B, K)]
+    secs, off = [], 0
+    for (n, dt), shp in zip(sizes, shapes):
+        off = -(-off // 16) * 16
+        secs.append((off, n, dt, shp))
+        off += n * torch.empty(0, dtype=dt).element_size()
+    return secs, -(-off // 16) * 16
+
+
 def det_buffers_packed(B, K, device, A=None):
     """The same five result tensors as views of ONE allocation (16-byte aligned sections), so that a whole batch's compact
     detections leave the GPU with a single device-to-host copy.  -> (bufs as ``_det_buffers``, flat uint8 tensor)."""
-    sizes = [(B, torch.int32), (B * K, torch.int64), (B * K, torch.float32), (B * K * 4, torch.float32), (B * K, torch.int32)]
-    shapes = [(B,), (B, K), (B, K), (B, K, 4), (B, K)]
-    offs, off = [], 0
-    for n, dt in sizes:
-        off = -(-off // 16) * 16
-        offs.append(off)
-        off += n * torch.empty(0, dtype=dt).element_size()
-    flat = torch.zeros(-(-off // 16) * 16, device=device, dtype=torch.uint8)
-    bufs = tuple(flat[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt).view(shp)
-                 for o, (n, dt), shp in zip(offs, sizes, shapes))
+    secs, total = det_packed_layout(B, K)
+    flat = torch.zeros(total, device=device, dtype=torch.uint8)
+    bufs = tuple(flat[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt).view(shp) for o, n, dt, shp in secs)
     if A is not None:
         bufs = bufs + (_det_workspace(B, A, device),)
     return bufs, flat

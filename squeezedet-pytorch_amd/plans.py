@@ -170,18 +170,40 @@ def wino_sk_host_schedule(ngroups, N, C, G, minseg=2, h_bias_pm=1000, ksplit=0):
 
 
 class WinoSkSchedule:
-    """Device copy of the balanced schedule of one (pixel geometry, N, C) layer shape + its partial-slab workspace and arrival
-    counters (zeroed once; every launch leaves them zero).  Shared by every layer of that shape: launches on one stream are ordered."""
+    """Device copy of the balanced schedule of one (pixel geometry, N, C) layer shape, shared by every layer of that shape, + the
+    partial-slab workspaces and arrival counters of its launches (zeroed once; every launch leaves its counters zero).  A workspace
+    belongs to ONE stream: launches on a stream are ordered, launches on different streams (two inference lanes, two user threads)
+    may overlap and must not share slabs or tickets, so ``workspace()`` hands out one set per launch stream."""
 
     def __init__(self, ngroups, N, C, device):
         self.G = wino_sk_grid()
         minseg, hb, ks = wino_sk_params(N, C)
         seg_off, segs, nslabs = wino_sk_host_schedule(ngroups, N, C, self.G, minseg, hb, ks)
+        self.device = torch.device(device)
         self.seg_off = torch.from_numpy(seg_off).to(device)
         self.segs = torch.from_numpy(segs).contiguous().to(device)
         self.nslabs = nslabs
-        self.ws = torch.empty(max(nslabs, 1) * 8192, device=device, dtype=torch.float32)
-        self.cnt = torch.zeros(max(nslabs, 1) * 4, device=device, dtype=torch.int32)
+        self._ws = {}
+
+    def workspace(self):
+        """(slab workspace, arrival counters) of the stream the launch is about to be enqueued on."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        hit = self._ws.get(key)
+        if hit is None:
+            if len(self._ws) > 16:
+                self._ws.clear()
+            hit = self._ws[key] = (torch.empty(max(self.nslabs, 1) * 8192, device=self.device, dtype=torch.float32),
+                                   torch.zeros(max(self.nslabs, 1) * 4, device=self.device, dtype=torch.int32))
+        return hit
+
+    # (single-stream callers and the tests read these)
+    @property
+    def ws(self):
+        return self.workspace()[0]
+
+    @property
+    def cnt(self):
+        return self.workspace()[1]
 
 
 def wino_sk_schedule(ngroups, N, C, device):
