@@ -232,6 +232,12 @@ int sqd_wino_cfg_info(int cfg_id, int* bn, int* waves);
 int sqd_conv_wino_fwd(const float* x, const float* u_packed, const float* bias, float* y, const float* ymask, const float* ymul,
                       int B, int H, int W, int C, int x_pitch, int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu,
                       int accumulate, int cfg_id, void* stream);
+/* The same convolution for NARROW outputs and long reductions -- ConvDet (Conv2d(768 -> 72, 3, padding 1), src/model/squeezedet.py:
+ * 73-75,83; squeezedetplus 512 -> 72): N <= 80, u_packed = sqd_pack_wino_weight output with Npad = 80.  Twelve-wave workgroups of
+ * (4x16-pixel group, 16-channel block) units whose waves share the group's transformed input through LDS (csrc/conv_wino_vs.hip);
+ * bias + optional ReLU epilogue only.  Results equal sqd_conv_wino_fwd's bit for bit. */
+int sqd_conv_wino_vs_fwd(const float* x, const float* u_packed, const float* bias, float* y, int B, int H, int W, int C, int x_pitch,
+                         int x_coff, int N, int Npad, int y_pitch, int y_coff, int relu, void* stream);
 /* Transformed weights U = G g G^T of an OIHW [No][Ci][3][3] parameter into the layout above; dgrad != 0 packs the
  * data-gradient orientation (in/out channels swapped, taps flipped). */
 int sqd_pack_wino_weight(const float* w_oihw, float* u_packed, int No, int Ci, int Npad, int dgrad, void* stream);

@@ -1,0 +1,4 @@
+#!/bin/bash
+T=gpurun_out/r05f; mkdir -p $T
+timeout -k 10 300 python scratch/vs_check.py > $T/vs_check.log 2>&1; echo rc $?; grep -v amdgpu.ids $T/vs_check.log | tail -6
+timeout -k 10 300 python scratch/diag/vs_diag.py > $T/vs_diag.log 2>&1; echo rc $?; grep -v amdgpu.ids $T/vs_diag.log

@@ -59,6 +59,7 @@ _SIGNATURES = {
     'sqd_wino_num_cfgs': [],
     'sqd_wino_cfg_info': [c_i, c_p, c_p],
     'sqd_conv_wino_fwd': [c_p] * 6 + [c_i] * 13 + [c_p],
+    'sqd_conv_wino_vs_fwd': [c_p] * 4 + [c_i] * 11 + [c_p],
     'sqd_wino_sk_grid': [],
     'sqd_wino_sk_schedule': [c_i] * 7 + [c_p, c_p, c_i, c_p, c_p],
     'sqd_conv_wino_sk_fwd': [c_p] * 6 + [c_f] + [c_i] * 12 + [c_p, c_p, c_i, c_i, c_p, c_p] + [c_p, c_i, c_f, c_p] + [c_p],

@@ -21,6 +21,20 @@ static inline int sqd_launch_status() {
 
 static inline int sqd_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the device that is current at the call: kernels that need more than 64 KB of
+// LDS set it once PER DEVICE (a process may launch on several: reference-style DataParallel, tests that switch devices).  Idempotent,
+// so two threads racing through the first launch on a device is harmless.
+struct SqdDevOnce { unsigned long long done = 0; };
+static inline int sqd_max_lds_once(SqdDevOnce& st, const void* kern, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SQD_ERR_LAUNCH;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(&st.done, __ATOMIC_ACQUIRE) & bit) return SQD_OK;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return SQD_ERR_LAUNCH;
+  __atomic_fetch_or(&st.done, bit, __ATOMIC_RELEASE);
+  return SQD_OK;
+}
+
 // v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16], exact fp32 (k-ordered fma chain).
 // lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; acc reg r holds D[4*(l>>4)+r][l&15].
 // Workgroup id -> position in a persistent kernel's tile walk such that the workgroups of ONE XCD (ids w, w + 8, w + 16, ... share

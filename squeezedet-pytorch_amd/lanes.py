@@ -200,6 +200,11 @@ class DetectStream:
         # lanes + upload + download each on a hardware queue of their own: two of them on one queue serialise behind each other's
         # barrier packets (measured: 1.46 ms per batch of 20 with separate queues, 2.24 ms when the copy stream shares a lane's)
         streams, self.queues_distinct = pick_streams(self.device, lanes + 2)
+        if not self.queues_distinct:
+            # fewer hardware queues than streams (4 per process by default): give up the download stream first -- the packed
+            # results then leave on the lane's own stream, behind its step -- and keep lanes and upload apart
+            streams, self.queues_distinct = pick_streams(self.device, lanes + 1)
+            streams.append(None)
         with torch.cuda.device(self.device):
             self._lanes = [_Lane(self.device, i, streams[i]) for i in range(lanes)]
             self._copy, self._back = streams[lanes], streams[lanes + 1]
@@ -355,7 +360,11 @@ class DetectStream:
         nb = self._bufs(lane, n, with_input=False)
         key = ('dev', n, image.data_ptr(), tuple(image.shape), None if scales is None else scales.data_ptr(),
                None if shifts is None else shifts.data_ptr())
-        lane.comp.wait_stream(torch.cuda.current_stream(self.device))     # whatever produced the tensors on the caller's stream
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != lane.comp.cuda_stream and not cur.query():
+            # whatever is still producing the tensors on the caller's stream.  Skipped when that stream is idle: the marker of an
+            # unconditional wait sits in a hardware queue the caller's stream shares with one of the lanes and would serialise them
+            lane.comp.wait_stream(cur)
 
         def compute():
             self.det.detect_device(image, scales=scales, shifts=shifts, out=nb['out'])
@@ -425,10 +434,11 @@ class DetectStream:
             lane.done.record(lane.comp)
         r = nb['uses'] & 1
         nb['uses'] += 1
-        with torch.cuda.stream(self._back):                   # compact results -> pinned memory on a stream of their own: neither
-            self._back.wait_event(lane.done)                  # the lanes nor the uploads wait for the copy
+        back = self._back if self._back is not None else lane.comp
+        with torch.cuda.stream(back):                         # compact results -> pinned memory on a stream of their own: neither
+            back.wait_event(lane.done)                        # the lanes nor the uploads wait for the copy
             nb['res'][r].copy_(nb['flat'], non_blocking=True)
-            nb['copied'][r].record(self._back)
+            nb['copied'][r].record(back)
         lane.last_copied = nb['copied'][r]
         self._seq += 1
         self._outstanding.append((self._seq, nb, r, meta, tag))

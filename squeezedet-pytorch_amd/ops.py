@@ -267,6 +267,14 @@ def conv_wino(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, ymask=No
                                             drop.keep16 if drop is not None else 0, float(drop.scale) if drop is not None else 0.0,
                                             nat.ptr(drop_advance.state) if drop_advance is not None else None, nat.stream_handle(x.device))
         nat.check(rc, 'sqd_conv_wino_sk_fwd')
+    elif plan.cfg_id % 1000 == tiles.WINO_VS_CFG:
+        if yscale != 1.0 or drop is not None or drop_advance is not None or accumulate or ymask is not None or ymul is not None:
+            raise ValueError('conv_wino: the V-shared kernel (cfg tiles.WINO_VS_CFG) has the plain bias / ReLU epilogue only')
+        if plan.N > 80 or plan.Npad != 80:
+            raise ValueError('conv_wino: the V-shared kernel (cfg tiles.WINO_VS_CFG) runs N <= 80 packed 80 wide')
+        rc = nat.lib().sqd_conv_wino_vs_fwd(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), B, H, W, plan.C, xp, x_coff,
+                                            plan.N, plan.Npad, yp, y_coff, int(relu), nat.stream_handle(x.device))
+        nat.check(rc, 'sqd_conv_wino_vs_fwd')
     else:
         if yscale != 1.0 or drop is not None or drop_advance is not None:
             raise ValueError('conv_wino: yscale / drop / drop_advance need the balanced kernel (cfg tiles.WINO_SK_CFG)')

@@ -153,12 +153,13 @@ def choose_fused_cfg(C, E, npix):
 
 
 WINO_SK_CFG = 16            # the balanced (stream-K) Winograd kernel, csrc/conv_wino_sk.hip (32-channel packing, four waves)
+WINO_VS_CFG = 17            # the V-shared kernel for N <= 80 (ConvDet), csrc/conv_wino_vs.hip (80-channel packing, twelve waves)
 
 
 def wino_cfgs():
     """{cfg_id: (slice width, waves per workgroup)} of the Winograd F(2x2,3x3) kernel family."""
     import ctypes
-    out = {WINO_SK_CFG: (32, 4)}
+    out = {WINO_SK_CFG: (32, 4), WINO_VS_CFG: (80, 12)}
     for i in range(nat.lib().sqd_wino_num_cfgs()):
         bn, wv = ctypes.c_int(), ctypes.c_int()
         nat.check(nat.lib().sqd_wino_cfg_info(i, ctypes.byref(bn), ctypes.byref(wv)), 'sqd_wino_cfg_info')
@@ -172,6 +173,8 @@ def wino_kernel_name(cfg_id):
     c = cfg_id % 1000
     if c == WINO_SK_CFG:
         return 'conv_wino_sk'
+    if c == WINO_VS_CFG:
+        return 'conv_wino_vs'
     bn, wv = wino_cfgs()[c]
     return f'conv_wino{("", "_dp", "_us")[c // 4]}<{bn // 16},{wv}>'
 
@@ -180,7 +183,7 @@ def wino_cfg_ok(cfg_id, C):
     """Whether Winograd configuration ``cfg_id`` can run a layer with ``C`` input channels: ids 8..11 (U-stationary kernel)
     keep the slice's whole transformed weight set in LDS next to the patch ring."""
     c = cfg_id % 1000
-    if c < 8 or c == WINO_SK_CFG:
+    if c < 8 or c in (WINO_SK_CFG, WINO_VS_CFG):
         return True
     bn, wv = wino_cfgs()[c]
     return (2 * wv * 256 * 4 + (C // 8) * 32 * bn * 4) * 4 <= 160 * 1024
@@ -194,7 +197,17 @@ def choose_wino_cfg(C, N, npix):
     hit = _tuning().get(f'W:{C}:{N}:{npix}')
     if hit is None:
         hit = _nearest_tuned(f'W:{C}:{N}:', npix) if any(k.startswith(f'W:{C}:{N}:') for k in _tuning()) else None
+        if hit is not None and hit % 1000 == WINO_VS_CFG and not wino_vs_fills_chip(npix):
+            hit = 2                 # a neighbouring batch size measured the V-shared kernel; here its one-workgroup-per-CU grid would not fill
     return hit if (hit is not None and hit >= 0) else None
+
+
+def wino_vs_fills_chip(npix, cus=256):
+    """The V-shared kernel (WINO_VS_CFG) runs ONE twelve-unit workgroup per CU: its grid of ceil(5 * groups / 12) workgroups (groups of
+    64 pixels, estimated from the pixel count) should fill >= 85 % of its rounds -- 250 workgroups at bs=20, 24x78; at bs=8 (100
+    workgroups) conv_wino<2,4> measured 128 against 174 us."""
+    nwg = -(-5 * -(-npix // 64) // 12)
+    return nwg / (cus * -(-nwg // cus)) >= 0.85
 
 
 FIRE_WINO_CFGS = (4, 6, 8, 10, 12)  # 32-channel-slice ids of the deep-prefetch / U-stationary Winograd family; 12: the small-C form
