@@ -80,13 +80,20 @@ int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw,
  * descs_dev = device array of n records of 9 int64 {slab offset, dw offset, db offset (floats from slab_base / grad_base;
  * db offset < 0: no bias gradient), S, slab stride (= N*taps*C + N), N, C, taps, first workgroup of the record}
  * (a record takes ceil((N*taps*C + N) / 64) workgroups; total_blocks = their sum).  Results are bitwise those of the
- * per-layer reduction. */
-int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base, void* stream);
+ * per-layer reduction, times `scale` (1 = exactly the sum; the data-parallel exchange passes the rank's image count: the
+ * weighting of src/utils/data_parallel.py's gathered loss mean, src/engine/trainer.py:43). */
+int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base, float scale,
+                             void* stream);
 /* The same for a contiguous range of the table: descs_dev = address of the range's first record, n = records in the
  * range, block_first = that record's "first workgroup" field, nblocks = workgroups of the range.  Lets the backward of
  * src/engine/trainer.py:47 hand each finished stage's gradient bucket to the all-reduce early. */
 int sqd_wgrad_reduce_batched_range(const void* descs_dev, int n, int block_first, int nblocks, const float* slab_base,
-                                   float* grad_base, void* stream);
+                                   float* grad_base, float scale, void* stream);
+/* Element-wise steps of the gradient exchange that replaces the reference's DataParallel (src/engine/trainer.py:82-92,
+ * src/utils/data_parallel.py:93-113): g[0..n) = g * mul, divided by *div_by when div_by != NULL (a DEVICE scalar: the image count
+ * summed by the same all-reduce); fill_ptr (or NULL, outside [g, g+n)) receives fill_value (this rank's image count).  n may be 0
+ * with fill_ptr given. */
+int sqd_grad_scale(float* g, long long n, float mul, const float* div_by, float* fill_ptr, float fill_value, void* stream);
 
 
 /* Stem weight + bias gradient (the image needs no data gradient).  slab: S*(N*3*k*k + N) floats. */
@@ -129,16 +136,6 @@ int sqd_stem_pool_squeeze_fwd(const float* x_nchw, const float* w_oihw, const fl
 int sqd_stem_pool_squeeze_train_fwd(const float* x_nchw, const float* w_oihw, const float* bias, const float* w_sq, const float* b_sq,
                                     float* y_pooled, unsigned char* argmax, float* y_sq, int B, int Hin, int Win, int N, int ksize,
                                     int nsq, void* stream);
-
-/* Fire.squeeze + squeeze_activation + Fire.expand1x1 + expand1x1_activation (src/model/squeezedet.py:17-19) in ONE launch: the
- * squeeze tile feeds the expand1x1 from registers.  y_sq[..., sq_coff : +Nsq] = the squeeze output (read by the expand3x3 launch and
- * by the backward), y_out[..., out_coff : +E1] = the expand1x1 half of the Fire's concat.  Both weight sets packed as by
- * sqd_pack_conv_weight with kc = 32 (Npad = rows of the packing).  Nsq in {16, 32, 48, 64, 96}, E1 % 32 == 0, C > 32; anything else
- * returns SQD_ERR_UNSUPPORTED.  wg_cap as in sqd_conv_fwd (cfg_id / 1000). */
-int sqd_fire_squeeze_expand1x1_fwd(const float* x, const float* wsq_packed, const float* bsq, float* y_sq,
-                                   const float* we1_packed, const float* be1, float* y_out, int B, int H, int W, int C,
-                                   int x_pitch, int x_coff, int Nsq, int Nsq_pad, int sq_pitch, int sq_coff, int E1,
-                                   int E1_pad, int out_pitch, int out_coff, int wg_cap, void* stream);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True) (src/model/squeezedet.py:36,39,42), NHWC.
  * argmax (uint8, same shape as y, may be NULL) records the window position 0..8 for the backward. */

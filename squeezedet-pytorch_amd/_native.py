@@ -31,8 +31,9 @@ _SIGNATURES = {
     'sqd_pack_conv_weight': [c_p, c_p] + [c_i] * 6 + [c_p],
     'sqd_pack_conv_weights_batched': [c_p, c_i, c_i, c_p],
     'sqd_conv_wgrad': [c_p] * 5 + [c_i] * 11 + [c_p],
-    'sqd_wgrad_reduce_batched': [c_p, c_i, c_i, c_p, c_p, c_p],
-    'sqd_wgrad_reduce_batched_range': [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    'sqd_wgrad_reduce_batched': [c_p, c_i, c_i, c_p, c_p, c_f, c_p],
+    'sqd_wgrad_reduce_batched_range': [c_p, c_i, c_i, c_i, c_p, c_p, c_f, c_p],
+    'sqd_grad_scale': [c_p, ctypes.c_longlong, c_f, c_p, c_p, c_f, c_p],
     'sqd_conv_wgrad_wino': [c_p] * 5 + [c_i] * 11 + [c_p],
     'sqd_squeeze_bwd': [c_p] * 5 + [c_i] * 13 + [c_p],
     'sqd_stem_wgrad': [c_p] * 5 + [c_i] * 6 + [c_p],
@@ -42,7 +43,6 @@ _SIGNATURES = {
     'sqd_stem_conv_relu_pool_fwd': [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_stem_pool_squeeze_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     'sqd_stem_pool_squeeze_train_fwd': [c_p] * 8 + [c_i] * 6 + [c_p],
-    'sqd_fire_squeeze_expand1x1_fwd': [c_p] * 7 + [c_i] * 15 + [c_p],
     'sqd_maxpool3x3s2_ceil_fwd': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_fwd_relu': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     'sqd_maxpool3x3s2_ceil_bwd': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],

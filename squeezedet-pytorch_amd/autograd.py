@@ -139,21 +139,12 @@ def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
                     ym = ops.dropout_mask(dr, (Bq, H, W, e1 + e3))
                     drop_mask = ym
                     dr = None
-            # squeeze + expand1x1 in ONE launch (the squeeze tile feeds the expand1x1 from registers; forward of inference AND training)
-            # wherever the two would otherwise be separate plain launches
-            chain = (bridged is None and unpooled is None and zseg is None and zseg_t is None and ycfg is None and ycfg_t is None and xcfg is None and fcfg is None and ym is None
-                     and dr is None and base.fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1))
             out = None
             if bridged is not None:
                 sq, bridged = bridged, None
             else:
                 sq = torch.empty(Bq, H, W, s, device=a.device, dtype=torch.float32)
-                if chain:
-                    out = torch.empty(Bq, H, W, e1 + e3, device=sq.device, dtype=torch.float32)
-                    csq, ce1 = ops.fire_sq_e1_cfgs(s)
-                    ops.fire_sq_e1(a, 0, base.plan(f'{i}.squeeze@chain', fire.squeeze, csq), base.plan(f'{i}.expand1x1@chain', fire.expand1x1, ce1),
-                                   sq, 0, out, 0)
-                elif unpooled is not None:
+                if unpooled is not None:
                     ops.pool_squeeze(unpooled, 0, cin, base.plan(f'{i}.squeeze@pool', fire.squeeze, ops.POOL_SQUEEZE_CFG), sq, 0)
                     unpooled = None
                 else:
@@ -197,9 +188,7 @@ def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
                 continue
             if out is None:
                 out = torch.empty(Bq, H, W, e1 + e3, device=sq.device, dtype=torch.float32)
-            if chain:
-                base.conv3x3(f'{i}.expand3x3', fire.expand3x3, sq, 0, out, e1, relu=True)
-            elif xcfg is not None:
+            if xcfg is not None:
                 # inference: both expands in ONE Winograd launch (expand1x1 = the four inner transform positions, riding
                 # along as extra channel slices on the same staged squeeze tile)
                 ops.fire_wino(sq, 0, base.fire_wino_plan(i, fire, xcfg), out, 0, e1)

@@ -57,35 +57,6 @@ def run_backbone_backward(base, saved, dpred):
     sync = getattr(base, 'grad_sync', None)
     if sync is not None:
         sync.begin(grad_buf, total, B)
-    # Weight gradients off the critical path: the data-gradient chain (ConvDet dgrad -> per Fire: expand dgrads -> squeeze dgrad ->
-    # pool backward -> ...) is what the next layer waits for; the 31 weight-gradient launches only feed the slab reduction at the
-    # end.  With ``base.wgrad_side_stream`` they run on a second stream (a parallel branch of the captured hipGraph), ordered
-    # behind the gradient tensor they read by an event, and joined before the slabs are reduced.  Tensors read by side-stream
-    # kernels are kept alive until that join (the caching allocator would otherwise hand their memory to a later layer).
-    side = None
-    if getattr(base, 'wgrad_side_stream', False) and dpred.is_cuda:
-        side = getattr(base, '_wgrad_stream', None)
-        if side is None or side.device != dpred.device:
-            side = base._wgrad_stream = torch.cuda.Stream(device=dpred.device)
-    keep = []
-
-    def on_side(fn, *tensors):
-        """Run ``fn`` (weight-gradient launches reading ``tensors``) behind everything enqueued so far -- on the side stream when
-        enabled, else inline."""
-        if side is None:
-            fn()
-            return
-        ev = torch.cuda.Event()
-        ev.record()
-        keep.extend(tensors)
-        with torch.cuda.stream(side):
-            side.wait_event(ev)
-            fn()
-
-    def join_side():
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-
     # Stages of the backward = runs of layers between two pools.  With a gradient exchange attached, each stage's slabs
     # are reduced as soon as the stage is done and its slice of the flat buffer (named_parameters order: a stage is a
     # contiguous range, later stages of the network sit at higher offsets) is handed to the all-reduce; without one, all
@@ -96,10 +67,9 @@ def run_backbone_backward(base, saved, dpred):
         """Everything from ``first_param`` to the previous stage's start is final once the pending slabs are reduced."""
         if sync is None:
             return
-        join_side()                                        # the stage's slabs are complete
         row_hi = wb.row_of[first_param.rsplit('.', 1)[0]] + 1 if first_param is not None else wb.nrows
         if row_hi > stage['row']:
-            wb.reduce(grad_flat, stage['row'], row_hi)
+            wb.reduce(grad_flat, stage['row'], row_hi, scale=sync.scale)     # (weighted by this rank's image count on the way out)
             stage['row'] = row_hi
         lo = slots[first_param][0] if first_param is not None else 0
         sync.ready(lo, stage['hi'])
@@ -111,7 +81,7 @@ def run_backbone_backward(base, saved, dpred):
         for d in shape:
             n *= d
         return grad_flat[off:off + n].view(shape)
-    on_side(lambda: ops.conv_wgrad(dpred, 0, ncd, a_in, 0, cin_cd, 9, slab=wb.slab('convdet')), dpred, a_in)
+    ops.conv_wgrad(dpred, 0, ncd, a_in, 0, cin_cd, 9, slab=wb.slab('convdet'))
     last = len(layers) - 1
     assert layers[last][0] == 'fire'
     out_last = saved[f'fire{last}'][2]
@@ -145,11 +115,9 @@ def run_backbone_backward(base, saved, dpred):
         pre = f'features.{i}.'
         fused_e1 = bool(wb.fused.get(pre + 'expand1x1'))
 
-        def expand_wgrads(dA=dA, sq=sq, e1=e1, e3=e3, s=s, pre=pre, fused_e1=fused_e1):
-            if not fused_e1:
-                ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
-            ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
-        on_side(expand_wgrads, dA, sq)
+        if not fused_e1:
+            ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
+        ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
         dSq = torch.empty_like(sq)
         if fused_e1:
             # narrow expand1x1 (N <= 128: the first four Fires): weight-gradient slabs and the data gradient from ONE pass over the
@@ -165,8 +133,7 @@ def run_backbone_backward(base, saved, dpred):
             # gradient, and again -- for its sign only -- by the data-gradient kernel's ReLU-mask epilogue)
             ops.squeeze_bwd(dSq, x_in, fire.squeeze.weight, wb.slab(pre + 'squeeze'), dIn, relu_mask=prev_is_fire)
         else:
-            on_side(lambda dSq=dSq, x_in=x_in, s=s, cin=cin, pre=pre: ops.conv_wgrad(dSq, 0, s, x_in, 0, cin, 1, slab=wb.slab(pre + 'squeeze')),
-                    dSq, x_in)
+            ops.conv_wgrad(dSq, 0, s, x_in, 0, cin, 1, slab=wb.slab(pre + 'squeeze'))
             ops.conv(dSq, 0, base.plan(f'{i}.squeeze', fire.squeeze, ops.choose_cfg(1, s, cin, npix), 'dgrad'), dIn, 0,
                      ymask=x_in if prev_is_fire else None)
         dA = dIn
@@ -178,8 +145,9 @@ def run_backbone_backward(base, saved, dpred):
         ops.stem_wgrad_pooled(dA, None, am, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
     else:
         ops.stem_wgrad(dA, saved['image'].contiguous(), stem.out_channels, stem.kernel_size[0], out=stem_out)
-    join_side()
-    keep.clear()
+    if sync is not None:
+        lo0 = slots['features.0.weight'][0]
+        sync.scale_slice(lo0, lo0 + stem.weight.numel() + stem.bias.numel())      # the stem's gradient does not pass through the slab reduction
     if sync is None:
         wb.reduce(grad_flat)                               # all 31 Fire / ConvDet slab reductions: one launch
     else:

@@ -196,6 +196,9 @@ def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, restore_rng=
             seed, step = st['sqd_dropout']
             # a file with fewer streams than ranks: every rank continues the saved step on a seed of its own
             base.set_dropout_rng(seed + (rank // len(states)) * 0x9e3779b97f4a7c15 if len(states) != world else seed, step, dev)
+        elif base is not None and getattr(base, 'dropout', None) is not None and st.get('sqd_dropout') is None:
+            warnings.warn('checkpoint carries no dropout stream (written before the counter-based dropout): the dropout in front of '
+                          'ConvDet restarts at step 0 of the stream derived from the restored torch seed (masks of the first run repeat)')
         from .trainer import mark_rank_streams_set
         # all ranks' own streams are back: a later attach_data_parallel / Trainer(...) must not re-seed them.  Fewer streams than
         # ranks: several ranks now share a torch stream, so the next attach has to offset them again

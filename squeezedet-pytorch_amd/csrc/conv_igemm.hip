@@ -46,10 +46,6 @@ struct ConvArgs {
   // epilogue (conv_ws family, sqd_conv_drop_fwd): counter-based dropout of the output, sqd_common.h; drop_state = {seed, step} or null
   const unsigned long long* drop_state; int drop_keep; float drop_scale;
   long long total_px;
-  // CHAIN (sqd_fire_squeeze_expand1x1_fwd): a second 1x1 convolution applied to this launch's own (ReLU'd) output tile before it
-  // leaves the registers -- Fire.squeeze -> squeeze_activation -> Fire.expand1x1 -> expand1x1_activation (src/model/squeezedet.py:17-19)
-  const float* ch_w; const float* ch_bias; float* ch_y;     // expand1x1 weights (packed like any KC = 32 1x1 plan), bias, output buffer
-  int ch_N, ch_Npad, ch_pitch, ch_coff;                     // its channels (a multiple of 32), packed row count, output pitch / channel offset
 };
 
 // LDS tiles are "k-quad major": [KC/4][rows][4 floats].  A lane's MFMA operands for 4 consecutive
@@ -285,20 +281,9 @@ __device__ __forceinline__ f32x4 sqd_relu4(f32x4 v, float lo) {      // lo (wave
 // 1x1 groups simply skip the MFMAs (and operand reads) of the 8 outer taps, and the epilogue writes group 2i to
 // channel window [0, E) and group 2i+1 to [E, 2E) of the output -- the concat.  One launch, one staging of the
 // squeeze tile, and the 1x1 outputs' stores drain under the 3x3's matrix work.
-// CHAIN = true (1x1, one 16-pixel block per wave, the whole output width N = 16 NT in ONE slice): the launch is a Fire's squeeze AND
-// its expand1x1.  A finished squeeze tile sits in the accumulators as lane (pixel lr, channels 16 j + 4 g + 0..3) -- which IS the
-// B operand (k = g, column = pixel) of v_mfma_f32_16x16x4_f32 for input channel 16 j + 4 g + t, the channel order the k-quad-major
-// weight image gives any 1x1 stage of this kernel.  So behind its last K chunk the tile runs ch_N / 32 more stages whose activations
-// come from REGISTERS (ReLU(acc + bias), also stored as the squeeze output for the expand3x3 launch) and whose weight stage is a
-// [N / 4 k-quads][32 expand channels] block of the expand1x1 weights -- exactly the slots, the bytes (128 NT x 16 B) and the MFMA
-// count (8 NT) of one squeeze stage, fetched into the same double buffer by the same DMA pattern.  The squeeze output never comes
-// back from memory and the separate expand1x1 launch (17-34 us each on the 24x78 layers: launch ramp and tail, not arithmetic)
-// disappears.  The next tile's first activation stage is prefetched behind the last squeeze chunk as always and simply waits in its
-// buffer through the chain stages.
-template <int TAPS, int KC, int MT, int NT, int WM, int MINW, bool FUSE, bool WSTAT, bool CHAIN = false>
+template <int TAPS, int KC, int MT, int NT, int WM, int MINW, bool FUSE, bool WSTAT>
 __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)    // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
-  static_assert(!CHAIN || (TAPS == 1 && KC == 32 && MT == 1 && WM == 4 && !FUSE && !WSTAT), "chained 1x1: 64-pixel tiles, KC = 32");
   // WSTAT: the whole K fits one chunk (C <= KC), the weight slice is loaded once and stays in LDS (launch-time property
   // made a template flag so that the tap loop below contains no branch at all)
   static_assert(!FUSE || (TAPS == 9 && (NT % 2) == 0), "fused expand: 3x3 tiles with an even number of channel groups");
@@ -366,18 +351,6 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.x + a.x_coff - ((TAPS == 9) ? (long long)(a.W + 1) * a.x_pitch : 0ll)), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
-  // (CHAIN) a chain stage's weight image: [4 NT k-quads][32 rows][4 floats] = 128 NT slots; slot (kq, r) <- packed expand1x1 weights
-  // at (kq * Npad + 32 * stage + r) * 16 bytes (the KC = 32 packing is contiguous in kq for a 1x1)
-  int w2_offB[CHAIN ? W_IT : 1];
-  if constexpr (CHAIN) {
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      const int slot = it * NTHR + tid;
-      const int kq = slot >> 5, r = slot & 31;
-      w2_offB[it] = (kq < 4 * NT) ? (kq * a.ch_Npad + r) * 16 : 0;
-    }
-  }
-  const __amdgpu_buffer_rsrc_t w2res = __builtin_amdgcn_make_buffer_rsrc((void*)(CHAIN ? a.ch_w : a.w), 0, 0x7ffffff0, 0x00020000);
 
   // All fields are wave-uniform (SGPRs).  p0 = flat index of the tile's first output pixel.
   struct TilePos { int y0, x0, inner; long long p0; unsigned soff; };     // soff: byte offset of the tile origin from the resource base
@@ -429,10 +402,6 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_ptr_t)(wB + (buf * WSLOTS + it * NTHR + wm_s * 64) * 4), 16, w_offB[it],
                                              (int)((unsigned)cc * w_chunkB), 0, 0);
   };
-  auto dma_w2_one = [&](int it, int st, int buf) {          // (CHAIN) expand1x1 weight block of chain stage st
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w2res, (lds_ptr_t)(wB + (buf * WSLOTS + it * NTHR + wm_s * 64) * 4), 16, w2_offB[CHAIN ? it : 0],
-                                             st * (32 * 16), 0, 0);
-  };
 
   f32x4 acc[MT][NT], outv[MT][NT];
 #pragma unroll
@@ -444,10 +413,6 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
   // a tile's output window
   float* const biasL = wB + (w_stationary ? 1 : 2) * WSLOTS * 4;
   if (tid < BN) biasL[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;   // published by the first stage barrier
-  float* const bias2L = biasL + BN;                                                   // (CHAIN) the expand1x1 bias, ch_N floats
-  if constexpr (CHAIN) {
-    for (int i = tid; i < a.ch_N; i += NTHR) bias2L[i] = a.ch_bias ? a.ch_bias[i] : 0.f;
-  }
   int o_off[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -486,7 +451,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           f32x4 v = outv[i][j];
-          if constexpr (!CHAIN) v += *(const f32x4*)(biasL + j * 16 + 4 * g);         // (CHAIN: outv already is ReLU(acc + bias))
+          v += *(const f32x4*)(biasL + j * 16 + 4 * g);
           const int off = o_off[i] + (FUSE ? ((j >> 1) * 16 + ((j & 1) ? a.fuse_e : 0)) : j * 16);
           if (acc_i) v += *(const f32x4*)(ybase + off);
           if (has_mul) v *= *(const f32x4*)(mulbase + off);
@@ -516,7 +481,7 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
         if (!valid || np >= a.N) continue;
         const int n = FUSE ? (((j & 1) ? a.fuse_e : 0) + ((n0 >> 1) + (j >> 1) * 16 + 4 * g)) : np;
         f32x4 v = outv[i][j];
-        if constexpr (!CHAIN) v += *(const f32x4*)(biasL + j * 16 + 4 * g);
+        v += *(const f32x4*)(biasL + j * 16 + 4 * g);
         float* dst = a.y + gp * a.y_pitch + a.y_coff + n;
         if (a.accumulate) v += *(const f32x4*)dst;
         if (a.ymul) v *= *(const f32x4*)(a.ymul + gp * a.ymul_pitch + a.ymul_coff + n);
@@ -530,22 +495,6 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     }
   };
 
-  // (CHAIN) a finished chain stage (32 expand1x1 channels of the tile) waits in outv2 for its store behind the next barrier
-  f32x4 acc2[2], outv2[2];
-  bool pending2 = false;
-  int pst = 0;
-  TilePos ptp2 = cur;
-  const int nchain = CHAIN ? a.ch_N >> 5 : 0;
-  auto flush2 = [&](const TilePos tp, int st) {
-    const long long gp = tp.p0 + wm * 16 + lr;
-    if (gp >= a.total_px) return;
-    float* const dst = a.ch_y + gp * a.ch_pitch + a.ch_coff + st * 32 + 4 * g;
-#pragma unroll
-    for (int j2 = 0; j2 < 2; ++j2) {
-      const f32x4 v = outv2[j2] + *(const f32x4*)(bias2L + st * 32 + j2 * 16 + 4 * g);
-      *(f32x4*)(dst + j2 * 16) = sqd_relu4(v, 0.f);
-    }
-  };
 
   for (;;) {
     const int more_i = (int)((unsigned)(tile + tstride - ntiles) >> 31);     // tile + tstride < ntiles
@@ -556,9 +505,6 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
                                                         // only tracks the issuing wave's own reads of DMA-written LDS)
       __syncthreads();                 // ... and is published; all waves left the previous stage
       if (pending) { flush(ptp); pending = false; }
-      if constexpr (CHAIN) {
-        if (pending2) { flush2(ptp2, pst); pending2 = false; }
-      }
       const int last_i = 1 - (int)((unsigned)(cc + 1 - nchunks) >> 31);      // cc == nchunks - 1
       const bool last = last_i != 0;
       const int ncc = last ? 0 : cc + 1;
@@ -611,12 +557,6 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
         for (int q = 0; q < A_IT + W_IT; ++q) {
           if (q * STEPS / (A_IT + W_IT) != step) continue;
           if (q < A_IT) dma_act_one(q < A_IT ? q : 0, nsoff, sbuf ^ 1);
-          else if (CHAIN) {
-            // behind the last chunk the next WEIGHT stage is chain stage 0 (selects, not a branch: the tap loop stays one block)
-            const int qi = q - A_IT;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(last ? w2res : wres, (lds_ptr_t)(wB + ((wbuf ^ 1) * WSLOTS + qi * NTHR + wm_s * 64) * 4), 16,
-                                                     last ? w2_offB[CHAIN ? qi : 0] : w_offB[qi], last ? 0 : (int)((unsigned)ncc * w_chunkB), 0, 0);
-          }
           else if (!WSTAT) dma_w_one(q - A_IT, ncc, wbuf ^ 1);
         }
         // The next step's reads go out in the MIDDLE of this step's MFMAs: when the next step starts (and the compiler's
@@ -647,48 +587,11 @@ __global__ __launch_bounds__(WM * 64, MINW) void conv_dma_kernel(ConvArgs a) {
       sbuf ^= 1;
       if (!w_stationary) wbuf ^= 1;
     }
-    if constexpr (CHAIN) {
-      for (int st = 0; st < nchain; ++st) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (pending) {
-          // the tile's squeeze output: bias + ReLU once, in place -- stored for the expand3x3 launch AND kept as this wave's B operands
-#pragma unroll
-          for (int j = 0; j < NT; ++j) outv[0][j] = sqd_relu4(outv[0][j] + *(const f32x4*)(biasL + j * 16 + 4 * g), 0.f);
-          flush(ptp); pending = false;
-        }
-        if (pending2) { flush2(ptp2, pst); pending2 = false; }
-        // next weight stage: chain stage st + 1, or (behind the last one) chunk 0 of the squeeze for the next tile -- whose first
-        // activation stage has been waiting in its buffer since the last squeeze chunk
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-          if (st + 1 < nchain) dma_w2_one(it, st + 1, wbuf ^ 1);
-          else dma_w_one(it, 0, wbuf ^ 1);
-        }
-        const float* const w2L = wB + wbuf * WSLOTS * 4 + (g * 32 + lr) * 4;
-        acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sk = 0; sk < NT; ++sk) {
-          const f32x4 a0 = *(const f32x4*)(w2L + (4 * sk * 32) * 4), a1 = *(const f32x4*)(w2L + (4 * sk * 32 + 16) * 4);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            acc2[0] = mfma16(a0[t], outv[0][sk][t], acc2[0]);
-            acc2[1] = mfma16(a1[t], outv[0][sk][t], acc2[1]);
-          }
-        }
-        outv2[0] = acc2[0]; outv2[1] = acc2[1];
-        pending2 = true; pst = st; ptp2 = cur;
-        wbuf ^= 1;
-      }
-    }
     if (!more) break;
     tile += tstride;
     cur = nxt;
   }
   if (pending) flush(ptp);
-  if constexpr (CHAIN) {
-    if (pending2) flush2(ptp2, pst);
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may still be in flight when the LDS is released
 #endif
 }
@@ -916,11 +819,8 @@ static int launch_conv_ws(ConvArgs a, hipStream_t stream) {
   const int nslices = sqd_cdiv(a.N, BN);
   if (nslices * BN > a.Npad) return SQD_ERR_BAD_ARG;
   auto go = [&](auto kern) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return (int)SQD_ERR_LAUNCH;
-      attr_set = true;
-    }
+    static SqdDevOnce attr_once;                 // (per device: ADVICE round 4)
+    if (int rc_attr = sqd_max_lds_once(attr_once, (const void*)kern, 160 * 1024)) return (int)rc_attr;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
     int wgs_per_cu = nb > 4 ? 4 : nb;
@@ -1030,72 +930,6 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   a.nslices = nslices; a.gx = gx;
   hipLaunchKernelGGL(kern, dim3((unsigned)(gx * nslices)), dim3(NTHR), lds, stream, a);
   return sqd_launch_status();
-}
-
-// Fire squeeze + expand1x1 in one launch (conv_dma_kernel<1, 32, 1, NT, 4, ., false, false, CHAIN = true>, NT = squeeze width / 16)
-template <int NT>
-static int launch_conv_chain(ConvArgs a, hipStream_t stream) {
-  constexpr int BN = 16 * NT, NTHR = 256, KV = 8, NPIXP = 64;
-  constexpr int ASLOTS = (KV * NPIXP + NTHR - 1) / NTHR * NTHR, WSLOTS = (KV * BN + NTHR - 1) / NTHR * NTHR;
-  if (a.total_px * a.x_pitch * 4 >= (3ll << 30) || a.total_px * a.y_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)(2 * ASLOTS + 2 * WSLOTS) * 16 + (size_t)(BN + a.ch_N) * sizeof(float);
-  constexpr int MINW = (NT <= 2) ? 3 : 2;                 // waves per SIMD the register allocator leaves room for
-  auto kern = conv_dma_kernel<1, 32, 1, NT, 4, MINW, false, false, true>;
-  static int wgs_per_cu = 0;
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
-    lds_set = lds; wgs_per_cu = 0;
-  }
-  if (wgs_per_cu == 0) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
-    wgs_per_cu = nb > 6 ? 6 : nb;
-  }
-  a.tiles_x = a.tiles_y = 0;
-  a.ntiles = (int)((a.total_px + 63) / 64);
-  const int slots = sqd_num_cus() * ((a.wg_cap > 0 && a.wg_cap < wgs_per_cu) ? a.wg_cap : wgs_per_cu);
-  const int per_wg = sqd_cdiv(a.ntiles, slots < 1 ? 1 : slots);
-  const int gx = (sqd_cdiv(a.ntiles, per_wg) + 7) & ~7;
-  a.nslices = 1; a.gx = gx;
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NTHR), lds, stream, a);
-  return sqd_launch_status();
-}
-
-// Fire.squeeze + ReLU + Fire.expand1x1 + ReLU (src/model/squeezedet.py:17-19) in ONE launch: y_sq[..., sq_coff : +Nsq] = the squeeze
-// output (the expand3x3 launch reads it), y_out[..., out_coff : +E1] = the expand1x1 half of the Fire's concat.  Both weight sets
-// in the packing of a KC = 32 1x1 plan ([ceil(C/32)][8][Npad][4]).  Nsq in {16, 32, 48, 64, 96}, E1 a multiple of 32, C > 32.
-extern "C" int sqd_fire_squeeze_expand1x1_fwd(const float* x, const float* wsq_packed, const float* bsq, float* y_sq,
-                                              const float* we1_packed, const float* be1, float* y_out, int B, int H, int W, int C,
-                                              int x_pitch, int x_coff, int Nsq, int Nsq_pad, int sq_pitch, int sq_coff, int E1,
-                                              int E1_pad, int out_pitch, int out_coff, int wg_cap, void* stream) {
-  SQD_CHECK_ARG(x && wsq_packed && y_sq && we1_packed && y_out && B > 0 && H > 0 && W > 0 && C > 0 && wg_cap >= 0 && wg_cap <= 8);
-  SQD_CHECK_ARG((C & 3) == 0 && (x_pitch & 3) == 0 && (x_coff & 3) == 0 && (sq_pitch & 3) == 0 && (sq_coff & 3) == 0 &&
-                (out_pitch & 3) == 0 && (out_coff & 3) == 0);
-  SQD_CHECK_ARG(x_coff + C <= x_pitch && sq_coff + Nsq <= sq_pitch && out_coff + E1 <= out_pitch && Nsq <= Nsq_pad && E1 <= E1_pad);
-  SQD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y_sq & 15) == 0 && ((uintptr_t)y_out & 15) == 0 &&
-                ((uintptr_t)wsq_packed & 15) == 0 && ((uintptr_t)we1_packed & 15) == 0);
-  if (C <= 32 || (E1 & 31) || E1 > 1024) return SQD_ERR_UNSUPPORTED;
-  ConvArgs a = {};
-  a.ymask = nullptr; a.ymul = nullptr; a.ymask_pitch = a.ymask_coff = a.ymul_pitch = a.ymul_coff = 0;
-  a.x = x; a.w = wsq_packed; a.bias = bsq; a.y = y_sq; a.xmask = nullptr;
-  a.B = B; a.H = H; a.W = W; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
-  a.N = Nsq; a.Npad = Nsq_pad; a.y_pitch = sq_pitch; a.y_coff = sq_coff;
-  a.relu = 1; a.accumulate = 0; a.tiles_x = a.tiles_y = 0; a.ntiles = 0; a.nslices = 1; a.gx = 8; a.wg_cap = wg_cap; a.fuse_e = 0;
-  a.xmask_pitch = a.xmask_coff = 0;
-  a.total_px = (long long)B * H * W;
-  a.ch_w = we1_packed; a.ch_bias = be1; a.ch_y = y_out; a.ch_N = E1; a.ch_Npad = E1_pad; a.ch_pitch = out_pitch; a.ch_coff = out_coff;
-  if (a.total_px * out_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  switch (Nsq) {
-    case 16: return launch_conv_chain<1>(a, s);
-    case 32: return launch_conv_chain<2>(a, s);
-    case 48: return launch_conv_chain<3>(a, s);
-    case 64: return launch_conv_chain<4>(a, s);
-    case 96: return launch_conv_chain<6>(a, s);
-    default: return SQD_ERR_UNSUPPORTED;
-  }
 }
 
 // Tile configurations (cfg_id) -> template instance.  The host picks per layer; any config is

@@ -32,31 +32,6 @@
 #define SQD_WINO_DIAG 0           /* ablation builds only (scratch/diag/build_wino_diag.sh): bit 0 = no MFMA, 1 = no input transform,
                                      2 = no DMA inside the chunk loop, 3 = no output stores.  0 in the product library. */
 #endif
-#ifndef SQD_WINO_DMA_STEPS
-#define SQD_WINO_DMA_STEPS 8      /* the next stage's DMA instructions are spread over the first this-many of the 8 MFMA steps.
-                                     4 (+ SQD_WINO_U_FIRST) measured 7-12 % faster with each layer timed in a loop of its own
-                                     (profiles/r02c_wino_dma_timing.log) but 1 % SLOWER inside the network (A/B of the whole
-                                     step in one process, profiles/r02f_ab_uf4.log): 8 / 0 stay the defaults */
-#endif
-#ifndef SQD_WINO_U_FIRST
-#define SQD_WINO_U_FIRST 0        /* 1: the next stage's U slice is requested right behind the stage barrier (its buffer is free from
-                                     there on), ahead of the input transform; only the patch refill waits for the transform's reads */
-#endif
-#ifndef SQD_WINO_PIXMAJOR
-#define SQD_WINO_PIXMAJOR 0       /* the raw patch image of a wave: 0 = [k-quad][pixel][4 floats]; 1 = [pixel][k-quad][4 floats], i.e. adjacent
-                                     lanes of a DMA instruction fetch the two adjacent 16-byte pieces of one pixel (a 32-byte run of one
-                                     cache line per lane pair instead of every lane on a line of its own).  Round 3 A/B of the whole step
-                                     (gpurun_out/r03z/bench_pix*.json): 1 is 5 % SLOWER on conv_wino<2,4> (0.545 vs 0.520 ms) and the
-                                     U-stationary <2,4>, 1 % faster on <1,4> / <2,8> -- the patch fetch is not bound by lines touched */
-#endif
-#if SQD_WINO_PIXMAJOR
-#define SQD_WINO_PXS 8            /* floats per pixel of the raw image */
-#else
-#define SQD_WINO_PXS 4
-#endif
-#ifndef SQD_WINO_DMA_EARLY
-#define SQD_WINO_DMA_EARLY 0      /* 1: issue the whole next stage at the first MFMA step -- measured 5-8 % slower than spreading it */
-#endif
 
 struct WinoArgs {
   const float* x; const float* u; const float* bias; float* y;
@@ -159,11 +134,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
 #pragma unroll
   for (int it = 0; it < RAW_IT; ++it) {
     const int slot = it * 64 + lane;
-#if SQD_WINO_PIXMAJOR
-    const int kq = slot & 1, pix = slot >> 1;
-#else
     const int kq = slot / RP, pix = slot - kq * RP;
-#endif
     const bool real = kq < 2 && pix < 108;
     const int r = pix / 18, c = pix - r * 18;
     r_key[it] = real ? (r << 8 | c) : -1;
@@ -251,11 +222,7 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
   // are consumed by the lane that computed them and never leave its registers (the patch reads are 2-way bank
   // conflicted in this order: 16 ds_read_b64 per chunk, cheap next to a V round trip through LDS)
   const int tt = lr, cp = g;
-#if SQD_WINO_PIXMAJOR
-  const float* const rawL = rawW + (((2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 8 + 2 * cp);
-#else
   const float* const rawL = rawW + (((cp >> 1) * RP + (2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 4 + 2 * (cp & 1));
-#endif
   // U image per 16 channels: [8 position pairs][4 channel pairs][16 n][pos parity][2 channels] (k-quad-major: conflict-free)
   const float* const uR0 = UB + g * 64 + lr * 4;
   // the former V image now parks a finished tile's outputs until the next barrier: [4 px][NT][64 lanes] f32x4
@@ -330,10 +297,6 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
       // whose per-lane offsets replace this group's now (its own last stage is already in LDS)
       if (last) group_offsets(nxt);
       const unsigned nsoff = (last ? nxt.soff : cur.soff) + (unsigned)ncc * 32u;
-#if SQD_WINO_U_FIRST
-#pragma unroll
-      for (int it = 0; it < U_IT; ++it) dma_u_one(it, ncc, ubuf ^ 1);
-#endif
 
       // ---- input transform: V = B^T d B for (tile tt, channels 2cp, 2cp+1) ----
       f32x2 vv[16];                          // V[pos] for (tile lr, channels 2g, 2g+1): this lane's B operands of the chunk
@@ -345,8 +308,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
         f32x2 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * SQD_WINO_PXS), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * SQD_WINO_PXS);
-          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * SQD_WINO_PXS), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * SQD_WINO_PXS);
+          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * 4), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * 4);
+          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * 4), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * 4);
           t[0][j] = d0 - d2; t[1][j] = d1 + d2; t[2][j] = d2 - d1; t[3][j] = d1 - d3;
         }
 #pragma unroll
@@ -393,8 +356,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 4 && NT == 2) ? 2 : ((WV == 4 && NT
 #pragma unroll
       for (int step = 0; step < NSTEP; ++step) {
 #pragma unroll
-        for (int q = 0; q < (SQD_WINO_U_FIRST ? RAW_IT : NDMA); ++q) {
-          if (((SQD_WINO_DMA_EARLY) ? 0 : q * (SQD_WINO_DMA_STEPS) / (SQD_WINO_U_FIRST ? RAW_IT : NDMA)) != step) continue;
+        for (int q = 0; q < NDMA; ++q) {
+          if (q * NSTEP / NDMA != step) continue;      // the next stage's DMA instructions are spread over the 8 MFMA steps
           if (SQD_WINO_DIAG & 4) continue;
           if (q < RAW_IT) dma_raw_one(q < RAW_IT ? q : 0, nsoff);
           else dma_u_one(q - RAW_IT, ncc, ubuf ^ 1);
@@ -539,11 +502,7 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
 #pragma unroll
   for (int it = 0; it < RAW_IT; ++it) {
     const int slot = it * 64 + lane;
-#if SQD_WINO_PIXMAJOR
-    const int kq = slot & 1, pix = slot >> 1;
-#else
     const int kq = slot / RP, pix = slot - kq * RP;
-#endif
     const bool real = kq < 2 && pix < 108;
     const int r = pix / 18, c = pix - r * 18;
     r_key[it] = real ? (r << 8 | c) : -1;
@@ -647,11 +606,7 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
   };
   const float relu_lo = a.relu ? 0.f : -__builtin_inff();
   const int tt = lr, cp = g;
-#if SQD_WINO_PIXMAJOR
-  const int rawL_off = (((2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 8 + 2 * cp);
-#else
   const int rawL_off = (((cp >> 1) * RP + (2 * (tt >> 3)) * 18 + 2 * (tt & 7)) * 4 + 2 * (cp & 1));
-#endif
   const float* const uR0 = UB + g * 64 + lr * 4;
   const int acc_i = a.accumulate, has_mul = a.ymul != nullptr, has_mask = a.ymask != nullptr;
   const bool plain_epi = !acc_i && !has_mul && !has_mask;
@@ -726,8 +681,8 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
       if constexpr (E1) {
         // only the four inner positions are needed: rows 1, 2 x columns 1, 2 of the tile's 4x4 patch
         const float* const rawL = rawW + rb * WV * 256 * 4 + rawL_off;
-        const f32x2 d11 = *(const f32x2*)(rawL + (1 * 18 + 1) * SQD_WINO_PXS), d12 = *(const f32x2*)(rawL + (1 * 18 + 2) * SQD_WINO_PXS);
-        const f32x2 d21 = *(const f32x2*)(rawL + (2 * 18 + 1) * SQD_WINO_PXS), d22 = *(const f32x2*)(rawL + (2 * 18 + 2) * SQD_WINO_PXS);
+        const f32x2 d11 = *(const f32x2*)(rawL + (1 * 18 + 1) * 4), d12 = *(const f32x2*)(rawL + (1 * 18 + 2) * 4);
+        const f32x2 d21 = *(const f32x2*)(rawL + (2 * 18 + 1) * 4), d22 = *(const f32x2*)(rawL + (2 * 18 + 2) * 4);
         const f32x2 t11 = d11 + d21, t12 = d12 + d22, t21 = d21 - d11, t22 = d22 - d12;      // column transform rows 1, 2
         vv[5] = t11 + t12; vv[6] = t12 - t11; vv[9] = t21 + t22; vv[10] = t22 - t21;
       } else {
@@ -735,8 +690,8 @@ __device__ __forceinline__ void wino_pipe_body(const WinoArgs& a) {
         f32x2 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * SQD_WINO_PXS), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * SQD_WINO_PXS);
-          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * SQD_WINO_PXS), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * SQD_WINO_PXS);
+          const f32x2 d0 = *(const f32x2*)(rawL + (0 * 18 + j) * 4), d1 = *(const f32x2*)(rawL + (1 * 18 + j) * 4);
+          const f32x2 d2 = *(const f32x2*)(rawL + (2 * 18 + j) * 4), d3 = *(const f32x2*)(rawL + (3 * 18 + j) * 4);
           t[0][j] = d0 - d2; t[1][j] = d1 + d2; t[2][j] = d2 - d1; t[3][j] = d1 - d3;
         }
 #pragma unroll
@@ -902,11 +857,8 @@ static int launch_wino_pipe(WinoArgs a, hipStream_t stream) {
   auto kern = conv_wino_pipe_kernel<NT, WV, USTAT, FIRE>;
   // 32-bit SGPR byte offset of a tile's output origin / per-lane byte offsets inside a group (buffer-resource stores)
   if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static SqdDevOnce attr_once;                 // (per device: ADVICE round 4)
+  if (int rc_attr = sqd_max_lds_once(attr_once, (const void*)kern, 160 * 1024)) return rc_attr;
   int nb = 0;              // occupancy depends on the (C-dependent) LDS size of the stationary variant: ask per launch
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
   const int wgs_per_cu = nb > 4 ? 4 : nb;
@@ -1142,10 +1094,7 @@ extern "C" int sqd_conv_wino_fwd(const float* x, const float* u_packed, const fl
     case 1: return launch_wino<1, 8>(a, s);
     case 2: return launch_wino<2, 4>(a, s);
     case 3: return launch_wino<1, 4>(a, s);
-    case 4: return launch_wino_pipe<2, 8>(a, s);
-    case 5: return launch_wino_pipe<1, 8>(a, s);
-    case 6: return launch_wino_pipe<2, 4>(a, s);
-    case 7: return launch_wino_pipe<1, 4>(a, s);
+    // (ids 4..7, the deep-prefetch streamed-U forms, are retired: no measured row ever selected them -- profiles/r02d, r02f)
     case 8: return launch_wino_pipe<2, 8, true>(a, s);
     case 9: return launch_wino_pipe<1, 8, true>(a, s);
     case 10: return launch_wino_pipe<2, 4, true>(a, s);
@@ -1178,8 +1127,6 @@ extern "C" int sqd_fire_wino_fwd(const float* x, const float* u_packed, const fl
   a.N1 = N1; a.y_coff1 = y_coff1; a.nslices3 = sqd_cdiv(N3, 32);
   hipStream_t s = (hipStream_t)stream;
   switch (cfg_id) {
-    case 4: return launch_wino_pipe<2, 8, false, true>(a, s);
-    case 6: return launch_wino_pipe<2, 4, false, true>(a, s);
     case 8: return launch_wino_pipe<2, 8, true, true>(a, s);
     case 10: return launch_wino_pipe<2, 4, true, true>(a, s);
     case 12: return launch_wino_bridge16<1, false>(a, s);      // C <= 16: transformed input in registers, 16-wide passes (wino_bridge.h)
@@ -1219,7 +1166,6 @@ extern "C" int sqd_fire_bridge_fwd(const float* x, const float* u_packed, const 
   hipStream_t s = (hipStream_t)stream;
   const bool one = Nsq <= 16;
   switch (cfg_id) {
-    case 6: return one ? launch_wino_bridge<4, false, 1>(a, s) : launch_wino_bridge<4, false, 2>(a, s);
     case 10: return one ? launch_wino_bridge<4, true, 1>(a, s) : launch_wino_bridge<4, true, 2>(a, s);
     case 12: return one ? launch_wino_bridge16<1>(a, s) : launch_wino_bridge16<2>(a, s);
   }

@@ -607,13 +607,9 @@ extern "C" int sqd_conv_wino_sk_fwd(const float* x, const float* u_packed, const
   a.gxn_m = a.gxn > 1 ? (unsigned)(((1ull << 32) + a.gxn - 1) / a.gxn) : 0u; a.gyn_m = a.gyn > 1 ? (unsigned)(((1ull << 32) + a.gyn - 1) / a.gyn) : 0u;
   a.seg_off = seg_off; a.segs = (const SkSeg*)segs; a.ws = ws; a.cnt = cnt;
   constexpr size_t lds = (size_t)80 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_wino_sk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv_wino_sk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static SqdDevOnce once_plain, once_full;          // the attribute belongs to the device that is current at the call: once per device
+  if (int rc_attr = sqd_max_lds_once(once_plain, (const void*)conv_wino_sk_kernel<false>, (int)lds)) return rc_attr;
+  if (int rc_attr = sqd_max_lds_once(once_full, (const void*)conv_wino_sk_kernel<true>, (int)lds)) return rc_attr;
   const bool full = accumulate || ymask || ymul || yscale != 1.0f || drop_state;
   if (full) hipLaunchKernelGGL(conv_wino_sk_kernel<true>, dim3((unsigned)G), dim3(256), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(conv_wino_sk_kernel<false>, dim3((unsigned)G), dim3(256), lds, (hipStream_t)stream, a);

@@ -166,3 +166,27 @@ extern "C" int sqd_sgd_clip_step_parts(const void* descs_dev, int n, const float
                      (const SgdDesc*)descs_dev, grad_base, sumsq_parts, max_norm, lr, momentum, weight_decay, SQD_NORM_PARTS, norm_out);
   return sqd_launch_status();
 }
+
+// ---- the element-wise steps of the data-parallel gradient exchange (trainer.GradientExchange) without a torch kernel ----
+// The reference's DataParallel (src/utils/data_parallel.py:93-113) gathers the per-sample losses and differentiates their mean
+// (src/engine/trainer.py:43,47); one process per GPU gets the same gradient as sum_r(B_r * g_r) / sum_r(B_r).  g[0..n) = g * mul /
+// (*div_by if given); fill_ptr (or NULL) receives fill_value: the rank's image count that rides through the same all-reduce.
+__global__ __launch_bounds__(256) void grad_scale_kernel(float* __restrict__ g, long long n, float mul, const float* __restrict__ div_by,
+                                                         float* __restrict__ fill_ptr, float fill_value) {
+  if (fill_ptr && blockIdx.x == 0 && threadIdx.x == 0) *fill_ptr = fill_value;
+  const float d = div_by ? *div_by : 1.f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = g[i] * mul;
+    g[i] = div_by ? v / d : v;                 // a true division: the same rounding as torch's div_ by the summed count
+  }
+}
+
+extern "C" int sqd_grad_scale(float* g, long long n, float mul, const float* div_by, float* fill_ptr, float fill_value, void* stream) {
+  SQD_CHECK_ARG(n >= 0 && (g || n == 0) && (n > 0 || fill_ptr));
+  SQD_CHECK_ARG(!fill_ptr || !g || fill_ptr < g || fill_ptr >= g + n);          // the slot is not part of the scaled range
+  long long blocks = (n + 1023) / 1024;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, mul, div_by, fill_ptr, fill_value);
+  return sqd_launch_status();
+}

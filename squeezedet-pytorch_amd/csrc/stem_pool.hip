@@ -870,13 +870,8 @@ static int launch_stem_wave(StemWaveArgs a, hipStream_t s) {
   a.tiles_x_m = a.tiles_x > 1 ? (unsigned)(((1ull << 32) + a.tiles_x - 1) / a.tiles_x) : 0u;
   a.tiles_y_m = a.tiles_y > 1 ? (unsigned)(((1ull << 32) + a.tiles_y - 1) / a.tiles_y) : 0u;
   auto kern = stem_wave_kernel<PH, CB, ARGMAX, SQ>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static SqdDevOnce attr_once;                 // (per device: ADVICE round 4)
+  if (int rc_attr = lds <= 64 * 1024 ? SQD_OK : sqd_max_lds_once(attr_once, (const void*)kern, (int)lds)) return rc_attr;
   int dev = 0, cus = 256; hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     cus = prop.multiProcessorCount;

@@ -557,7 +557,7 @@ struct WgrDesc { long long slab_off, dw_off, db_off, S, slab_stride, N, C, TAPS,
 
 __global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_batched_kernel(const WgrDesc* __restrict__ descs, int n,
                                                                                    const float* __restrict__ slab_base,
-                                                                                   float* __restrict__ grad_base, int block_first) {
+                                                                                   float* __restrict__ grad_base, int block_first, float scale) {
   __shared__ float red[WGR_PARTS][WGR_OUT];
   const long long wg = (long long)blockIdx.x + block_first;      // workgroup id in the numbering of the whole table
   int row = 0;
@@ -580,6 +580,7 @@ __global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_batched_kern
   float t = red[0][o];
 #pragma unroll
   for (int p = 1; p < WGR_PARTS; ++p) t += red[p][o];
+  t *= scale;                                  // (1 = bitwise the plain sum; the data-parallel exchange passes this rank's image count)
   if (idx < nw) {
     const int c = (int)(idx % C); const long long q = idx / C;
     const int tap = (int)(q % TAPS); const int nn = (int)(q / TAPS);
@@ -590,10 +591,10 @@ __global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_batched_kern
 }
 
 extern "C" int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base,
-                                        void* stream) {
+                                        float scale, void* stream) {
   SQD_CHECK_ARG(descs_dev && n > 0 && n <= 4096 && total_blocks > 0 && slab_base && grad_base);
   hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(WGR_OUT * WGR_PARTS), 0, (hipStream_t)stream,
-                     (const WgrDesc*)descs_dev, n, slab_base, grad_base, 0);
+                     (const WgrDesc*)descs_dev, n, slab_base, grad_base, 0, scale);
   return sqd_launch_status();
 }
 
@@ -601,10 +602,10 @@ extern "C" int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_
 // slabs are written, so that stage's gradient bucket can enter the all-reduce while earlier layers are still being
 // differentiated): descs_dev points at the first record of the range, block_first = that record's first workgroup.
 extern "C" int sqd_wgrad_reduce_batched_range(const void* descs_dev, int n, int block_first, int nblocks, const float* slab_base,
-                                              float* grad_base, void* stream) {
+                                              float* grad_base, float scale, void* stream) {
   SQD_CHECK_ARG(descs_dev && n > 0 && n <= 4096 && block_first >= 0 && nblocks > 0 && slab_base && grad_base);
   hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)nblocks), dim3(WGR_OUT * WGR_PARTS), 0, (hipStream_t)stream,
-                     (const WgrDesc*)descs_dev, n, slab_base, grad_base, block_first);
+                     (const WgrDesc*)descs_dev, n, slab_base, grad_base, block_first, scale);
   return sqd_launch_status();
 }
 

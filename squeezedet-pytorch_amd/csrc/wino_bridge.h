@@ -389,11 +389,8 @@ static int launch_wino_bridge(WinoArgs a, hipStream_t stream) {
   if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
   auto kern = fire_bridge_kernel<WV, USTAT, NSQ>;
   if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static SqdDevOnce attr_once;                 // (per device: ADVICE round 4)
+  if (int rc_attr = sqd_max_lds_once(attr_once, (const void*)kern, 160 * 1024)) return rc_attr;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
   const int wgs_per_cu = nb > 4 ? 4 : nb;
@@ -783,11 +780,8 @@ static int launch_wino_bridge16_t(WinoArgs a, hipStream_t stream) {
   auto kern = fire_bridge16_kernel<NSQ, MODE, NCH>;
   if ((long long)a.B * a.H * a.W * a.y_pitch * 4 >= (1ll << 32) - (1ll << 30)) return SQD_ERR_UNSUPPORTED;
   if (MODE == 2 && (!a.sv || (long long)a.B * a.H * a.W * a.sv_pitch * 4 >= (1ll << 32) - (1ll << 30))) return SQD_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static SqdDevOnce attr_once;                 // (per device: ADVICE round 4)
+  if (int rc_attr = sqd_max_lds_once(attr_once, (const void*)kern, 160 * 1024)) return rc_attr;
   a.gxn = sqd_cdiv(a.W, 16); a.gyn = sqd_cdiv(a.H, 4);
   a.ngroups = a.B * a.gxn * a.gyn;
   if ((long long)(a.ngroups + 8) * (a.gxn > a.gyn ? a.gxn : a.gyn) >= (1ll << 32)) return SQD_ERR_UNSUPPORTED;

@@ -447,11 +447,8 @@ static int launch_wino_poolbridge16_t(WinoArgs a, int nseg, hipStream_t stream) 
   if (lds > 160 * 1024) return SQD_ERR_UNSUPPORTED;
   if (SAVE && (!a.sv || !a.sv_codes)) return SQD_ERR_BAD_ARG;
   auto kern = fire_poolbridge16_kernel<NSQ, NCH, SAVE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SQD_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static SqdDevOnce attr_once;                 // (per device: ADVICE round 4)
+  if (int rc_attr = sqd_max_lds_once(attr_once, (const void*)kern, 160 * 1024)) return rc_attr;
   a.pb_ng = sqd_cdiv(a.H, 4);
   a.pb_ns = sqd_cdiv(a.pb_wp, 7);
   if (nseg < 1) nseg = 1;

@@ -381,8 +381,9 @@ extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab,
   const long long px = (long long)B * H * W;
   if (px * dy_pitch * 4 >= (3ll << 30) || px * x_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;   // 32-bit SGPR byte offsets
   hipStream_t s = (hipStream_t)stream;
-  // N <= 80 (ConvDet: 72): one 5-block output-channel group (x 16 or 32 input channels); else 64-channel groups
-  const int rc = (N % 64) ? ((tc <= 1 || C <= 16) ? launch_wino_wgrad<5, 1>(a, s) : launch_wino_wgrad<5, 2>(a, s))
+  // N <= 80 (ConvDet: 72): one 5-block output-channel group x 16 input channels (tc is ignored: the 32-channel form spilled and made the
+  // slab reduction slower by more than it gained, profiles/r04*); else 64-channel groups x 16 or 32 input channels
+  const int rc = (N % 64) ? launch_wino_wgrad<5, 1>(a, s)
                           : ((tc <= 1 || C <= 16) ? launch_wino_wgrad<4, 1>(a, s) : launch_wino_wgrad<4, 2>(a, s));
   if (rc != SQD_OK || !dw) return rc;
   return sqd_wgrad_reduce_launch(slab, dw, db, S, a.slab_stride, N, C, 9, stream);

@@ -158,13 +158,7 @@ class SqueezeDetBase(nn.Module):
         # no mask tensor and no torch RNG kernel in the step.  fused_dropout = False draws the mask as a tensor (stand-alone kernel)
         self.fused_dropout = True
         self._drop = None                   # (torch.initial_seed() it was derived from, ops.DropState)
-        # forward (inference and training): squeeze + expand1x1 of a Fire in one launch (ops.fire_sq_e1) wherever they would be two plain
-        # launches.  OFF: measured slower in the step (inference 1.553 -> 1.607 ms, training 5.49 -> 5.57 ms; per Fire 100 vs 88 us at
-        # C512/768 -> 96 -> 384, 56 vs 52 at -> 64 -> 256, 37 vs 39 at -> 48 -> 192): a chain stage is 8 NT MFMAs per wave between two
-        # barriers, too short to hide its own weight fetch, and the chained form forces the one-slice squeeze tiling
-        self.fuse_sq_e1 = os.environ.get('SQD_FUSE_SQ_E1', '0')[:1] == '1'
-        self.wgrad_side_stream = os.environ.get('SQD_WGRAD_SIDE_STREAM', '0')[:1] == '1'     # backward: weight gradients on a second stream
-        self._wgrad_stream = None
+        self._drop_restored = False         # the stream came from set_dropout_rng (a checkpoint), not from torch's seed
         self.fuse_squeeze_bwd = os.environ.get('SQD_FUSE_SQUEEZE_BWD', '1')[:1] != '0'     # backward: squeeze wgrad + dgrad in one launch
         self.init_weights()
 
@@ -296,8 +290,13 @@ class SqueezeDetBase(nn.Module):
         and the per-rank seed offsets of ``trainer.attach_data_parallel`` give every rank its own masks; re-seeding with the same
         value is not observable here and continues the stream: ``set_dropout_rng(seed, 0, device)`` restarts it explicitly)."""
         seed = torch.initial_seed()
-        if self._drop is None or self._drop[0] != seed or self._drop[1].state.device != torch.device(device) or self._drop[1].p != self.dropout_prob:
+        stale = self._drop is not None and (self._drop[1].state.device != torch.device(device) or self._drop[1].p != self.dropout_prob)
+        # a RESTORED stream (set_dropout_rng: checkpoint resume) is not tied to torch's seed any more: the per-rank re-seeding of a later
+        # attach_data_parallel, or a torch.manual_seed of the training script, must not silently restart it at step 0
+        reseeded = self._drop is not None and not self._drop_restored and self._drop[0] != seed
+        if self._drop is None or stale or reseeded:
             self._drop = (seed, ops.DropState(self.dropout_prob, seed ^ 0x5851f42d4c957f2d, device))
+            self._drop_restored = False
         return self._drop[1]
 
     def get_dropout_rng(self):
@@ -305,10 +304,12 @@ class SqueezeDetBase(nn.Module):
         return None if self._drop is None else self._drop[1].get()
 
     def set_dropout_rng(self, seed, step, device):
-        """Restore a saved dropout stream (checkpoint resume); it stays in force until the process is re-seeded."""
+        """Restore a saved dropout stream (checkpoint resume); it stays in force -- also across a later ``torch.manual_seed`` / the
+        per-rank seed offsets of ``attach_data_parallel`` -- until ``set_dropout_rng`` is called again."""
         d = ops.DropState(self.dropout_prob, 0, device)
         d.set(seed, step)
         self._drop = (torch.initial_seed(), d)
+        self._drop_restored = True          # (drop_state() keeps it whatever happens to torch's seed; set_dropout_rng again replaces it)
 
     def invalidate_plans(self):
         """Drop every packed / transformed weight copy.  The caches notice optimizer steps, ``load_state_dict``, ``.to()``

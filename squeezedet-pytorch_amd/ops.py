@@ -167,51 +167,6 @@ def conv(x, x_coff, plan, y, y_coff, relu=False, accumulate=False, xmask=None, x
     return y
 
 
-def fire_sq_e1_cfgs(s):
-    """(squeeze cfg id, expand1x1 cfg id) whose packings ops.fire_sq_e1 takes: the 64-pixel LDS-DMA 1x1 configuration covering all
-    ``s`` squeeze channels in one slice, and a KC = 32 packing with 32-row padding for the expand1x1; None if ``s`` has none."""
-    sq = e1 = None
-    for cid, (taps, kc, px, bn) in cfg_table().items():
-        if taps == 1 and kc == 32 and px == 64 and _CFG_DMA.get(cid, 0) == 1:
-            if bn == s:
-                sq = cid
-            if bn == 32:
-                e1 = cid
-    return (sq, e1) if (sq is not None and e1 is not None) else None
-
-
-def fire_sq_e1_ok(cin, s, e1):
-    """Shapes sqd_fire_squeeze_expand1x1_fwd runs: squeeze width 16 / 32 / 48 / 64 / 96, expand1x1 width a multiple of 32, C > 32."""
-    return s in (16, 32, 48, 64, 96) and e1 % 32 == 0 and e1 <= 1024 and cin > 32 and cin % 4 == 0 and fire_sq_e1_cfgs(s) is not None
-
-
-def fire_sq_e1(x, x_coff, sq_plan, e1_plan, sq, sq_coff, out, out_coff, wg_cap=0):
-    """sq[..., sq_coff:+s] = relu(squeeze(x)), out[..., out_coff:+e1] = relu(expand1x1(sq)) -- one launch (Fire.forward,
-    src/model/squeezedet.py:17-19): the squeeze tile feeds the expand1x1 from registers."""
-    _check_nhwc(x, 'x'); _check_nhwc(sq, 'sq'); _check_nhwc(out, 'out')
-    B, H, W, xp = x.shape
-    if tuple(sq.shape[:3]) != (B, H, W) or tuple(out.shape[:3]) != (B, H, W):
-        raise ValueError('fire_sq_e1: x / sq / out disagree on B,H,W')
-    s, e1 = sq_plan.N, e1_plan.N
-    if (sq_plan.taps, e1_plan.taps, sq_plan.kc, e1_plan.kc) != (1, 1, 32, 32) or e1_plan.C != s or sq_plan.Npad != s or not fire_sq_e1_ok(sq_plan.C, s, e1):
-        raise ValueError('fire_sq_e1: plans do not fit (KC = 32 packings, squeeze in one slice)')
-    if x_coff < 0 or x_coff + sq_plan.C > xp or sq_coff < 0 or sq_coff + s > sq.shape[3] or out_coff < 0 or out_coff + e1 > out.shape[3]:
-        raise ValueError('fire_sq_e1: channel window out of range')
-    br = None
-    if timing._timer is not None:
-        npix = B * H * W
-        br = _Bracket(f'fire_sq_e1<{s // 16}>', f'sq+e1 C{sq_plan.C} S{s} E{e1} {H}x{W}', 2.0 * npix * (sq_plan.C * s + s * e1),
-                      4.0 * (npix * (sq_plan.C + s + e1) + s * sq_plan.C + s * e1))
-    rc = nat.lib().sqd_fire_squeeze_expand1x1_fwd(nat.ptr(x), nat.ptr(sq_plan.w), nat.ptr(sq_plan.bias), nat.ptr(sq), nat.ptr(e1_plan.w),
-                                                  nat.ptr(e1_plan.bias), nat.ptr(out), B, H, W, sq_plan.C, xp, x_coff, s, sq_plan.Npad,
-                                                  sq.shape[3], sq_coff, e1, e1_plan.Npad, out.shape[3], out_coff, int(wg_cap),
-                                                  nat.stream_handle(x.device))
-    nat.check(rc, 'sqd_fire_squeeze_expand1x1_fwd')
-    if br is not None:
-        br.done()
-    return sq, out
-
-
 def fire_expand(x, x_coff, fplan, y, y_coff):
     """y[..., y_coff:y_coff+E] = relu(expand1x1(x)), y[..., y_coff+E:y_coff+2E] = relu(expand3x3(x)), one launch."""
     _check_nhwc(x, 'x'); _check_nhwc(y, 'y')

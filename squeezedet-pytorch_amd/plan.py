@@ -31,8 +31,8 @@ def _conv1x1(batch, H, W, Cin, N):
 
 def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
                           use_winograd=True, fuse_expand=True, fuse_fire_bridge=True, fuse_expand_wino=True,
-                          fuse_pool_squeeze=False, fuse_stem_squeeze=True, fuse_sq_e1=False):
-    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order.  The seven switches are
+                          fuse_pool_squeeze=False, fuse_stem_squeeze=True):
+    """-> list of (kernel name as bench.py / KernelTimer prints it, shape tag), in launch order.  The six switches are
     ``SqueezeDetBase``'s attributes of the same names, one to one."""
     layers = layer_table(arch)
     H, W = ops.stem_out_size(input_size[0], input_size[1], layers[0][3])
@@ -78,12 +78,8 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
         if zseg is None and ycfg is None:
             xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fuse_expand_wino and use_winograd) else None
             fcfg = ops.choose_fused_cfg(s, e1, npix) if (xcfg is None and fuse_expand and e1 == e3) else None
-        chain = (not bridged and unpooled is None and zseg is None and ycfg is None and xcfg is None and fcfg is None
-                 and fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1))
         if bridged:
             pass
-        elif chain:
-            plan.append((f'fire_sq_e1<{s // 16}>', f'sq+e1 C{cin} S{s} E{e1} {H}x{W}'))
         elif unpooled is not None:
             plan.append(('pool_squeeze', f'pool+squeeze C{cin} N{s} {unpooled[0]}x{unpooled[1]}'))
             unpooled = None
@@ -99,9 +95,7 @@ def inference_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), a
             plan.append(('fire_bridge', f'fire C{s} E{e1}+{e3} -> S{nxt[2]} {H}x{W}'))
             bridged = True
             continue
-        if chain:
-            plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
-        elif xcfg is not None:
+        if xcfg is not None:
             plan.append((ops.fire_wino_kernel_name(xcfg), f'fire C{s} E{e1}+{e3} {H}x{W}'))
         elif fcfg is not None:
             plan.append((ops.cfg_kernel_name(fcfg).replace('conv_dma', 'fire_expand'), f'expand C{s} E{e1} {H}x{W}'))
@@ -120,7 +114,7 @@ def _wgrad(batch, H, W, N, C, taps):
 
 
 def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
-                         use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True, fuse_sq_e1=False, dropout=True,
+                         use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True, dropout=True,
                          fused_dropout=True, fuse_train_forward=True, fuse_fire_bridge=True, fuse_stem_squeeze=True):
     """Launches of one training iteration's forward (activations saved; ``fuse_train_forward``: the stem + squeeze launch and the
     two small-C bridges run in their STORING forms -- what the backward reads is written by the fused launch -- where the table has
@@ -190,19 +184,15 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
             dcfg = ops.conv_drop_cfg(s, e1, batch * H * W) if (fused_dropout and s % 8 == 0 and use_winograd) else None
             if dcfg is None:
                 plan.append(('dropout_mask', f'{batch * H * W * (e1 + e3)} elements'))
-        if fuse_sq_e1 and ops.fire_sq_e1_ok(cin, s, e1) and not (is_last and dropout) and not bridged:
-            plan.append((f'fire_sq_e1<{s // 16}>', f'sq+e1 C{cin} S{s} E{e1} {H}x{W}'))
-            plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
+        if not bridged:
+            plan.append(_conv1x1(batch, H, W, cin, s))
+        bridged = False
+        if dcfg is not None:
+            plan.append((ops.cfg_kernel_name(dcfg), f'1tap C{s} N{e1} {H}x{W}'))
+            plan.append(('conv_wino_sk', f'9tap C{s} N{e3} {H}x{W}'))
         else:
-            if not bridged:
-                plan.append(_conv1x1(batch, H, W, cin, s))
-            bridged = False
-            if dcfg is not None:
-                plan.append((ops.cfg_kernel_name(dcfg), f'1tap C{s} N{e1} {H}x{W}'))
-                plan.append(('conv_wino_sk', f'9tap C{s} N{e3} {H}x{W}'))
-            else:
-                plan.append(_conv1x1(batch, H, W, s, e1))
-                plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
+            plan.append(_conv1x1(batch, H, W, s, e1))
+            plan.append(_conv3x3(batch, H, W, s, e3, use_winograd))
         C = e1 + e3
     ncd = anchors_per_grid * (num_classes + 5)
     ccd = convdet_in_channels(arch)

@@ -422,8 +422,9 @@ class WgradBatch:
         off, n = self.slabs[key]
         return self.workspace[off:off + n]
 
-    def reduce(self, grad_flat, row_lo=0, row_hi=None):
-        """Reduce the slabs of records [row_lo, row_hi) (default: all) into ``grad_flat``."""
+    def reduce(self, grad_flat, row_lo=0, row_hi=None, scale=1.0):
+        """Reduce the slabs of records [row_lo, row_hi) (default: all) into ``grad_flat``, times ``scale`` (the data-parallel exchange's
+        image-count weight; 1 leaves the sums bit for bit)."""
         row_hi = self.nrows if row_hi is None else row_hi
         if not (0 <= row_lo < row_hi <= self.nrows):
             raise ValueError('WgradBatch.reduce: bad record range')
@@ -432,10 +433,10 @@ class WgradBatch:
         br = _Bracket('wgrad_reduce_batched', f'{nrec} layers', 0.0, self.bytes * (b1 - b0) / max(self.total_blocks, 1)) if timing._timer is not None else None
         if nrec == self.nrows:
             rc = nat.lib().sqd_wgrad_reduce_batched(nat.ptr(self.table), self.nrows, self.total_blocks, nat.ptr(self.workspace),
-                                                    nat.ptr(grad_flat), nat.stream_handle(grad_flat.device))
+                                                    nat.ptr(grad_flat), float(scale), nat.stream_handle(grad_flat.device))
         else:
             rc = nat.lib().sqd_wgrad_reduce_batched_range(nat.c_p(self.table.data_ptr() + row_lo * 9 * 8), nrec, b0, b1 - b0,
-                                                          nat.ptr(self.workspace), nat.ptr(grad_flat), nat.stream_handle(grad_flat.device))
+                                                          nat.ptr(self.workspace), nat.ptr(grad_flat), float(scale), nat.stream_handle(grad_flat.device))
         nat.check(rc, 'sqd_wgrad_reduce_batched')
         if br is not None:
             br.done()

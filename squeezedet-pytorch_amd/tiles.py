@@ -161,6 +161,8 @@ def wino_cfgs():
     import ctypes
     out = {WINO_SK_CFG: (32, 4), WINO_VS_CFG: (80, 12)}
     for i in range(nat.lib().sqd_wino_num_cfgs()):
+        if 4 <= i <= 7:             # retired ids (deep-prefetch, streamed U): the library answers "unsupported"
+            continue
         bn, wv = ctypes.c_int(), ctypes.c_int()
         nat.check(nat.lib().sqd_wino_cfg_info(i, ctypes.byref(bn), ctypes.byref(wv)), 'sqd_wino_cfg_info')
         out[i] = (bn.value, wv.value)
@@ -169,7 +171,7 @@ def wino_cfgs():
 
 def wino_kernel_name(cfg_id):
     """Name of a Winograd configuration as bench.py / the profiles print it: conv_wino<NT,WAVES> (ids 0..3),
-    conv_wino_dp<..> (4..7: deep-prefetch staging), conv_wino_us<..> (8..11: U-stationary, barrier-free)."""
+    conv_wino_us<..> (8..11: U-stationary, barrier-free; ids 4..7, the deep-prefetch streamed-U forms, are retired)."""
     c = cfg_id % 1000
     if c == WINO_SK_CFG:
         return 'conv_wino_sk'
@@ -179,11 +181,14 @@ def wino_kernel_name(cfg_id):
     return f'conv_wino{("", "_dp", "_us")[c // 4]}<{bn // 16},{wv}>'
 
 
-def wino_cfg_ok(cfg_id, C):
-    """Whether Winograd configuration ``cfg_id`` can run a layer with ``C`` input channels: ids 8..11 (U-stationary kernel)
-    keep the slice's whole transformed weight set in LDS next to the patch ring."""
+def wino_cfg_ok(cfg_id, C, N=None):
+    """Whether Winograd configuration ``cfg_id`` can run a layer with ``C`` input (and, when given, ``N`` output) channels: ids 8..11
+    (U-stationary kernel) keep the slice's whole transformed weight set in LDS next to the patch ring; the V-shared kernel runs
+    N <= 80 (with the plain bias / ReLU epilogue)."""
     c = cfg_id % 1000
-    if c < 8 or c in (WINO_SK_CFG, WINO_VS_CFG):
+    if c == WINO_VS_CFG:
+        return N is None or N <= 80
+    if c < 8 or c == WINO_SK_CFG:
         return True
     bn, wv = wino_cfgs()[c]
     return (2 * wv * 256 * 4 + (C // 8) * 32 * bn * 4) * 4 <= 160 * 1024
@@ -210,7 +215,7 @@ def wino_vs_fills_chip(npix, cus=256):
     return nwg / (cus * -(-nwg // cus)) >= 0.85
 
 
-FIRE_WINO_CFGS = (4, 6, 8, 10, 12)  # 32-channel-slice ids of the deep-prefetch / U-stationary Winograd family; 12: the small-C form
+FIRE_WINO_CFGS = (8, 10, 12)  # 32-channel-slice ids of the U-stationary Winograd family; 12: the small-C form
 
 
 def fire_wino_cfg_ok(cfg_id, C, E1=None, E3=None):
@@ -238,7 +243,7 @@ def fire_wino_kernel_name(cfg_id):
     return 'fire_wino16' if cfg_id % 1000 == 12 else wino_kernel_name(cfg_id).replace('conv_wino', 'fire_wino')
 
 
-FIRE_BRIDGE_CFGS = (6, 10, 12)
+FIRE_BRIDGE_CFGS = (10, 12)
 
 
 def fire_bridge_lds_bytes(cfg_id, C, N3, N1, Nsq):
@@ -321,16 +326,10 @@ def wgrad_uses_wino(N, C, taps, B, H, W, wino=None):
 
 def _wino_wgrad_tc(N, C):
     """Input-channel blocks of 16 per workgroup of the Winograd wgrad kernel: 2 (32 channels) unless that would leave the
-    last block half empty (C = 16, 48, ...: measured 50 vs 62 us on C48 -> N192) or the 5-block ConvDet variant runs."""
+    last block half empty (C = 16, 48, ...: measured 50 vs 62 us on C48 -> N192) or the 5-block ConvDet variant runs (its 32-channel form
+    was measured and removed: 228 -> 218 us for the kernel, but twice the splits and slab bytes cost the reduction more than that)."""
     if N % 64:
-        # the 5-block (N <= 80: ConvDet) variant can take 32 input channels per workgroup (SQD_WW52=1): the dY tile is staged for half
-        # as many channel groups, 228 -> 218 us at bs=20 -- but a resident round then has twice the splits (S 10 -> 21), its slabs grow
-        # from 20 to 42 MB and the batched reduction pays the 10 us back (0.112 -> 0.124 ms): off
-        import os
-        return 2 if (os.environ.get('SQD_WW52', '0')[:1] == '1' and C % 32 == 0) else 1
-    import os
-    if os.environ.get('SQD_WW_TC1', '0')[:1] == '1':      # (A/B: 16-channel in-tiles everywhere = twice the blocks, half the splits and slab bytes)
-        return 1
+        return 1                # the 5-block (N <= 80: ConvDet) variant: 16 input channels per workgroup
     return 1 if (C % 32 == 16 or C < 32) else 2
 
 

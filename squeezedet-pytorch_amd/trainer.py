@@ -67,18 +67,52 @@ class GradientExchange:
         self._pending = []
         self.buckets_last_step = []
         self._active = self.world() > 1 or (self.force and _dist() is not None)
+        # weight of this rank's gradient in the global mean: the backward multiplies it in where the gradients are produced (the slab
+        # reduction's ``scale``, ``scale_slice`` for the stem) -- no element-wise pass over the buckets
+        self.scale = self._b if self._active else 1.0
+        self._native = bool(self._active and flat.is_cuda)
         if self._active:
-            flat[total:].fill_(self._b)
+            if self._native:
+                from . import _native as nat
+                # the count slot, through the library (one thread): no torch kernel in the exchange
+                nat.check(nat.lib().sqd_grad_scale(None, 0, 1.0, None, nat.c_p(flat.data_ptr() + 4 * self._total), self._b,
+                                                   nat.stream_handle(flat.device)), 'sqd_grad_scale')
+            else:
+                flat[total:].fill_(self._b)
             if flat.is_cuda and self.overlap and self._side is None:
                 self._side = torch.cuda.Stream(device=flat.device)
 
+    def scale_slice(self, lo, hi):
+        """Weight ``flat[lo:hi]`` (a gradient that did not come out of the slab reduction: the stem's) by this rank's image count."""
+        if not self._active or hi <= lo:
+            return
+        if self._native:
+            from . import _native as nat
+            nat.check(nat.lib().sqd_grad_scale(nat.c_p(self._flat.data_ptr() + 4 * int(lo)), int(hi - lo), self.scale, None, None, 0.0,
+                                               nat.stream_handle(self._flat.device)), 'sqd_grad_scale')
+        else:
+            self._flat[lo:hi].mul_(self.scale)
+
+    def _divide(self, lo, grad_hi):
+        """flat[lo:grad_hi] /= the summed image count (device scalar in the count slot), on the current stream."""
+        from . import _native as nat
+        nat.check(nat.lib().sqd_grad_scale(nat.c_p(self._flat.data_ptr() + 4 * int(lo)), int(grad_hi - lo), 1.0,
+                                           nat.c_p(self._flat.data_ptr() + 4 * self._total), None, 0.0,
+                                           nat.stream_handle(self._flat.device)), 'sqd_grad_scale')
+
     def ready(self, lo, hi):
+        """``flat[lo:hi]`` is final on the current stream AND already weighted by ``scale``: all-reduce it (SUM).  On the GPU the
+        bucket is divided by the summed image count right behind its collective, on the side stream (the count slot travels with the
+        first bucket handed over -- the tail of the buffer -- so it is final before any division); CPU buffers (gloo rehearsals) are
+        divided in ``finish``."""
         if not self._active or hi <= lo:
             return
         t_in = time.perf_counter() if self.trace is not None else 0.0
         d = _dist()
         if hi == self._total:
             hi = self._flat.numel()             # the count slot travels with the tail bucket
+        elif not self.buckets_last_step and self._native:
+            raise RuntimeError('GradientExchange.ready: the first bucket must be the tail of the buffer (it carries the count slot)')
         self.buckets_last_step.append((int(lo), int(hi)))
         grad_hi = min(hi, self._total)
         if self._side is not None:
@@ -86,12 +120,12 @@ class GradientExchange:
             ev.record()
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
-                self._flat[lo:grad_hi].mul_(self._b)
                 work = d.all_reduce(self._flat[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
+                work.wait()                     # (stream-level: the side stream waits for the collective, the host does not)
+                self._divide(lo, grad_hi)
         else:
-            self._flat[lo:grad_hi].mul_(self._b)
             work = d.all_reduce(self._flat[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append(work)
+            self._pending.append((work, lo, grad_hi))
         if self.trace is not None:
             self.trace.append((f'ready[{lo}:{hi}]', time.perf_counter() - t_in))
 
@@ -99,15 +133,19 @@ class GradientExchange:
         if not self._active:
             return
         t_in = time.perf_counter() if self.trace is not None else 0.0
-        for w in self._pending:
+        for w, _lo, _hi in self._pending:
             w.wait()                            # CUDA: the current stream waits for the collective; CPU: blocks
         if self.trace is not None:
             self.trace.append(('finish.wait', time.perf_counter() - t_in))
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        elif self._native:
+            for _w, lo, hi in self._pending:
+                self._divide(lo, hi)
+        else:
+            flat, total = self._flat, self._total
+            flat[:total].div_(flat[total])      # global image count, summed by the same all-reduce
         self._pending = []
-        flat, total = self._flat, self._total
-        flat[:total].div_(flat[total])          # global image count, summed by the same all-reduce
         self._flat = None
 
 
@@ -419,6 +457,10 @@ class FusedClipSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        """One clip + SGD step.  Returns the total gradient norm (``clip_grad_norm_``'s return value) as a 0-dim DEVICE tensor that
+        ALIASES a persistent workspace (also kept in ``last_norm``): the next ``step`` overwrites it in place -- a copy per step would
+        be the one torch kernel of an otherwise torch-free captured training step.  Callers that keep norms across iterations take
+        the value at once (``float(norm)`` / ``norm.item()``) or ``norm.clone()`` (``norm_value()`` = the float of the latest step)."""
         from . import _native as nat
         loss = None
         if closure is not None:
@@ -469,6 +511,10 @@ class FusedClipSGD(torch.optim.Optimizer):
         torch.autograd.graph.increment_version(params)        # (the packed-weight caches key on the version counters)
         self.last_norm = norm
         return norm if closure is None else loss
+
+    def norm_value(self):
+        """The latest step's total gradient norm as a Python float (one host sync), or None before the first clipped step."""
+        return None if self.last_norm is None else float(self.last_norm)
 
     def state_dict(self):
         g = self.param_groups[0]

@@ -100,6 +100,7 @@ def _exchange_worker(rank, world, port, out_dir, B=5):
         ex.begin(flat, total, sizes[rank])
         top = total
         for c in cuts:                                              # tail first, like the backward walk
+            ex.scale_slice(c, top)                                  # (the HIP backward weights a stage's gradients where it produces them)
             ex.ready(c, top); top = c
         ex.finish()
         results[label] = flat[:total].clone()

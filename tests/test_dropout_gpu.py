@@ -149,3 +149,26 @@ def test_masks_differ_between_steps_and_seeds_and_follow_manual_seed():
         a3 = m.base(x).clone()
     assert float((a3 - a).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max()))
     assert m.base.drop_state(dev).get()[1] == 1
+
+
+def test_restored_dropout_stream_survives_reseeding():
+    """a stream restored by ``set_dropout_rng`` (checkpoint resume) used to be dropped -- silently restarted at step 0 --
+    as soon as torch was re-seeded (the per-rank offset of ``attach_data_parallel`` on ranks > 0, a ``torch.manual_seed`` of the
+    training script).  It now stays until ``set_dropout_rng`` replaces it; a stream DERIVED from torch's seed still follows it."""
+    import squeezedet_pytorch_amd as sqd
+    from squeezedet_pytorch_amd.model import SqueezeDetBase
+    cfg = sqd.make_cfg(input_size=(64, 96))
+    base = SqueezeDetBase(cfg).cuda()
+    torch.manual_seed(11)
+    d0 = base.drop_state('cuda:0')
+    assert base.get_dropout_rng()[1] == 0
+    torch.manual_seed(12)                                   # derived stream: follows the new seed
+    assert base.drop_state('cuda:0') is not d0
+    base.set_dropout_rng(0x1234567, 41, 'cuda:0')
+    torch.manual_seed(13)
+    torch.manual_seed(torch.initial_seed() + 3)             # what attach_data_parallel does on rank 3
+    assert tuple(base.get_dropout_rng()) == (0x1234567, 41)
+    kept = base.drop_state('cuda:0')
+    assert tuple(kept.get()) == (0x1234567, 41)
+    base.set_dropout_rng(99, 7, 'cuda:0')
+    assert tuple(base.drop_state('cuda:0').get()) == (99, 7)

@@ -303,16 +303,15 @@ def test_bs20_gradients_vs_reference_float64_golden(golden_dir):
     (1002, 8, 96, 312, 16, 64),      # <2,4>, one workgroup per CU: 960 super-groups on 128 streams = 8 rounds
     (1003, 8, 96, 312, 16, 64),      # <1,4>
     (1000, 6, 48, 156, 32, 128),     # <2,8>
-    (1006, 8, 96, 312, 16, 64),      # deep-prefetch kernel <2,4>: ring slots wrap many times inside one workgroup
-    (1007, 8, 96, 312, 16, 64),      # deep-prefetch <1,4>
-    (1004, 6, 48, 156, 32, 128),     # deep-prefetch <2,8>
-    (6, 20, 24, 78, 768, 72),        # deep-prefetch ConvDet at bs=20: 96 chunks per tile, partial last slice
-    (1006, 3, 7, 20, 8, 24),         # one chunk per tile: the prefetch cursor runs two TILES ahead
     (1010, 8, 96, 312, 16, 64),      # U-stationary, barrier-free <2,4>: free-running waves over many tiles
     (10, 20, 48, 156, 32, 128),      # ... fire6/7 at bs=20
     (1008, 6, 48, 156, 32, 128),     # U-stationary <2,8>
     (11, 20, 96, 312, 64, 16),       # U-stationary <1,4>: the C64 -> N16 data gradient of fire3's expand3x3
     (1002, 20, 24, 78, 768, 72),     # ConvDet at bs=20 under a cap: 3 slices, tail super-group with idle waves
+    (17, 20, 24, 78, 768, 72),       # V-shared kernel (conv_wino_vs.hip): ConvDet at bs=20, 250 twelve-unit workgroups, 96 chunks
+    (17, 16, 24, 78, 512, 72),       # ... squeezedetplus' ConvDet at bs=16
+    (17, 3, 7, 20, 8, 24),           # ... one chunk, N = 24 (blocks 2..4 of every group idle), partial groups on both axes
+    (17, 7, 4, 16, 32, 72),          # ... 35 units: the last workgroup has an idle wave; groups cut by workgroup boundaries
 ])
 def test_conv_wino_multi_round_persistent(cfg_id, B, H, W, C, N):
     """Kernel level: the persistent loop of conv_wino.hip (``tile += tstride``, the cross-tile prefetch of the next

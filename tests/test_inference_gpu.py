@@ -383,39 +383,6 @@ def test_golden_forward_with_and_without_stem_squeeze(golden_dir):
     np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
 
 
-@pytest.mark.parametrize("bridges", [True, False])
-def test_golden_forward_through_chained_squeeze_expand1x1(golden_dir, bridges):
-    """The reference-generated goldens with every Fire that runs squeeze and expand1x1 as two plain launches switched to the ONE-launch
-    chained form (``fuse_sq_e1``, a tested switch that is off by default: measured slower in the step): same 1e-4 bound."""
-    from squeezedet_pytorch_amd import timing
-    g = np.load(os.path.join(golden_dir, "backbone_small.npz"))
-    for arch in ("squeezedet", "squeezedetplus"):
-        cfg, m, sd = _model(arch, (64, 96))
-        m.base.fuse_sq_e1 = True
-        m.base.fuse_fire_bridge = bridges
-        x = synthetic.make_images(2, (64, 96), seed=3)
-        kt = timing.KernelTimer()
-        timing.set_timer(kt)
-        try:
-            with torch.no_grad():
-                pred = m.base(x.cuda())
-        finally:
-            timing.set_timer(None)
-        torch.cuda.synchronize()
-        n = sum(1 for r in kt.records if r[0].startswith('fire_sq_e1'))
-        assert n >= (6 if arch == 'squeezedet' else 1), n                   # (SqueezeDet+: only its 96-channel squeezes have a chained form)
-        np.testing.assert_allclose(pred.cpu().numpy(), g[f"{arch}_pred"], atol=TOL, rtol=0)
-    gk = np.load(os.path.join(golden_dir, "kitti_full.npz"))
-    cfg, m, sd = _model('squeezedet', (384, 1248))
-    m.base.fuse_sq_e1 = True
-    m.base.fuse_fire_bridge = bridges
-    x1 = synthetic.make_images(1, (384, 1248), seed=0)
-    with torch.no_grad():
-        pred1 = m.base(x1.cuda())
-    np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
-    np.testing.assert_allclose(pred1[0].cpu().numpy()[gk["top_idx"]], gk["pred_top"], atol=TOL, rtol=0)
-
-
 def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
     """The reference-generated goldens with every Fire -> Fire pair the bridge launches can take (expand pair + the next Fire's
     squeeze in one kernel, squeeze width <= 32: fire3 -> fire4 and fire6 -> fire7 of SqueezeDet; and through the max pool,

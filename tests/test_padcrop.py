@@ -105,10 +105,52 @@ def test_detect_dataset_does_not_deadlock_with_few_workers(workers, capsys):
     det.cfg = types.SimpleNamespace(batch_size=2, print_interval=10, num_workers=workers, device='cpu')
     seen = {}
 
-    def fake_detect_images(images, image_ids=None, rgb_mean=None, rgb_std=None):
-        seen['mean'] = rgb_mean
-        return [{'image_meta': {'image_id': iid, 'pix': int(im[0, 0, 0])}} for im, iid in zip(images, image_ids)]
-    det.detect_images = fake_detect_images
+    class _Staged:                                  # the host side of lanes.Staging: loader threads put their image into slot b
+        def __init__(self, n):
+            self.n, self.images = n, [None] * n
+
+        def put(self, b, im):
+            self.images[b] = np.asarray(im)
+            return True
+
+    class _Result:
+        def __init__(self, st, ids, tag):
+            self.tag = tag
+            self._out = [{'image_meta': {'image_id': iid, 'pix': int(im[0, 0, 0]), 'index': b}} for b, (im, iid) in enumerate(zip(st.images, ids))]
+
+        def per_image(self):
+            return self._out
+
+    class _FakeStream:                              # lanes.DetectStream's interface without a GPU: results come back one batch late
+        _lanes = [None, None]
+
+        def __init__(self, rgb_mean):
+            seen['mean'] = rgb_mean
+            self.q = []
+
+        def pending(self):
+            return len(self.q)
+
+        def oldest_ready(self):
+            return len(self.q) > 1
+
+        def stage(self, n):
+            return _Staged(n)
+
+        def submit(self, st, image_ids=None, tag=None):
+            assert all(im is not None for im in st.images)
+            self.q.append(_Result(st, image_ids, tag))
+
+        def discard(self, st):
+            pass
+
+        def fetch(self):
+            return 0, self.q.pop(0)
+
+        def drain(self):
+            out, self.q = [(0, r) for r in self.q], []
+            return out
+    det.stream = lambda lanes=None, graph=True, rgb_mean=None, rgb_std=None: _FakeStream(rgb_mean)
     res = []
     t = threading.Thread(target=lambda: res.extend(det.detect_dataset(_Set(5))), daemon=True)
     t.start(); t.join(30)

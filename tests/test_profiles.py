@@ -36,8 +36,6 @@ def test_launch_plan_totals():
     r = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_stem_squeeze=False)
     assert r[0][0] == 'stem_pool<3>' and len(r) == len(p) + 1
     # squeeze + expand1x1 as one launch (a tested switch, off: measured slower): 7 launch pairs merge
-    r = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_sq_e1=True)
-    assert len(r) == len(p) - 7 and sum(1 for n, _ in r if n.startswith('fire_sq_e1')) == 7
     # without the bridges: the plain launch set
     q = plan.inference_launch_plan('squeezedet', 20, (384, 1248), fuse_fire_bridge=False)
     assert len(q) == 1 + 2 + 29 + 1 + 1 and sum(1 for n, _ in q if n.startswith('conv_wino')) == 11
@@ -78,3 +76,42 @@ def test_training_traffic_profile_matches_shipped_launch_set():
     for kernel in tr:
         if kernel.startswith(('conv_', 'fire_', 'stem_', 'maxpool', 'wgrad_reduce_batched')):
             assert kernel in want, f'{kernel}: in the training profile but not launched by the shipped plan'
+
+
+def _latest_round_tag():
+    import glob
+    import re
+    tags = sorted({re.match(r'(r\d+[a-z]*)_kernel_stats_serial\.csv', os.path.basename(f)).group(1)
+                   for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats_serial.csv'))})
+    assert tags, 'no serial kernel trace committed (scratch/prof.sh <tag> _serial --inflight 1 --no-pipeline)'
+    return tags[-1]
+
+
+def test_serial_kernel_trace_reproduces_the_event_medians_of_the_bench_line():
+    """``roofline.frac`` must be recomputable from profiles/ alone.  The round's SERIAL rocprofv3 kernel trace
+    (one step at a time: ``bench.py --inflight 1``; with two lanes in flight a kernel's average mixes contended launches) and the
+    serial bench line of the same build agree on the dominant kernel's average launch duration within 5 %, launch for launch."""
+    import csv
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from kernel_names import short_name
+    tag = _latest_round_tag()
+    line = json.loads([l for l in open(os.path.join(ROOT, 'profiles', f'{tag}_bench_serial.json')) if l.startswith('{')][-1])
+    roof = line['roofline']
+    assert line.get('steps_in_flight', 1) == 1 and not line.get('degraded', False)
+    dur, calls = {}, {}
+    for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats_serial.csv'))):
+        k = short_name(r['Name'])
+        dur[k] = dur.get(k, 0.0) + float(r['TotalDurationNs']); calls[k] = calls.get(k, 0) + int(r['Calls'])
+    k = roof['kernel']
+    assert k in dur, f'{k} (the bench line\'s dominant kernel) is not in the serial trace'
+    assert calls[k] % roof['launches_per_step'] == 0
+    rocprof_us = dur[k] / calls[k] / 1e3
+    assert abs(rocprof_us - roof['avg_launch_us']) <= 0.05 * roof['avg_launch_us'], (k, rocprof_us, roof['avg_launch_us'])
+    # frac from profiles/ alone: algorithmic flops per launch (on the line) / the trace's average duration / the peak
+    frac = roof['algorithmic_per_launch']['gflop'] / rocprof_us * 1e-3 / roof['peak']
+    assert abs(frac - roof['frac']) <= 0.05 * roof['frac']
+    # the same trace lists every kernel of the shipped inference plan
+    from squeezedet_pytorch_amd import plan
+    for kernel in plan.launches_per_kernel(plan.inference_launch_plan('squeezedet', 20, (384, 1248))):
+        assert kernel in dur, f'{kernel}: in the shipped plan, absent from the serial trace'

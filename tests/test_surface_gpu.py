@@ -151,8 +151,7 @@ def test_bench_default_line_has_pipeline_and_cpu_legs():
 @pytest.mark.parametrize("flags", [{}, {'fuse_fire_bridge': False}, {'fuse_fire_bridge': False, 'fuse_expand_wino': False},
                                    {'fuse_fire_bridge': False, 'fuse_expand': False, 'fuse_expand_wino': False},
                                    {'fuse_fire_bridge': False, 'fuse_pool_squeeze': True}, {'use_winograd': False},
-                                   {'fuse_stem_squeeze': False}, {'fuse_stem_squeeze': False, 'fuse_fire_bridge': False},
-                                   {'fuse_sq_e1': True}, {'fuse_sq_e1': True, 'fuse_fire_bridge': False, 'fuse_stem_squeeze': False}])
+                                   {'fuse_stem_squeeze': False}, {'fuse_stem_squeeze': False, 'fuse_fire_bridge': False}])
 def test_inference_launch_plan_equals_real_launches(flags):
     """plan.inference_launch_plan (host only; what tests/test_profiles.py checks profiles/traffic.json against) lists exactly
     the launches the model issues -- kernel name and shape tag, in order -- for the default flags and for non-default ones."""

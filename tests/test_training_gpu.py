@@ -219,26 +219,6 @@ def test_kitti_size_backward_spot_check():
     _check_grads_flip_aware(m.named_parameters(), grads)
 
 
-def test_training_step_with_chained_squeeze_expand1x1():
-    """One training iteration with the forward's squeeze + expand1x1 pairs as ONE launch each (``fuse_sq_e1``; the saved squeeze
-    tensors are bit-identical, the expand1x1 outputs differ by summation order): loss and every gradient agree with the default path."""
-    size = (64, 96)
-    x = synthetic.make_images(2, size, seed=5)
-    res = {}
-    for flag in (False, True):
-        cfg, m, sd = _train_model('squeezedet', size)
-        m.base.fuse_sq_e1 = flag
-        gt = synthetic.make_gt(2, cfg.anchors, size, seed=2, min_boxes=2, max_boxes=3)
-        loss, _ = m({'image': x.cuda(), 'gt': gt.cuda()})
-        loss.mean().backward()
-        res[flag] = (loss.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()})
-    assert torch.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
-    for n, gd in res[False][1].items():
-        gc = res[True][1][n]
-        denom = max(float(gd.norm()), 1e-12)
-        assert float((gc - gd).norm()) / denom <= 2e-3, (n, float((gc - gd).norm()) / denom)
-
-
 @pytest.mark.parametrize("k,N,H,W", [(3, 64, 64, 96), (3, 64, 50, 70), (7, 96, 64, 96)])
 def test_stem_wgrad_pooled(k, N, H, W):
     """Fused forward (conv+ReLU+pool with argmax) + backward folded into the stem wgrad vs CPU autograd."""

@@ -64,8 +64,10 @@ while time.time() - t0 < budget:
         n_ok += 1
     # Winograd form of the same 3x3 layer (C % 8 == 0), same windows; the epilogue options need y's own geometry
     if taps == 9 and C % 8 == 0:
-        wc = int(rs.choice([c for c in ops.wino_cfgs() if ops.wino_cfg_ok(c, C) and ops.wino_cfg_ok(c, N)])) + 1000 * int(rs.choice([0, 0, 1]))
-        wmode = int(rs.randint(0, 4)); wrelu = bool(rs.randint(0, 2))
+        wc = int(rs.choice([c for c in ops.wino_cfgs() if ops.wino_cfg_ok(c, C) and ops.wino_cfg_ok(c, N) and (c != ops.WINO_VS_CFG or N <= 80)]))
+        vs = wc == ops.WINO_VS_CFG                              # the V-shared kernel: N <= 80, plain epilogue, no workgroup cap
+        wc += 0 if vs else 1000 * int(rs.choice([0, 0, 1]))
+        wmode = 0 if vs else int(rs.randint(0, 4)); wrelu = bool(rs.randint(0, 2))
         yw = y0.clone().cuda(); wkw = {}; wref = nhwc(ref)
         if wmode in (1, 3):
             wkw['accumulate'] = True; wref = wref + y0[..., yo:yo + N]
@@ -81,7 +83,7 @@ while time.time() - t0 < budget:
         if not (e5 <= tolw and torch.equal(outw[..., :yo], y0[..., :yo]) and torch.equal(outw[..., yo + N:], y0[..., yo + N:])):
             print('WINOGRAD MISMATCH', dict(wc=wc, B=B, H=H, W=W, C=C, N=N, xp=xp, xo=xo, yp=yp, yo=yo, mode=wmode, relu=wrelu, err=e5, tol=tolw)); sys.exit(1)
         worst = max(worst, e5 / tolw); n_ok += 1
-        if N % 8 == 0 and rs.rand() < 0.5:             # data-gradient packing: dX = conv_transpose(dY, w)
+        if N % 8 == 0 and rs.rand() < 0.5 and (not vs or C <= 80):             # data-gradient packing: dX = conv_transpose(dY, w)
             dyw = torch.randn(B, N, H, W)
             refdx = nhwc(F.conv_transpose2d(dyw, w, None, padding=1))
             dxw = torch.full((B, H, W, C), float('nan')).cuda()
