@@ -101,10 +101,9 @@ class GradientExchange:
                                            nat.stream_handle(self._flat.device)), 'sqd_grad_scale')
 
     def ready(self, lo, hi):
-        """``flat[lo:hi]`` is final on the current stream AND already weighted by ``scale``: all-reduce it (SUM).  On the GPU the
-        bucket is divided by the summed image count right behind its collective, on the side stream (the count slot travels with the
-        first bucket handed over -- the tail of the buffer -- so it is final before any division); CPU buffers (gloo rehearsals) are
-        divided in ``finish``."""
+        """``flat[lo:hi]`` is final on the current stream AND already weighted by ``scale``: all-reduce it (SUM) -- on the side stream when
+        overlapping.  ``finish`` divides by the summed image count (the count slot travels with the first bucket handed over, the tail
+        of the buffer)."""
         if not self._active or hi <= lo:
             return
         t_in = time.perf_counter() if self.trace is not None else 0.0
@@ -121,11 +120,9 @@ class GradientExchange:
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
                 work = d.all_reduce(self._flat[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
-                work.wait()                     # (stream-level: the side stream waits for the collective, the host does not)
-                self._divide(lo, grad_hi)
         else:
             work = d.all_reduce(self._flat[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append((work, lo, grad_hi))
+        self._pending.append((work, lo, grad_hi))
         if self.trace is not None:
             self.trace.append((f'ready[{lo}:{hi}]', time.perf_counter() - t_in))
 
@@ -139,9 +136,11 @@ class GradientExchange:
             self.trace.append(('finish.wait', time.perf_counter() - t_in))
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
-        elif self._native:
-            for _w, lo, hi in self._pending:
-                self._divide(lo, hi)
+        if self._native:
+            # ONE launch over the whole buffer, behind the last collective (the summed count is in the slot by then).  (Dividing every
+            # bucket on the side stream right behind its own collective -- side waits on the collective's stream, the next collective
+            # waits on side again -- captured into a graph that crashed hipStreamEndCapture on ROCm 7.2; 8 MB take ~5 us here.)
+            self._divide(0, self._total)
         else:
             flat, total = self._flat, self._total
             flat[:total].div_(flat[total])      # global image count, summed by the same all-reduce

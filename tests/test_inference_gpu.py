@@ -332,8 +332,10 @@ def test_golden_forward_through_one_launch_winograd_fire(golden_dir, monkeypatch
     def always(C, E1, E3, npix):
         if C % 8 or E1 % 16:
             return None
+        if not ops.fire_wino_cfg_ok(10, C):          # (larger squeezes: the U-stationary form does not fit; the streamed-U ids are retired)
+            return None
         used['n'] += 1
-        return 10 if ops.fire_wino_cfg_ok(10, C) else 6
+        return 10
     monkeypatch.setattr(ops, 'choose_fire_wino_cfg', always)
     monkeypatch.setattr(ops, 'choose_wino_cfg', lambda C, N, npix: (2 if C % 8 == 0 else None))
     g = np.load(os.path.join(golden_dir, "backbone_small.npz"))
@@ -349,7 +351,7 @@ def test_golden_forward_through_one_launch_winograd_fire(golden_dir, monkeypatch
     with torch.no_grad():
         pred1 = m.base(x1.cuda())
     np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
-    assert used['n'] >= 30
+    assert used['n'] >= 12
 
 
 def test_golden_forward_with_and_without_stem_squeeze(golden_dir):
@@ -392,7 +394,7 @@ def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
     used = {'n': 0}
 
     def always(C, E1, E3, Nsq, npix):
-        for cid in (12, 10, 6):
+        for cid in (12, 10):
             if ops.fire_bridge_cfg_ok(cid, C, E3, E1, Nsq):
                 used['n'] += 1
                 return cid
@@ -425,7 +427,7 @@ def test_golden_forward_through_fire_bridges(golden_dir, monkeypatch):
         pred1 = m.base(x1.cuda())
     np.testing.assert_allclose(pred1[0, ::257].cpu().numpy(), gk["pred_rows"], atol=TOL, rtol=0)
     np.testing.assert_allclose(pred1[0].cpu().numpy()[gk["top_idx"]], gk["pred_top"], atol=TOL, rtol=0)
-    assert used['n'] == 6                                   # three bridges x two SqueezeDet forwards
+    assert used['n'] == 4                                   # two bridges (fire3 -> fire4, fire4 -> pool -> fire6) x two SqueezeDet forwards
 
 
 def test_filter_nms_boundary_gpu():
