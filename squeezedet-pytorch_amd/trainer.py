@@ -53,6 +53,7 @@ class GradientExchange:
         self._side = None
         self._flat = None
         self._pending = []
+        self._captured_works = []
         self.buckets_last_step = []            # [(lo, hi)] of the latest backward, for tests / logging
         # diagnostics (SQD_EXCHANGE_TRACE=1): host wall time spent inside ready() / finish() per step, [(name, seconds)]
         import os
@@ -123,6 +124,13 @@ class GradientExchange:
         else:
             work = d.all_reduce(self._flat[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, lo, grad_hi))
+        if self._flat.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a collective issued while a hipGraph is being captured: its Work object (and the events inside, recorded in the capturing
+            # stream) is kept alive for the life of the exchange.  Released, those events go back to the process group's event cache and
+            # the next EAGER collective (a barrier right behind the capture) reuses one; the group's watchdog thread has been seen to
+            # query such an event while it still counted as "recorded in a capturing stream" and to abort the process (about one run
+            # in ten of `bench.py --force-dist`).  A handful of objects per captured step.
+            self._captured_works.append(work)
         if self.trace is not None:
             self.trace.append((f'ready[{lo}:{hi}]', time.perf_counter() - t_in))
 

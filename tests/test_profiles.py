@@ -109,7 +109,7 @@ def test_serial_kernel_trace_reproduces_the_event_medians_of_the_bench_line():
     rocprof_us = dur[k] / calls[k] / 1e3
     assert abs(rocprof_us - roof['avg_launch_us']) <= 0.05 * roof['avg_launch_us'], (k, rocprof_us, roof['avg_launch_us'])
     # frac from profiles/ alone: algorithmic flops per launch (on the line) / the trace's average duration / the peak
-    frac = roof['algorithmic_per_launch']['gflop'] / rocprof_us * 1e-3 / roof['peak']
+    frac = roof['algorithmic_per_launch']['gflop'] / rocprof_us * 1e3 / roof['peak']           # GFLOP / us = 1e3 TFLOP/s
     assert abs(frac - roof['frac']) <= 0.05 * roof['frac']
     # the same trace lists every kernel of the shipped inference plan
     from squeezedet_pytorch_amd import plan
