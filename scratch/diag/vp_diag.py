@@ -7,7 +7,10 @@ lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(_
 B, H, W, C, N = 20, 24, 78, 96, 384
 x = torch.randn(B, H, W, C, device='cuda').relu_()
 w = torch.randn(N, C, 3, 3, device='cuda') * 0.05; b = torch.randn(N, device='cuda')
-plan = ops.WinoPlan(w, b, tiles.WINO_VP_CFG)
+class _P: pass
+plan = _P(); plan.bias = b
+plan.w = torch.empty(C // 8, 16, N, 8, device='cuda')
+nat.check(nat.lib().sqd_pack_wino_weight(nat.ptr(w), nat.ptr(plan.w), N, C, N, 0, nat.stream_handle(w.device)), 'pack')
 y = torch.empty(B, H, W, N, device='cuda')
 names = {31: 'warm-up', 0: 'full', 1: 'no input transform', 2: 'no epilogue stores', 4: 'no epilogue (inverse transform + stores)', 8: 'no stage barrier',
          16: 'U operands not loaded in the loop', -31: 'none of them'}

@@ -1,21 +1,39 @@
-"""conv_wino_vp (cfg 18) against conv_wino<2,4> (bit for bit) and fp32 conv2d, then timed at the C96 -> N384 shape."""
+"""conv_wino_vp (the experimental persistent V-shared kernel, scratch/diag/conv_wino_vp.hip) against conv_wino<2,4> (bit for bit) and fp32 conv2d, then timed at the C96 -> N384 shape."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
 import torch, torch.nn.functional as F
-from squeezedet_pytorch_amd import ops, tiles
+from squeezedet_pytorch_amd import ops, tiles, _native as nat
+_lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libvpdiag.so'))      # scratch/diag/vp_diag.sh
+_vp = _lib.sqd_vp_diag_0
+_vp.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 11 + [ctypes.c_void_p]; _vp.restype = ctypes.c_int
+
+class VpPlan:
+    """Weights packed Npad = N wide for the experimental persistent kernel."""
+    def __init__(self, w, b):
+        N, C = w.shape[0], w.shape[1]
+        self.N, self.C, self.Npad, self.bias = N, C, N, b.contiguous()
+        self.w = torch.empty(C // 8, 16, N, 8, device=w.device)
+        nat.check(nat.lib().sqd_pack_wino_weight(nat.ptr(w.contiguous()), nat.ptr(self.w), N, C, N, 0, nat.stream_handle(w.device)), 'pack')
+
+def conv_vp(x, xo, plan, y, yo, relu):
+    B, H, W, xp = x.shape
+    rc = _vp(nat.ptr(x), nat.ptr(plan.w), nat.ptr(plan.bias), nat.ptr(y), B, H, W, plan.C, xp, xo, plan.N, plan.Npad, y.shape[3], yo, int(relu),
+             nat.stream_handle(x.device))
+    assert rc == 0, rc
 def run(C, N, B, H, W, relu, pe=0):
     torch.manual_seed(C + N + H)
     x = torch.randn(B, H, W, C + pe, device='cuda')
     w = torch.randn(N, C, 3, 3, device='cuda') * (2.0 / (9 * C)) ** 0.5
     b = torch.randn(N, device='cuda') * 0.1
     xo = pe // 2 // 4 * 4
-    p2 = ops.WinoPlan(w, b, 2); p18 = ops.WinoPlan(w, b, tiles.WINO_VP_CFG)
+    p2 = ops.WinoPlan(w, b, 2); p18 = VpPlan(w, b)
     y2 = torch.full((B, H, W, N + 8), 7.0, device='cuda'); y18 = torch.full((B, H, W, N + 8), 7.0, device='cuda')
     ops.conv_wino(x, xo, p2, y2, 4, relu=relu)
     ok = True
     for rep in range(3):
         y18.fill_(7.0)
-        ops.conv_wino(x, xo, p18, y18, 4, relu=relu)
+        conv_vp(x, xo, p18, y18, 4, relu)
         torch.cuda.synchronize()
         same = torch.equal(y2, y18)
         if not same:
@@ -48,8 +66,10 @@ for (C, N, B) in [(96, 384, 20), (128, 384, 16), (96, 384, 40), (96, 192, 20)]:
     w = torch.randn(N, C, 3, 3, device='cuda') * 0.05; b = torch.randn(N, device='cuda')
     y = torch.empty(B, 24, 78, N, device='cuda')
     line = f'C{C}->N{N} bs={B}:'
-    for cfg in (2, 0, tiles.WINO_SK_CFG, tiles.WINO_VP_CFG):
+    for cfg in (2, 0, tiles.WINO_SK_CFG):
         plan = ops.WinoPlan(w, b, cfg)
         t = timeit(lambda: ops.conv_wino(x, 0, plan, y, 0, relu=True))
         line += f'  cfg{cfg} {t:7.1f} us'
+    vplan = VpPlan(w, b)
+    line += f'  conv_wino_vp {timeit(lambda: conv_vp(x, 0, vplan, y, 0, True)):7.1f} us'
     print(line, flush=True)
