@@ -10,5 +10,6 @@ timeout -k 10 300 python bench.py --mode infer --no-cpu-baseline --inflight 1 --
 bash scratch/prof.sh $TAG _serial --inflight 1 --no-pipeline > gpurun_out/$TAG/prof_infer_serial.log 2>&1; echo "prof serial rc $?"
 bash scratch/prof.sh $TAG "" > gpurun_out/$TAG/prof_infer.log 2>&1; echo "prof rc $?"
 bash scratch/prof_train.sh $TAG > gpurun_out/$TAG/prof_train.log 2>&1; echo "prof_train rc $?"
+SQD_BENCH_ARGS="--gpus 1 --force-dist" bash scratch/prof_train.sh $TAG _dist > gpurun_out/$TAG/prof_train_dist.log 2>&1; echo "prof_train_dist rc $?"
 bash scratch/traffic.sh $TAG "infer train" > gpurun_out/$TAG/traffic.log 2>&1; echo "traffic rc $?"
 tail -30 gpurun_out/$TAG/traffic.log

@@ -115,3 +115,21 @@ def test_serial_kernel_trace_reproduces_the_event_medians_of_the_bench_line():
     from squeezedet_pytorch_amd import plan
     for kernel in plan.launches_per_kernel(plan.inference_launch_plan('squeezedet', 20, (384, 1248))):
         assert kernel in dur, f'{kernel}: in the shipped plan, absent from the serial trace'
+
+
+def test_no_torch_kernel_in_a_steady_training_step_with_the_gradient_exchange():
+    """the rocprofv3 kernel trace of ``bench.py --gpus 1 --force-dist --mode train`` (the RCCL exchange in a
+    one-rank group) lists no ``at::native`` kernel that runs once per step: every torch kernel in it belongs to the set-up (far fewer
+    calls than steps).  Also without the exchange (the plain training trace)."""
+    import csv
+    tag = _latest_round_tag()
+    for name in (f'{tag}_kernel_stats_train_dist.csv', f'{tag}_kernel_stats_train.csv'):
+        rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', name))))
+        # steps in the trace: the per-step kernels of the HIP library (one launch per step) give the count
+        steps = min(int(r['Calls']) for r in rows if r['Name'].startswith(('loss_partial_kernel', 'void loss_partial_kernel', 'grad_sumsq_kernel')))
+        assert steps >= 20, (name, steps)
+        torch_kernels = [(r['Name'][:80], int(r['Calls'])) for r in rows if 'at::native' in r['Name']]
+        per_step = [(n, c) for n, c in torch_kernels if c >= steps]
+        assert not per_step, (name, per_step)
+        if 'dist' in name:
+            assert any('grad_scale_kernel' in r['Name'] for r in rows), 'the exchange\'s own element-wise kernel is missing from the trace'
