@@ -450,7 +450,7 @@ def main():
             ex.submit(st)
             while ex.pending() > 2 * len(ex._lanes) - 1:
                 ex.fetch()
-        for i in range(max(8, 3 * len(ex._host))):          # fills every staging buffer of the ring, captures every lane
+        for i in range(max(60, args.warmup, 3 * len(ex._host))):          # fills every staging buffer of the ring, captures every lane, warms the clocks
             one(fill=i < len(ex._host))
         last = ex.drain()[-1][1]
         barrier()
@@ -515,7 +515,7 @@ def main():
         cfg.batch_size, cfg.num_workers, cfg.print_interval = B, min(8, max(1, (os.cpu_count() or 2) // 2)), 1 << 30
         try:
             with contextlib.redirect_stdout(io.StringIO()):
-                det.detect_dataset(InMemory(4 * B))                       # warm: captures the lanes at this batch size
+                det.detect_dataset(InMemory(40 * B))                      # warm: captures the lanes at this batch size, clocks up
                 barrier()
                 t0 = time.perf_counter()
                 res = det.detect_dataset(InMemory(nb * B))
@@ -567,7 +567,9 @@ def main():
                     for _t, last in ex.drain():
                         pass
                     return last
-                run_lanes(3 * args.inflight + 2)                       # eager first use, capture, a few replays per lane
+                # eager first use, capture, then enough replays to bring the clocks back up: building the executor probes the streams'
+                # hardware queues with idle kernels (tens of ms of a nearly idle GPU), and the first ~10 ms after idle run at a lower clock
+                run_lanes(max(args.warmup, 3 * args.inflight + 2, 60))
                 barrier()
                 t0 = time.perf_counter()
                 last = run_lanes(args.steps)

@@ -164,6 +164,7 @@ class _Lane:
         self.consumed = torch.cuda.Event()
         self.consumed.record(self.comp)
         self.last_copied = None      # event of the latest result copy out of this lane's packed buffer
+        self.pool = None             # memory pool shared by this lane's captured graphs
         self.uses = 0
 
 
@@ -182,6 +183,7 @@ class DetectStream:
         if lanes < 1:
             raise ValueError('DetectStream: lanes must be >= 1')
         self.graph = bool(graph)
+        self.max_ragged_graphs_per_lane = 1    # captured shapes per lane besides the full batch size
         self.degraded = False
         self.captures = 0
         self.eager_batches = 0
@@ -418,8 +420,13 @@ class DetectStream:
         lane.seen[key] = seen + 1
         g = lane.graphs.get(key)
         if g is None and self.graph and seen >= 1:
-            g = self._capture(lane, compute)
-            lane.graphs[key] = g
+            # every captured shape keeps a memory pool of its own (~0.6-1 GB of activations at bs=20): the full batch size is always
+            # captured, of other (ragged) shapes only the first one a lane sees twice -- a stream of many different ragged batch sizes
+            # stays on eager launches
+            others = sum(1 for k2, v in lane.graphs.items() if v != 'eager' and k2[1] != self.cap)
+            if key[1] == self.cap or others < self.max_ragged_graphs_per_lane:
+                g = self._capture(lane, compute)
+                lane.graphs[key] = g
         with torch.cuda.stream(lane.comp):
             if g is not None and g != 'eager':
                 g.replay()
@@ -458,7 +465,11 @@ class DetectStream:
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             # thread_local: loader threads, a collective library's watchdog ... may touch the runtime while this thread captures
-            with torch.cuda.graph(g, stream=lane.comp, capture_error_mode='thread_local'):
+            if lane.pool is None:
+                lane.pool = torch.cuda.graph_pool_handle()
+            # one memory pool per LANE: its graphs never run concurrently (one stream) and keep nothing alive between replays (the result
+            # buffers live outside), so a second shape or a second input tensor reuses the first graph's activation memory
+            with torch.cuda.graph(g, stream=lane.comp, pool=lane.pool, capture_error_mode='thread_local'):
                 with torch.no_grad():
                     compute()
             self.captures += 1
