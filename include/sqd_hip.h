@@ -75,6 +75,13 @@ int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_oihw, float*
  * always runs 1). */
 int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw, float* db, int B, int H, int W,
                         int N, int dy_pitch, int dy_coff, int C, int x_pitch, int x_coff, int S, int tc, void* stream);
+/* The slabs of up to 6 such layers that share B, H, W (the expand3x3 layers of one backward stage: the runs of Fire modules between two
+ * pools, src/model/squeezedet.py:33-49) in ONE launch, every layer cut into the same S splits: S then only has to fill the chip once over
+ * ALL the layers, which divides the slab bytes and the per-workgroup epilogues by the number of layers.  layers = host array of n records of
+ * 9 int64 {dy, x, slab (device pointers), N, dy_pitch, dy_coff, C, x_pitch, x_coff}; slab i holds S * (N_i*9*C_i + N_i) floats.  Every
+ * layer needs N % 64 == 0 and must select tile form tc (tc = 1: C < 32 or C % 32 == 16; tc = 2 otherwise); SQD_ERR_UNSUPPORTED otherwise.
+ * Bitwise the slabs of n sqd_conv_wgrad_wino(dw = NULL) calls with the same S and tc. */
+int sqd_conv_wgrad_wino_group(const long long* layers, int n, int B, int H, int W, int S, int tc, void* stream);
 
 /* dw == NULL in sqd_conv_wgrad: write the S partial slabs only; the caller then reduces many layers with ONE launch:
  * descs_dev = device array of n records of 9 int64 {slab offset, dw offset, db offset (floats from slab_base / grad_base;

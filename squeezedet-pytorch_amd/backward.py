@@ -24,9 +24,14 @@ def _wgrad_layout(base, saved, B, H, W):
         slots[n] = (off, tuple(p.shape)); off += p.numel()
     layers = layer_table(base.arch)
     entries = []
+    # expand3x3 weight gradients that share a launch: the Fire modules between two pools (same grid), same tile form
+    e3s = [(f'features.{i}.expand3x3', layers[i][4], layers[i][2]) + tuple(saved[f'fire{i}'][2].shape[:3])
+           for i in range(len(layers) - 1, 1, -1) if layers[i][0] == 'fire']
+    groups = ops.wino_wgrad_groups(e3s, enabled=getattr(base, 'group_wgrad', None))
 
     def add(pre, N, C, taps, shp, fused=False):
-        entries.append((pre, N, C, taps, shp[0], shp[1], shp[2], slots[pre + '.weight'][0], slots[pre + '.bias'][0], fused))
+        entries.append((pre, N, C, taps, shp[0], shp[1], shp[2], slots[pre + '.weight'][0], slots[pre + '.bias'][0], fused,
+                        groups.get(pre) if taps == 9 else None))
     add('convdet', base.convdet.out_channels, base.convdet.in_channels, 9, (B, H, W))
     for i in range(len(layers) - 1, 1, -1):
         if layers[i][0] != 'fire':
@@ -49,7 +54,7 @@ def run_backbone_backward(base, saved, dpred):
     cd = base.convdet
     a_in = saved['convdet_in']
     cin_cd = a_in.shape[3]
-    shape_key = (B, H, W, bool(getattr(base, 'fuse_squeeze_bwd', False))) + tuple(tuple(saved[f'fire{i}'][2].shape) for i in range(len(layers)) if layers[i][0] == 'fire')
+    shape_key = (B, H, W, bool(getattr(base, 'fuse_squeeze_bwd', False)), getattr(base, 'group_wgrad', None)) + tuple(tuple(saved[f'fire{i}'][2].shape) for i in range(len(layers)) if layers[i][0] == 'fire')
     wb, slots, total = base.wgrad_batch(lambda: _wgrad_layout(base, saved, B, H, W), shape_key)
     # + 1: the data-parallel exchange carries this rank's image count through the same all-reduce (trainer.GradientExchange)
     grad_buf = torch.empty(total + 1, device=dpred.device, dtype=torch.float32)
@@ -62,6 +67,7 @@ def run_backbone_backward(base, saved, dpred):
     # contiguous range, later stages of the network sit at higher offsets) is handed to the all-reduce; without one, all
     # slabs are reduced by a single launch at the end.
     stage = {'row': 0, 'hi': total}
+    pending = {}                                           # group id -> the members seen so far (ops.conv_wgrad_wino_group)
 
     def close_stage(first_param):
         """Everything from ``first_param`` to the previous stage's start is final once the pending slabs are reduced."""
@@ -117,7 +123,16 @@ def run_backbone_backward(base, saved, dpred):
 
         if not fused_e1:
             ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
-        ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
+        grp = wb.group_of.get(pre + 'expand3x3')
+        if grp is None:
+            ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
+        else:
+            # runs with the other expand3x3 layers of this stage, as soon as the last of them has its gradient (dA stays alive until then)
+            lst = pending.setdefault(grp[0], [])
+            lst.append((dA, e1, e3, sq, 0, s, wb.slab(pre + 'expand3x3')))
+            if len(lst) == len(grp[3]):
+                ops.conv_wgrad_wino_group(lst, grp[1], grp[2])
+                del pending[grp[0]]
         dSq = torch.empty_like(sq)
         if fused_e1:
             # narrow expand1x1 (N <= 128: the first four Fires): weight-gradient slabs and the data gradient from ONE pass over the
@@ -148,6 +163,7 @@ def run_backbone_backward(base, saved, dpred):
     if sync is not None:
         lo0 = slots['features.0.weight'][0]
         sync.scale_slice(lo0, lo0 + stem.weight.numel() + stem.bias.numel())      # the stem's gradient does not pass through the slab reduction
+    assert not pending, 'a weight-gradient group was left incomplete'
     if sync is None:
         wb.reduce(grad_flat)                               # all 31 Fire / ConvDet slab reductions: one launch
     else:

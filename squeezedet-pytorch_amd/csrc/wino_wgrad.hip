@@ -61,8 +61,10 @@ extern "C" int sqd_ww_set_debug(unsigned long long* p) {
 // was measured neutral (profiles/r04u_ww_occupancy3.log); an eight-wave form (two positions per wave, half the accumulators, FOUR waves per
 // SIMD at 126 registers for the 64 x 16 tile) was 5-8 % SLOWER than this kernel and spills for the wider tiles
 // (profiles/r04_wino_wgrad_eight_waves.log; the code is in the history at commit 'Final evidence set r04z'): more waves do not help.
+// The body serves two launch forms: one layer per launch (wino_wgrad_kernel) and several layers of one backward stage in ONE launch
+// (wino_wgrad_group_kernel below).  ``pos`` is the workgroup's position among the layer's ``nwg`` workgroups (XCD-contiguous order).
 template <int TN, int TC>
-__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
+__device__ __forceinline__ void ww_body(const WwArgs& a, const int pos, const int nwg) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(TN >= 4 && (TC == 1 || TC == 2), "the bank swizzle swaps 16-channel blocks pairwise inside the first four");
   constexpr int CHD = TN * 16, CHX = TC * 16;
@@ -80,18 +82,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
   // Which (split, channel-block pair) this workgroup owns.  All block pairs of ONE split read the same pixel groups (the dY tile is
   // re-read by every input-channel block, the X patch by every output-channel block), so they should share an XCD's L2: positions are
   // split-major and the workgroups of an XCD own a contiguous run of positions (sqd_xcd_contiguous) -- each pixel group then
-  // crosses the fabric into one L2 instead of into several, and the re-reads come back at L2-hit latency.  SQD_WW_XCD=0: the old
-  // block-pair-major order (A/B builds).
-#ifndef SQD_WW_XCD
-#define SQD_WW_XCD 1
-#endif
-#if SQD_WW_XCD
-  const int ntile = (int)gridDim.x / a.S;
-  const int pos = sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  // crosses the fabric into one L2 instead of into several, and the re-reads come back at L2-hit latency.
+  const int ntile = nwg / a.S;
   const int s = pos / ntile, bg = pos - s * ntile;
-#else
-  const int s = (int)blockIdx.x % a.S, bg = (int)blockIdx.x / a.S;
-#endif
   const int ng = bg / a.ncg, cg = bg - ng * a.ncg;
   const int n0 = ng * CHD, c0 = cg * CHX;
 
@@ -346,18 +339,61 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
 }
 
 template <int TN, int TC>
+__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  ww_body<TN, TC>(a, sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x), (int)gridDim.x);
+#endif
+}
+
+// Several layers of one backward stage (same B, H, W and tile form) in ONE launch: every layer gets the same number of splits S, so all
+// workgroups do the same work, and S is what fills the chip once over ALL the layers -- a fraction of what each layer would need alone.
+// A workgroup's K loop gets that much longer (the epilogue -- LDS exchange + 36-73 KB of slab stores -- is 8-16 % of a wave's time at ~10
+// groups per workgroup, profiles/r04t_ww_stamp.log) and the slab bytes shrink by the same factor.  Layers are contiguous runs of
+// positions, so an XCD still works on one or two layers' pixel groups at a time.
+#define WW_MAX_GROUP 6
+struct WwGroupArgs { WwArgs l[WW_MAX_GROUP]; int wg0[WW_MAX_GROUP + 1]; int n; };
+
+template <int TN, int TC>
+__global__ __launch_bounds__(256, 2) void wino_wgrad_group_kernel(WwGroupArgs ga) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int pos = sqd_xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < WW_MAX_GROUP; ++k) i = (k < ga.n && pos >= ga.wg0[k]) ? k : i;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const WwArgs a = ga.l[i];
+  ww_body<TN, TC>(a, pos - ga.wg0[i], ga.wg0[i + 1] - ga.wg0[i]);
+#endif
+}
+
+template <int TN, int TC>
+static int launch_wino_wgrad_group(WwGroupArgs& ga, int S, hipStream_t stream) {
+  constexpr int DSLOTS = 64 * TN * 4, XSLOTS = (108 * TC * 4 + 255) / 256 * 256;
+  constexpr size_t lds = (size_t)2 * (DSLOTS + XSLOTS) * 16;
+  auto kern = wino_wgrad_group_kernel<TN, TC>;
+  static SqdDevOnce once;
+  if (lds > 64 * 1024 && sqd_max_lds_once(once, (const void*)kern, (int)lds) != SQD_OK) return SQD_ERR_LAUNCH;
+  int wg = 0;
+  for (int i = 0; i < ga.n; ++i) {
+    WwArgs& a = ga.l[i];
+    a.S = S; a.ncg = sqd_cdiv(a.C, TC * 16);
+    ga.wg0[i] = wg;
+    wg += sqd_cdiv(a.N, TN * 16) * a.ncg * S;
+  }
+  for (int i = ga.n; i <= WW_MAX_GROUP; ++i) ga.wg0[i] = wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wg), dim3(256), lds, stream, ga);
+  return sqd_launch_status();
+}
+
+template <int TN, int TC>
 static int launch_wino_wgrad(WwArgs a, hipStream_t stream) {
   constexpr int DSLOTS = 64 * TN * 4, XSLOTS = (108 * TC * 4 + 255) / 256 * 256;
   constexpr size_t lds = (size_t)2 * (DSLOTS + XSLOTS) * 16;
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   static_assert((size_t)(4 * 3 * TC + 1) * 64 * 16 <= lds, "epilogue exchange fits the staging buffers");
   auto kern = wino_wgrad_kernel<TN, TC>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static SqdDevOnce once;
+  if (lds > 64 * 1024 && sqd_max_lds_once(once, (const void*)kern, (int)lds) != SQD_OK) return SQD_ERR_LAUNCH;
   a.ncg = sqd_cdiv(a.C, TC * 16);
   const int groups = sqd_cdiv(a.N, TN * 16) * a.ncg;
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * a.S)), dim3(256), lds, stream, a);
@@ -389,3 +425,33 @@ extern "C" int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab,
   return sqd_wgrad_reduce_launch(slab, dw, db, S, a.slab_stride, N, C, 9, stream);
 }
 
+
+// Winograd weight-gradient slabs of up to WW_MAX_GROUP 3x3 layers that share B, H, W (one backward stage) in ONE launch; every layer is
+// cut into the same S splits.  ``layers``: n records of 9 64-bit words {dy, x, slab, N, dy_pitch, dy_coff, C, x_pitch, x_coff} (pointers
+// and element counts; host memory).  All layers must select the same tile form: N % 64 == 0 for all of them, and C < 32 or C % 32 == 16
+// for all (tc = 1) or for none (tc = 2).  Slabs only (the caller reduces them: sqd_wgrad_reduce_batched).
+extern "C" int sqd_conv_wgrad_wino_group(const long long* layers, int n, int B, int H, int W, int S, int tc, void* stream) {
+  SQD_CHECK_ARG(layers && n >= 1 && n <= WW_MAX_GROUP && B > 0 && H > 0 && W > 0 && S > 0 && S <= 65535 && (tc == 1 || tc == 2));
+  WwGroupArgs ga;
+  ga.n = n;
+  const long long px = (long long)B * H * W;
+  for (int i = 0; i < n; ++i) {
+    const long long* r = layers + 9 * i;
+    WwArgs& a = ga.l[i];
+    a.dy = (const float*)(uintptr_t)r[0]; a.x = (const float*)(uintptr_t)r[1]; a.slab = (float*)(uintptr_t)r[2];
+    a.N = (int)r[3]; a.dy_pitch = (int)r[4]; a.dy_coff = (int)r[5]; a.C = (int)r[6]; a.x_pitch = (int)r[7]; a.x_coff = (int)r[8];
+    a.B = B; a.H = H; a.W = W;
+    SQD_CHECK_ARG(a.dy && a.x && a.slab && a.N > 0 && a.C > 0);
+    SQD_CHECK_ARG((a.N & 3) == 0 && (a.C & 3) == 0 && (a.dy_pitch & 3) == 0 && (a.dy_coff & 3) == 0 && (a.x_pitch & 3) == 0 && (a.x_coff & 3) == 0);
+    SQD_CHECK_ARG(a.dy_coff + a.N <= a.dy_pitch && a.x_coff + a.C <= a.x_pitch);
+    SQD_CHECK_ARG(((uintptr_t)a.dy & 15) == 0 && ((uintptr_t)a.x & 15) == 0);
+    a.gxn = sqd_cdiv(W, 16); a.gyn = sqd_cdiv(H, 4); a.ngroups = B * a.gxn * a.gyn;
+    a.slab_stride = (long long)a.N * 9 * a.C + a.N;
+    if (a.N % 64 || S > a.ngroups) return SQD_ERR_UNSUPPORTED;
+    if ((tc == 2) != !(a.C < 32 || a.C % 32 == 16)) return SQD_ERR_UNSUPPORTED;      // every layer must want this tile form
+    if (px * a.dy_pitch * 4 >= (3ll << 30) || px * a.x_pitch * 4 >= (3ll << 30)) return SQD_ERR_UNSUPPORTED;
+  }
+  for (int i = n; i < WW_MAX_GROUP; ++i) ga.l[i] = ga.l[0];
+  hipStream_t s = (hipStream_t)stream;
+  return tc == 1 ? launch_wino_wgrad_group<4, 1>(ga, S, s) : launch_wino_wgrad_group<4, 2>(ga, S, s);
+}

@@ -160,6 +160,7 @@ class SqueezeDetBase(nn.Module):
         self._drop = None                   # (torch.initial_seed() it was derived from, ops.DropState)
         self._drop_restored = False         # the stream came from set_dropout_rng (a checkpoint), not from torch's seed
         self.fuse_squeeze_bwd = os.environ.get('SQD_FUSE_SQUEEZE_BWD', '1')[:1] != '0'     # backward: squeeze wgrad + dgrad in one launch
+        self.group_wgrad = ops.WINO_WGRAD_GROUP   # backward: the expand3x3 weight gradients of a stage share one launch (ops.conv_wgrad_wino_group)
         self.init_weights()
 
     # ---- reference: init_weights, src/model/squeezedet.py:89-97 ----

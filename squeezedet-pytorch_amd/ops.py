@@ -11,6 +11,7 @@ writing ``ops.choose_cfg`` / ``ops.ConvPlan`` / ``ops.KernelTimer``.
 """
 from __future__ import annotations
 
+import ctypes
 import torch
 
 from . import _native as nat
@@ -711,6 +712,36 @@ def conv_wgrad(dy, dy_coff, N, x, x_coff, C, taps, slab=None, wino=None):
     if br is not None:
         br.done()
     return None if deferred else (dw, db)
+
+
+def conv_wgrad_wino_group(items, S, tc):
+    """The Winograd weight-gradient slabs of several 3x3 layers of one backward stage in ONE launch (``tiles.wino_wgrad_groups``
+    decides which).  ``items``: [(dy, dy_coff, N, x, x_coff, C, slab)] with dy / x NHWC on the same [B,H,W] grid; ``slab`` = the layer's
+    ``WgradBatch`` view of S * (N*9*C + N) floats.  Every layer is cut into the same ``S`` splits; slabs only (the batched reduction
+    follows)."""
+    if not 1 <= len(items) <= WINO_WGRAD_GROUP_MAX:
+        raise ValueError('grouped weight gradient: 1..%d layers' % WINO_WGRAD_GROUP_MAX)
+    B, H, W = items[0][0].shape[:3]
+    rows, flops, byts, tag = [], 0.0, 0.0, []
+    for dy, dy_coff, N, x, x_coff, C, slab in items:
+        _check_nhwc(dy, 'dy'); _check_nhwc(x, 'x')
+        if tuple(dy.shape[:3]) != (B, H, W) or tuple(x.shape[:3]) != (B, H, W):
+            raise ValueError('grouped weight gradient: the layers of a group share B,H,W')
+        if dy_coff + N > dy.shape[3] or x_coff + C > x.shape[3] or N % 64 or C % 4 or _wino_wgrad_tc(N, C) != tc:
+            raise ValueError('grouped weight gradient: channel window out of range / wrong tile form')
+        if slab.numel() != S * (N * 9 * C + N) or not slab.is_contiguous() or slab.dtype != torch.float32:
+            raise ValueError('grouped weight gradient: slab workspace does not match the layer')
+        rows += [dy.data_ptr(), x.data_ptr(), slab.data_ptr(), N, dy.shape[3], dy_coff, C, x.shape[3], x_coff]
+        flops += 2.0 * B * H * W * N * C * 4
+        byts += 4.0 * (B * H * W * (C + N) + 2 * S * (N * 9 * C + N))
+        tag.append(f'C{C} N{N}')
+    table = (ctypes.c_longlong * len(rows))(*rows)
+    br = _Bracket('conv_wgrad_wino_group', f'wgrad 9tap {" + ".join(tag)} {H}x{W}', flops, byts) if timing._timer is not None else None
+    rc = nat.lib().sqd_conv_wgrad_wino_group(ctypes.cast(table, ctypes.c_void_p), len(items), B, H, W, int(S), int(tc),
+                                             nat.stream_handle(items[0][0].device))
+    nat.check(rc, 'sqd_conv_wgrad_wino_group')
+    if br is not None:
+        br.done()
 
 
 def squeeze_bwd_ok(N, C):

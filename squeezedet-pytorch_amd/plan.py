@@ -115,7 +115,7 @@ def _wgrad(batch, H, W, N, C, taps):
 
 def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), anchors_per_grid=9, num_classes=3,
                          use_winograd=True, data_parallel_stages=False, fuse_squeeze_bwd=True, dropout=True,
-                         fused_dropout=True, fuse_train_forward=True, fuse_fire_bridge=True, fuse_stem_squeeze=True):
+                         fused_dropout=True, fuse_train_forward=True, fuse_fire_bridge=True, fuse_stem_squeeze=True, group_wgrad=None):
     """Launches of one training iteration's forward (activations saved; ``fuse_train_forward``: the stem + squeeze launch and the
     two small-C bridges run in their STORING forms -- what the backward reads is written by the fused launch -- where the table has
     their rows; the other inference-only fusions stay off), multi-task loss forward / backward and the backbone backward, as
@@ -210,6 +210,10 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
         plan.append(_conv3x3(batch, H, W, ncd, ccd, use_winograd))                   # ConvDet data gradient
     rows_total, rows_done = 1, 0                       # slab-reduction records: ConvDet, then 3 per Fire in backward order
     last = len(layers) - 1
+    # expand3x3 weight gradients that share a launch (``group_wgrad`` = ``SqueezeDetBase.group_wgrad``): issued when the last member is reached
+    groups = ops.wino_wgrad_groups([(i, layers[i][4], layers[i][2], batch, geo[i][0], geo[i][1]) for i in range(last, 1, -1)
+                                    if layers[i][0] == 'fire'], enabled=group_wgrad)
+    pending = {}
     for i in range(last, 1, -1):
         l = layers[i]
         Hi, Wi, Ci = geo[i] if i in geo else (None, None, None)
@@ -225,7 +229,13 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
         fused_e1 = fuse_squeeze_bwd and ops.squeeze_bwd_ok(e1, s)
         if not fused_e1:
             plan.append(_wgrad(batch, Hi, Wi, e1, s, 1))
-        plan.append(_wgrad(batch, Hi, Wi, e3, s, 9))
+        if i in groups:
+            gid, _S, _tc, members = groups[i]
+            pending.setdefault(gid, []).append(f'C{s} N{e3}')
+            if len(pending[gid]) == len(members):
+                plan.append(('conv_wgrad_wino_group', f'wgrad 9tap {" + ".join(pending.pop(gid))} {Hi}x{Wi}'))
+        else:
+            plan.append(_wgrad(batch, Hi, Wi, e3, s, 9))
         if fused_e1:
             plan.append(('squeeze_bwd', f'sqbwd C{s} N{e1} {Hi}x{Wi}'))                # expand1x1 weight + data gradient, one launch
         else:

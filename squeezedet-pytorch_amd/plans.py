@@ -395,17 +395,21 @@ _WGR_OUT = 64               # outputs per workgroup of the slab-reduction kernel
 
 class WgradBatch:
     """Workspace + descriptor table for reducing the partial slabs of many conv weight gradients with ONE launch into a
-    flat gradient buffer.  ``entries``: [(key, N, C, taps, B, H, W, dw_offset, db_offset)] (offsets in floats into the flat
-    buffer).  Slab workspace and table are allocated once and reused every step (pointer-stable)."""
+    flat gradient buffer.  ``entries``: [(key, N, C, taps, B, H, W, dw_offset, db_offset[, fused[, group]])] (offsets in floats into the
+    flat buffer; ``fused``: slabs written by ``ops.squeeze_bwd``; ``group``: a ``tiles.wino_wgrad_groups`` value).  Slab workspace and table are allocated once and reused every step (pointer-stable)."""
 
     def __init__(self, entries, device):
         rows, self.slabs, off, blk = [], {}, 0, 0
         self.row_blocks = [0]                  # first workgroup of every record (+ the total at the end)
-        self.fused = {}
+        self.fused, self.group_of, self.splits = {}, {}, {}
         for key, N, C, taps, B, H, W, dw_off, db_off, *flags in entries:
             fused = bool(flags and flags[0])       # the layer's slabs come from ops.squeeze_bwd (its own split)
             self.fused[key] = fused
-            S, stride = wgrad_split(N, C, taps, B, H, W, fused_dgrad=fused)
+            grp = flags[1] if len(flags) > 1 else None      # (group id, S, tc, member keys): the layer runs in a grouped launch
+            if grp is not None:
+                self.group_of[key] = grp
+            S, stride = wgrad_split(N, C, taps, B, H, W, fused_dgrad=fused, group_S=None if grp is None else grp[1])
+            self.splits[key] = S
             rows.append([off, dw_off, db_off, S, stride, N, C, taps, blk])
             self.slabs[key] = (off, S * stride)
             off += S * stride

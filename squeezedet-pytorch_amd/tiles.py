@@ -333,17 +333,66 @@ def _wino_wgrad_tc(N, C):
     return 1 if (C % 32 == 16 or C < 32) else 2
 
 
+import os as _os
+WINO_WGRAD_GROUP = _os.environ.get('SQD_WW_GROUP', '1')[:1] != '0'   # the expand3x3 weight gradients of one backward stage share a launch
+                                                                     # (ops.conv_wgrad_wino_group; env: A/B runs)
+WINO_WGRAD_GROUP_MAX = 6   # csrc/wino_wgrad.hip WW_MAX_GROUP
+
+
+def wino_wgrad_blocks(N, C):
+    """(out-channel, in-channel) blocks of dU a Winograd weight-gradient launch cuts a layer into (64 x 16|32; N <= 80: all of N x 16)."""
+    tc = _wino_wgrad_tc(N, C)
+    return -(-C // (16 * tc)) if N % 64 else (N // 64) * -(-C // (16 * tc))
+
+
+def wino_wgrad_groups(layers, wino=None, enabled=None):
+    """Which 3x3 weight gradients share a launch.  ``layers``: [(key, N, C, B, H, W)] in launch (backward) order.  Returns
+    {key: (group id, S, tc, member keys)} for the layers that run grouped: Winograd form, N % 64 == 0, same pixel grid, same tile form, at
+    least two of them (at most WINO_WGRAD_GROUP_MAX per launch).  S = the splits EVERY member is cut into: one resident round of
+    workgroups over the whole group (or the measured row 'GW:tc:blocks:npix' of the table)."""
+    if not (WINO_WGRAD_GROUP if enabled is None else enabled):
+        return {}
+    buckets = {}
+    for key, N, C, B, H, W in layers:
+        if wgrad_uses_wino(N, C, 9, B, H, W, wino) and N % 64 == 0:
+            buckets.setdefault((B, H, W, _wino_wgrad_tc(N, C)), []).append((key, N, C))
+    out, gid = {}, 0
+    for (B, H, W, tc), members in buckets.items():
+        for lo in range(0, len(members), WINO_WGRAD_GROUP_MAX):
+            part = members[lo:lo + WINO_WGRAD_GROUP_MAX]
+            if len(part) < 2:
+                continue
+            blocks = sum(wino_wgrad_blocks(N, C) for _k, N, C in part)
+            ngroups = B * -(-H // 4) * -(-W // 16)
+            import os
+            tw = int(os.environ.get('SQD_WW_TARGET', _TARGET_WGS_WINO))
+            S = max(1, min(ngroups, tw // blocks if blocks <= tw else 1))
+            tuned = _tuning().get(f'GW:{tc}:{blocks}:{B * H * W}')
+            if tuned is not None and tuned >= 1:
+                S = max(1, min(ngroups, int(tuned)))
+            keys = tuple(k for k, _n, _c in part)
+            for k in keys:
+                out[k] = (gid, S, tc, keys)
+            gid += 1
+    return out
+
+
 def _wgrad_wide():
     import os
     return os.environ.get('SQD_WGRAD_WIDE', '1')[:1] != '0'
 
 
-def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False):
+def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False, group_S=None):
     """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab.
+    ``group_S``: the layer runs inside a grouped launch (``wino_wgrad_groups``) with that many splits.
     ``fused_dgrad``: the layer runs ``ops.squeeze_bwd`` (weight + data gradient in one launch: all N in one group, 64-channel in-tiles).
     S comes from the workgroup targets below unless the measured table has a row 'G:taps:N:C:npix' (tools/tune_insitu.py --mode
     train: the split of each layer tried inside the training step)."""
     tuned = _tuning().get(f'G:{taps}:{N}:{C}:{B * H * W}')
+    if group_S is not None:
+        if not wgrad_uses_wino(N, C, taps, B, H, W, wino):
+            raise ValueError('grouped weight gradient: Winograd 3x3 layers only')
+        return int(group_S), N * taps * C + N
     if wgrad_uses_wino(N, C, taps, B, H, W, wino):
         ngroups = B * -(-H // 4) * -(-W // 16)                    # 4x16-pixel groups = the K axis of the 16 position GEMMs
         # (out-channel, in-channel) blocks of dU per workgroup: 64 x 16|32, or all of N <= 80 x 16 (ConvDet)
