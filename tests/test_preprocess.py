@@ -72,6 +72,43 @@ def test_gpu_preprocess_vs_oracle(sizes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sizes,target", [
+    ([(33, 3001), (1, 1), (7, 1), (1, 9)], (384, 1248)),        # odd byte offsets, one-pixel sources, the packed buffer ends inside a dword
+    ([(40, 3000), (3, 2731)], (64, 96)),                          # a row segment larger than the LDS staging buffer: direct path
+    ([(40, 2728), (41, 2729)], (64, 96)),                         # ... and just inside it
+    ([(375, 1242)] * 3, (384, 1248)),
+    ([(97, 300), (13, 1023)], (61, 517)),                         # target not a multiple of the 4-row / 256-column workgroup tile
+])
+def test_gpu_preprocess_staged_rows_vs_oracle(sizes, target):
+    """The resize kernel stages each workgroup's two source-row segments in LDS (aligned dwords; the tail of the packed buffer
+    byte by byte) and whitens through a per-channel table: same values as the oracle's per-pixel arithmetic at every alignment."""
+    from squeezedet_pytorch_amd.preprocess import preprocess_batch
+    rs = np.random.RandomState(5)
+    images = [rs.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    out, scales, _meta = preprocess_batch(images, target)
+    for b, im in enumerate(images):
+        ref, sc = oracle.preprocess_image(im, target)
+        np.testing.assert_allclose(out[b].cpu().numpy(), ref, atol=2e-5, rtol=0)
+        np.testing.assert_allclose(scales[b].cpu().numpy(), sc, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,target", [
+    ([(1, 1), (400, 1300), (383, 1249), (5, 2000), (390, 7)], (384, 1248)),
+    ([(61, 517), (60, 516), (62, 519), (3, 3)], (61, 517)),
+])
+def test_gpu_padcrop_staged_rows_bit_exact_vs_oracle(sizes, target):
+    from squeezedet_pytorch_amd.preprocess import preprocess_batch
+    rs = np.random.RandomState(6)
+    images = [rs.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    out, _shifts, meta = preprocess_batch(images, target, forbid_resize=True)
+    for b, im in enumerate(images):
+        ref, pad, crop = oracle.crop_or_pad_image(im, target, oracle.KITTI_RGB_MEAN, oracle.KITTI_RGB_STD)
+        assert np.array_equal(out[b].cpu().numpy(), ref), b
+        assert meta['padding'][b].tolist() == list(pad) and meta['crops'][b].tolist() == list(crop)
+
+
+@pytest.mark.gpu
 def test_detect_images_end_to_end():
     """uint8 images -> GPU preprocess -> backbone -> fused detect, vs the oracle fed with the oracle's own
     pre-processed tensor (same kept anchors away from near-ties; boxes in original-image coordinates)."""
