@@ -12,8 +12,14 @@ sizes = torch.tensor([[H0, W0]] * B, dtype=torch.int32).cuda()
 out = torch.empty(B, 3, H, W, device='cuda'); sc = torch.empty(B, 2, device='cuda')
 mean = (ctypes.c_float * 3)(93.877, 98.801, 95.923); std = (ctypes.c_float * 3)(78.782, 80.130, 81.200)
 st = nat.stream_handle(out.device)
-def resize(): nat.check(nat.lib().sqd_preprocess_u8_fwd(nat.ptr(src), nat.ptr(off), nat.ptr(sizes), nat.ptr(out), nat.ptr(sc), mean, std, B, H, W, st), 'pre')
-def padcrop(): nat.check(nat.lib().sqd_preprocess_u8_padcrop_fwd(nat.ptr(src), nat.ptr(off), nat.ptr(sizes), nat.ptr(out), nat.ptr(sc), None, mean, std, B, H, W, st), 'pc')
+import os
+LIB = nat.lib()
+if os.environ.get('PRE_LIB'):            # A/B: the round-4 kernels built alone (scratch/libpre_r04.so)
+    LIB = ctypes.CDLL(os.environ['PRE_LIB'])
+    for f in ('sqd_preprocess_u8_fwd', 'sqd_preprocess_u8_padcrop_fwd'):
+        getattr(LIB, f).argtypes = getattr(nat.lib(), f).argtypes; getattr(LIB, f).restype = ctypes.c_int
+def resize(): nat.check(LIB.sqd_preprocess_u8_fwd(nat.ptr(src), nat.ptr(off), nat.ptr(sizes), nat.ptr(out), nat.ptr(sc), mean, std, B, H, W, st), 'pre')
+def padcrop(): nat.check(LIB.sqd_preprocess_u8_padcrop_fwd(nat.ptr(src), nat.ptr(off), nat.ptr(sizes), nat.ptr(out), nat.ptr(sc), None, mean, std, B, H, W, st), 'pc')
 for name, fn in (('resize', resize), ('padcrop', padcrop)):
     for _ in range(20): fn()
     torch.cuda.synchronize()
