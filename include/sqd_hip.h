@@ -86,7 +86,8 @@ int sqd_conv_wgrad_wino_group(const long long* layers, int n, int B, int H, int 
 /* dw == NULL in sqd_conv_wgrad: write the S partial slabs only; the caller then reduces many layers with ONE launch:
  * descs_dev = device array of n records of 9 int64 {slab offset, dw offset, db offset (floats from slab_base / grad_base;
  * db offset < 0: no bias gradient), S, slab stride (= N*taps*C + N), N, C, taps, first workgroup of the record}
- * (a record takes ceil((N*taps*C + N) / 64) workgroups; total_blocks = their sum).  Results are bitwise those of the
+ * (a record takes ceil((N*taps*C + N) / 64) workgroups; total_blocks = their sum; slab_base 16-byte aligned, slab offsets and strides
+ * multiples of 4 floats -- they are, with the N % 4 == 0, C % 4 == 0 the slab writers require).  Results are bitwise those of the
  * per-layer reduction, times `scale` (1 = exactly the sum; the data-parallel exchange passes the rank's image count: the
  * weighting of src/utils/data_parallel.py's gathered loss mean, src/engine/trainer.py:43). */
 int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base, float scale,

@@ -555,10 +555,15 @@ extern "C" int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_o
 // table is the same every step.  Same arithmetic and order as wgrad_reduce_kernel (bitwise identical results).
 struct WgrDesc { long long slab_off, dw_off, db_off, S, slab_stride, N, C, TAPS, block_begin; };
 
-__global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_batched_kernel(const WgrDesc* __restrict__ descs, int n,
-                                                                                   const float* __restrict__ slab_base,
-                                                                                   float* __restrict__ grad_base, int block_first, float scale) {
-  __shared__ float red[WGR_PARTS][WGR_OUT];
+// One wave per workgroup: 16 lanes x float4 cover the workgroup's 64 outputs, the four lane groups are the four slab partitions, so one
+// load instruction fetches 256 contiguous bytes of FOUR slab rows (1 KB per wave instruction; the scalar form moved 256 B).  Partition p
+// still sums rows p, p + 4, ... in order and the partitions are combined 0..3: bitwise the sums of wgrad_reduce_kernel.
+// (Slab offsets, strides and record sizes are multiples of 4 floats -- N % 4 == 0, C % 4 == 0 -- so a float4 is live or dead as a whole.)
+__global__ __launch_bounds__(64) void wgrad_reduce_batched_kernel(const WgrDesc* __restrict__ descs, int n,
+                                                                  const float* __restrict__ slab_base,
+                                                                  float* __restrict__ grad_base, int block_first, float scale) {
+  static_assert(WGR_OUT == 64 && WGR_PARTS == 4, "16 lanes x float4 x 4 partitions = one wave");
+  __shared__ f32x4 red[WGR_PARTS][WGR_OUT / 4];
   const long long wg = (long long)blockIdx.x + block_first;      // workgroup id in the numbering of the whole table
   int row = 0;
   while (row + 1 < n && descs[row + 1].block_begin <= wg) ++row;      // uniform (scalar loads)
@@ -566,34 +571,38 @@ __global__ __launch_bounds__(WGR_OUT * WGR_PARTS) void wgrad_reduce_batched_kern
   const float* slab = slab_base + d.slab_off;
   const int S = (int)d.S, C = (int)d.C, TAPS = (int)d.TAPS;
   const long long nw = d.N * d.TAPS * d.C;
-  const int o = threadIdx.x & (WGR_OUT - 1), part = threadIdx.x / WGR_OUT;
-  const long long idx = (wg - d.block_begin) * WGR_OUT + o;
+  const int o4 = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const long long idx = (wg - d.block_begin) * WGR_OUT + 4 * o4;
   const bool live = idx < nw + d.N;
-  float s = 0.f;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (live) {
 #pragma unroll 8
-    for (int k = part; k < S; k += WGR_PARTS) s += slab[(long long)k * d.slab_stride + idx];
+    for (int k = part; k < S; k += WGR_PARTS) s += *(const f32x4*)(slab + (long long)k * d.slab_stride + idx);
   }
-  red[part][o] = s;
+  red[part][o4] = s;
   __syncthreads();
   if (part != 0 || !live) return;
-  float t = red[0][o];
+  f32x4 t = red[0][o4];
 #pragma unroll
-  for (int p = 1; p < WGR_PARTS; ++p) t += red[p][o];
+  for (int p = 1; p < WGR_PARTS; ++p) t += red[p][o4];
   t *= scale;                                  // (1 = bitwise the plain sum; the data-parallel exchange passes this rank's image count)
-  if (idx < nw) {
-    const int c = (int)(idx % C); const long long q = idx / C;
-    const int tap = (int)(q % TAPS); const int nn = (int)(q / TAPS);
-    grad_base[d.dw_off + ((long long)nn * C + c) * TAPS + tap] = t;
-  } else if (d.db_off >= 0) {
-    grad_base[d.db_off + (idx - nw)] = t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long e = idx + i;
+    if (e < nw) {
+      const int c = (int)(e % C); const long long q = e / C;
+      const int tap = (int)(q % TAPS); const int nn = (int)(q / TAPS);
+      grad_base[d.dw_off + ((long long)nn * C + c) * TAPS + tap] = t[i];
+    } else if (d.db_off >= 0) {
+      grad_base[d.db_off + (e - nw)] = t[i];
+    }
   }
 }
 
 extern "C" int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_blocks, const float* slab_base, float* grad_base,
                                         float scale, void* stream) {
   SQD_CHECK_ARG(descs_dev && n > 0 && n <= 4096 && total_blocks > 0 && slab_base && grad_base);
-  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(WGR_OUT * WGR_PARTS), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(64), 0, (hipStream_t)stream,
                      (const WgrDesc*)descs_dev, n, slab_base, grad_base, 0, scale);
   return sqd_launch_status();
 }
@@ -604,7 +613,7 @@ extern "C" int sqd_wgrad_reduce_batched(const void* descs_dev, int n, int total_
 extern "C" int sqd_wgrad_reduce_batched_range(const void* descs_dev, int n, int block_first, int nblocks, const float* slab_base,
                                               float* grad_base, float scale, void* stream) {
   SQD_CHECK_ARG(descs_dev && n > 0 && n <= 4096 && block_first >= 0 && nblocks > 0 && slab_base && grad_base);
-  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)nblocks), dim3(WGR_OUT * WGR_PARTS), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)nblocks), dim3(64), 0, (hipStream_t)stream,
                      (const WgrDesc*)descs_dev, n, slab_base, grad_base, block_first, scale);
   return sqd_launch_status();
 }
