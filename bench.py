@@ -379,7 +379,7 @@ def main():
                     graph = torch.cuda.CUDAGraph()
                     # with a process group alive other threads of this process (the collective library's watchdog) may touch
                     # the runtime while this thread captures: only this thread's calls belong to the capture
-                    mode = {'capture_error_mode': 'thread_local'} if (dist is not None and not os.environ.get('SQD_BENCH_GLOBAL_CAPTURE')) else {}
+                    mode = {'capture_error_mode': 'thread_local'} if dist is not None else {}
                     with torch.cuda.graph(graph, stream=side, **mode):
                         step()
                 torch.cuda.current_stream().wait_stream(side)
@@ -635,9 +635,6 @@ def main():
                 hip_pred = model.base(x).cpu()
             hip_det = tuple(t.cpu().numpy() for t in out_bufs[:5])
         # release the captured step (graph exec, its memory pool) before the training half: nothing after this needs it
-        if os.environ.get('SQD_BENCH_KEEP_GRAPH'):       # diagnostics: leave the captured step alive next to the training half
-            result['_keep'] = (model, det, run)
-            return
         det.__dict__.pop('_streams', None)
         del model, det, run, infer_step
         import gc
@@ -650,7 +647,7 @@ def main():
         from squeezedet_pytorch_amd.trainer import make_train_step
         step_parts = {}
         step, describe, probe = make_train_step(cfg, sd, x, rank, joined, dist, force_exchange=args.force_dist, parts=step_parts,
-                                                fused_optimizer=not os.environ.get('SQD_BENCH_TORCH_SGD'))
+                                                fused_optimizer=True)
         if rank == 0 and joined == 1 and not args.no_cpu_baseline and args.mode == 'both':
             train_probe = probe()                    # (gt, eval-mode loss of the initial weights), before any optimizer step
         # the whole step (fwd, loss, bwd, gradient exchange, clip, SGD, weight re-pack) replays as a hipGraph: RCCL collectives
@@ -673,19 +670,6 @@ def main():
         summ, nprof = event_profile(step, run, nprof=3)
         ms = elapsed / args.steps * 1e3
         roof, kernels = roofline_of(summ, ms, nprof, mode='train')
-        if os.environ.get('SQD_EXCHANGE_TRACE'):
-            # diagnostics: host wall time of single synchronized eager steps, the time the host spent inside the gradient
-            # exchange's calls, and the sum of the kernels' own HIP-event times -- where does a slow step spend its time?
-            from squeezedet_pytorch_amd.trainer import find_base
-            for k in range(3):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter(); inner(); t_enq = time.perf_counter() - t0
-                torch.cuda.synchronize(); t_all = time.perf_counter() - t0
-                print(f'[bench trace r{rank}] eager training step {k}: host enqueue {t_enq * 1e3:.1f} ms, until GPU idle {t_all * 1e3:.1f} ms; '
-                      f'kernel event sum {sum(v["ms"] for v in summ.values()):.2f} ms', file=sys.stderr)
-            tr = getattr(getattr(step_parts.get('base'), 'grad_sync', None), 'trace', None)
-            if tr:
-                print(f'[bench trace r{rank}] gradient exchange host time, last step: ' + ', '.join(f'{n} {t * 1e3:.2f} ms' for n, t in tr[-4:]), file=sys.stderr)
         result['train'] = {
             'value': round(B * joined * args.steps / elapsed, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4), 'timed_with': how,
             'degraded': bool(wanted_graph and how != 'hipGraph replay'),       # a capture that failed: eager launches were timed instead
@@ -700,10 +684,7 @@ def main():
     # 95..1500 ms.  Round 3 isolated the trigger -- DESIGN.md section 6: torch's own clip_grad_norm_ + torch.optim.SGD launches in
     # that situation; with the fused optimizer step this bench uses, both orders run at 16-20 ms there and inference-first is
     # the faster one -- so the special order is gone.)
-    order = ('infer', 'train')
-    if os.environ.get('SQD_BENCH_ORDER'):              # diagnostics: force the order of the two halves ("infer,train")
-        order = tuple(os.environ['SQD_BENCH_ORDER'].split(','))
-    for half in order:
+    for half in ('infer', 'train'):
         if half == 'infer' and args.mode in ('both', 'infer'):
             bench_infer()
         if half == 'train' and args.mode in ('both', 'train'):

@@ -10,7 +10,6 @@ and returns the gradients of the 64 canonical OIHW parameters.
 """
 from __future__ import annotations
 
-import os
 
 import torch
 
@@ -123,8 +122,6 @@ def run_backbone_forward(base, image, save=False, drop_mask=None, drop=None):
             if (save and base.fuse_train_forward and nxt is not None and nxt[0] == 'pool' and nxt2 is not None and nxt2[0] == 'fire'
                     and base.fuse_fire_bridge and base.use_winograd):
                 zseg_t = ops.choose_fire_pool_bridge(s, e1, e3, nxt2[2], npix)
-                if zseg_t is not None and os.environ.get('SQD_ZSEG_TRAIN'):      # (A/B: segments per strip of the storing form)
-                    zseg_t = int(os.environ['SQD_ZSEG_TRAIN'])
             if zseg is None and ycfg is None:
                 xcfg = ops.choose_fire_wino_cfg(s, e1, e3, npix) if (fusable and base.fuse_expand_wino and base.use_winograd) else None
                 fcfg = ops.choose_fused_cfg(s, e1, npix) if (fusable and xcfg is None and base.fuse_expand and e1 == e3) else None

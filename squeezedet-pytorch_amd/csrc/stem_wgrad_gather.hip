@@ -241,10 +241,7 @@ __global__ __launch_bounds__(256, OCC) void stem_wgrad_gather_kernel(StemWgradAr
 #endif
 }
 
-static int stem_wgrad_gather_occ() {
-  const char* e = getenv("SQD_STEM_GATHER_OCC");
-  return (e && e[0] == '3') ? 3 : 2;
-}
+static int stem_wgrad_gather_occ() { return 2; }      // workgroups per CU the launch is sized for (3 measured no faster)
 
 static int stem_wgrad_gather_slabs(const StemWgradArgs& a, int S, int occ) {
   int dev = 0, cus = 256; hipDeviceProp_t prop;

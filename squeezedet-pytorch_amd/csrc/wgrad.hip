@@ -31,7 +31,6 @@ struct WgradArgs {
   // [N][C] (OIHW, 1x1), the data-gradient output window and whether x's ReLU mask applies to it
   const float* w; float* dx;
   int dx_pitch, dx_coff, dx_mask;
-  int dg_vmcnt0;        // A/B switch (SQD_SQBWD_VMCNT0=1): the block barrier waits for EVERYTHING instead of the counted wait
 };
 
 // LDS tiles are pixel-major rows of exactly TN*16 (dY) / TC*16 (X) floats, filled by LDS-DMA
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   if (pb < a.nblocks) dma_block(pb, 0);
   for (; pb < a.nblocks; pb += (int)gridDim.x) {
     if (DG) {
-      if (first_block || a.dg_vmcnt0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (first_block) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DG_ST) : "memory");
       first_block = false;
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -468,7 +467,7 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
   a.N = N; a.dy_pitch = dy_pitch; a.dy_coff = dy_coff; a.C = C; a.x_pitch = x_pitch; a.x_coff = x_coff;
   a.total_px = (long long)B * H * W;
   a.slab_stride = (long long)N * taps * C + N;
-  a.w = nullptr; a.dx = nullptr; a.dx_pitch = a.dx_coff = a.dx_mask = 0; a.dg_vmcnt0 = 0;
+  a.w = nullptr; a.dx = nullptr; a.dx_pitch = a.dx_coff = a.dx_mask = 0;
   hipStream_t s = (hipStream_t)stream;
   const int tn = N >= 64 ? 4 : sqd_cdiv(N, 16);
   int rc = SQD_ERR_UNSUPPORTED;
@@ -483,13 +482,10 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
     // Round 3: wider output tiles where the layer is wide enough.  A workgroup that owns TC = 8 in-channel tiles (128 channels)
     // re-reads dY half as often as with 4, and N = 96 (the squeeze of fire13 / fire14) runs as ONE 6-tile group instead of 64 + a
     // half-empty 64 (X streamed once instead of twice, no padded MFMAs): the 24x78 1x1 weight gradients were bound by L2 -> LDS
-    // bytes per MFMA, not by HBM or the matrix pipe.  SQD_WGRAD_WIDE=0 restores the 64 x 64 tiles (A/B).
-    static const bool wide = [] { const char* e = getenv("SQD_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+    // bytes per MFMA, not by HBM or the matrix pipe.
     int tn1 = tn, tc = C >= 64 ? 4 : sqd_cdiv(C, 16);
-    if (wide) {
-      if (N > 64 && N <= 96) tn1 = 6;
-      if (C >= 256) tc = 8;          // (C = 128 at 96x312 measured slower with the wide tile: 60.7 -> 74.2 us)
-    }
+    if (N > 64 && N <= 96) tn1 = 6;
+    if (C >= 256) tc = 8;            // (C = 128 at 96x312 measured slower with the wide tile: 60.7 -> 74.2 us)
     // pixels per block sized so the double-buffered LDS image stays <= 40 KB: 4-5 workgroups per CU instead of one
     // (the late 24x78 layers have only ~300 blocks of 128 pixels: with one resident workgroup per CU nothing overlapped)
 #define SQD_WG_CASE(TNv, TCv) if (tn1 == TNv && tc == TCv) rc = launch_wgrad<1, TNv, TCv, ((TNv + TCv >= 6) ? 2 : ((TNv + TCv >= 3) ? 4 : 8))>(a, S, s);
@@ -533,7 +529,6 @@ extern "C" int sqd_squeeze_bwd(const float* dy, const float* x, const float* w_o
   a.total_px = (long long)B * H * W;
   a.slab_stride = (long long)N * C + N;
   a.w = w_oihw; a.dx = dx; a.dx_pitch = dx_pitch; a.dx_coff = dx_coff; a.dx_mask = relu_mask;
-  { const char* e = getenv("SQD_SQBWD_VMCNT0"); a.dg_vmcnt0 = (e && e[0] == '1') ? 1 : 0; }
   hipStream_t s = (hipStream_t)stream;
   const int tn = N > 96 ? 8 : (N > 64 ? 6 : sqd_cdiv(N, 16));
   const int tc = C >= 64 ? 4 : sqd_cdiv(C, 16);

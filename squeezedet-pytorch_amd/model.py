@@ -18,7 +18,6 @@ There is no CPU path: modules raise if the input is not on a GPU or the HIP libr
 """
 from __future__ import annotations
 
-import os
 
 import numpy as np
 import torch
@@ -147,7 +146,7 @@ class SqueezeDetBase(nn.Module):
         self.fuse_expand = True                   # inference forward: expand1x1 + expand3x3 in one launch
         self.fuse_expand_wino = True              # ... in Winograd form (ops.fire_wino) where the table has an X: row
         self.fuse_fire_bridge = True              # ... together with the NEXT Fire's squeeze (ops.fire_bridge) where it has a Y: row
-        self.fuse_train_forward = os.environ.get('SQD_FUSE_TRAIN_FWD', '1')[:1] != '0'    # training forward: the bridges in their storing forms
+        self.fuse_train_forward = True    # training forward: the bridges in their storing forms
         # inference forward: pool 2 / 3 folded into the following squeeze (ops.pool_squeeze).  Off by default: measured equal
         # to the two separate kernels (0.174 vs 0.18 ms) -- both are bound by the 9x L2 read amplification of the window gather
         self.fuse_pool_squeeze = False
@@ -159,7 +158,7 @@ class SqueezeDetBase(nn.Module):
         self.fused_dropout = True
         self._drop = None                   # (torch.initial_seed() it was derived from, ops.DropState)
         self._drop_restored = False         # the stream came from set_dropout_rng (a checkpoint), not from torch's seed
-        self.fuse_squeeze_bwd = os.environ.get('SQD_FUSE_SQUEEZE_BWD', '1')[:1] != '0'     # backward: squeeze wgrad + dgrad in one launch
+        self.fuse_squeeze_bwd = True     # backward: squeeze wgrad + dgrad in one launch
         self.group_wgrad = ops.WINO_WGRAD_GROUP   # backward: the expand3x3 weight gradients of a stage share one launch (ops.conv_wgrad_wino_group)
         self.init_weights()
 

@@ -138,11 +138,9 @@ def wino_sk_params(N=None, C=None):
     (profiles/r04b_sk_schedule_variants.log): a long reduction (ConvDet, 96 chunks) is fastest cut in four (215 us against 241 for
     the unit kernel and 270 for contiguous runs, whose workgroups sit at 512 different K positions); short reductions are fastest
     uncut (k = 1), where the round-robin deal alone beats the unit kernel's grid rounding on many-slice layers (C72 -> N768: 177
-    against 231 us).  Env overrides for A/B runs."""
-    import os
+    against 231 us).  (Sweeps replace this function: tools/sk_bench.py.)"""
     ks = 1 if (C is None or C // 8 < 48) else 4
-    return (int(os.environ.get('SQD_SK_MINSEG', 2)), int(os.environ.get('SQD_SK_HBIAS', 1000)),
-            int(os.environ.get('SQD_SK_KSPLIT', ks)))
+    return 2, 1000, ks
 
 
 def wino_sk_grid():

@@ -333,9 +333,8 @@ def _wino_wgrad_tc(N, C):
     return 1 if (C % 32 == 16 or C < 32) else 2
 
 
-import os as _os
-WINO_WGRAD_GROUP = _os.environ.get('SQD_WW_GROUP', '1')[:1] != '0'   # the expand3x3 weight gradients of one backward stage share a launch
-                                                                     # (ops.conv_wgrad_wino_group; env: A/B runs)
+WINO_WGRAD_GROUP = True    # the expand3x3 weight gradients of one backward stage share a launch (ops.conv_wgrad_wino_group;
+                           # per model: SqueezeDetBase.group_wgrad)
 WINO_WGRAD_GROUP_MAX = 6   # csrc/wino_wgrad.hip WW_MAX_GROUP
 
 
@@ -364,8 +363,7 @@ def wino_wgrad_groups(layers, wino=None, enabled=None):
                 continue
             blocks = sum(wino_wgrad_blocks(N, C) for _k, N, C in part)
             ngroups = B * -(-H // 4) * -(-W // 16)
-            import os
-            tw = int(os.environ.get('SQD_WW_TARGET', _TARGET_WGS_WINO))
+            tw = _TARGET_WGS_WINO
             S = max(1, min(ngroups, tw // blocks if blocks <= tw else 1))
             tuned = _tuning().get(f'GW:{tc}:{blocks}:{B * H * W}')
             if tuned is not None and tuned >= 1:
@@ -375,11 +373,6 @@ def wino_wgrad_groups(layers, wino=None, enabled=None):
                 out[k] = (gid, S, tc, keys)
             gid += 1
     return out
-
-
-def _wgrad_wide():
-    import os
-    return os.environ.get('SQD_WGRAD_WIDE', '1')[:1] != '0'
 
 
 def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False, group_S=None):
@@ -397,8 +390,7 @@ def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False, group_S=None)
         ngroups = B * -(-H // 4) * -(-W // 16)                    # 4x16-pixel groups = the K axis of the 16 position GEMMs
         # (out-channel, in-channel) blocks of dU per workgroup: 64 x 16|32, or all of N <= 80 x 16 (ConvDet)
         blocks = -(-C // (16 * _wino_wgrad_tc(N, C))) if N % 64 else (N // 64) * -(-C // (16 * _wino_wgrad_tc(N, C)))
-        import os
-        tw = int(os.environ.get('SQD_WW_TARGET', _TARGET_WGS_WINO))
+        tw = _TARGET_WGS_WINO
         S = max(1, min(ngroups, tw // blocks if blocks <= tw else 1))
         if tuned is not None and tuned >= 1:
             S = max(1, min(ngroups, int(tuned)))
@@ -408,8 +400,7 @@ def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False, group_S=None)
             raise ValueError('fused 1x1 backward: 1x1 layers with N <= 128')
         nblocks = -(-(B * H * W) // 32)
         groups = -(-C // 64)
-        import os
-        target = int(os.environ.get('SQD_SQBWD_WGS', _TARGET_WGS_SQBWD))      # (env: A/B sweeps)
+        target = _TARGET_WGS_SQBWD
         S = max(1, min(nblocks, target // groups, 1024))
         if tuned is not None and tuned >= 1:
             S = max(1, min(nblocks, int(tuned), 1024))
@@ -427,11 +418,10 @@ def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False, group_S=None)
         nblocks = B * -(-H // 4) * -(-W // 16)
     else:
         tc = 4 if C >= 64 else -(-C // 16)
-        if _wgrad_wide():                       # (mirrors csrc/wgrad.hip sqd_conv_wgrad: 128-channel in-tiles, N = 96 as one 6-tile group)
-            if 64 < N <= 96:
-                tn = 6
-            if C >= 256:
-                tc = 8
+        if 64 < N <= 96:                        # (mirrors csrc/wgrad.hip sqd_conv_wgrad: 128-channel in-tiles, N = 96 as one 6-tile group)
+            tn = 6
+        if C >= 256:
+            tc = 8
         nblocks = -(-(B * H * W) // 128)
     groups = -(-N // (tn * 16)) * -(-C // (tc * 16))
     S = max(1, min(nblocks, (_TARGET_WGS if taps == 9 else _TARGET_WGS_1X1) // groups, 256))

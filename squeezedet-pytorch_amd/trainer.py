@@ -55,9 +55,6 @@ class GradientExchange:
         self._pending = []
         self._captured_works = []
         self.buckets_last_step = []            # [(lo, hi)] of the latest backward, for tests / logging
-        # diagnostics (SQD_EXCHANGE_TRACE=1): host wall time spent inside ready() / finish() per step, [(name, seconds)]
-        import os
-        self.trace = [] if os.environ.get('SQD_EXCHANGE_TRACE') else None
 
     def world(self):
         d = _dist()
@@ -107,7 +104,6 @@ class GradientExchange:
         of the buffer)."""
         if not self._active or hi <= lo:
             return
-        t_in = time.perf_counter() if self.trace is not None else 0.0
         d = _dist()
         if hi == self._total:
             hi = self._flat.numel()             # the count slot travels with the tail bucket
@@ -131,17 +127,12 @@ class GradientExchange:
             # query such an event while it still counted as "recorded in a capturing stream" and to abort the process (about one run
             # in ten of `bench.py --force-dist`).  A handful of objects per captured step.
             self._captured_works.append(work)
-        if self.trace is not None:
-            self.trace.append((f'ready[{lo}:{hi}]', time.perf_counter() - t_in))
 
     def finish(self):
         if not self._active:
             return
-        t_in = time.perf_counter() if self.trace is not None else 0.0
         for w, _lo, _hi in self._pending:
             w.wait()                            # CUDA: the current stream waits for the collective; CPU: blocks
-        if self.trace is not None:
-            self.trace.append(('finish.wait', time.perf_counter() - t_in))
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         if self._native:

@@ -1,11 +1,11 @@
 """Isolated timing of the balanced Winograd kernel (cfg 16) against the unit kernel (cfg 2) on the 24x78 bs=20 layer shapes, over
-schedule variants (SQD_SK_KSPLIT / SQD_SK_HBIAS / SQD_SK_MINSEG).  usage: python tools/sk_bench.py [variant ...]   variant = ks,hb,minseg"""
+schedule variants (tools replace ``plans.wino_sk_params`` for the sweep).  usage: python tools/sk_bench.py [variant ...]   variant = ks,hb,minseg"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from squeezedet_pytorch_amd import ops
+from squeezedet_pytorch_amd import ops, plans
 
 B = int(os.environ.get('BATCH', 20))
 ITERS = int(os.environ.get('ITERS', 30))
@@ -40,7 +40,7 @@ for (C, N, H, W) in shapes:
     ref = y.clone()
     p16 = ops.WinoPlan(w, b, ops.WINO_SK_CFG)
     for (ks, hb, ms) in variants:
-        os.environ['SQD_SK_KSPLIT'], os.environ['SQD_SK_HBIAS'], os.environ['SQD_SK_MINSEG'] = str(ks), str(hb), str(ms)
+        plans.wino_sk_params = (lambda N=None, C=None, _v=(ms, hb, ks): _v); plans._SK_SCHEDULES.clear()
         t = timeit(lambda: ops.conv_wino(x, 0, p16, y, 0, relu=True))
         err = (y - ref).abs().max().item()
         line += f'{t:12.1f}{" " if err < 1e-3 else "!"}   '
