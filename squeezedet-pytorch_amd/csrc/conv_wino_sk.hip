@@ -25,10 +25,6 @@
 #include <algorithm>
 #include <stdlib.h>
 
-#ifndef SQD_SK_U_FIRST
-#define SQD_SK_U_FIRST 0          /* 1: the next stage's U slice is requested right behind the stage barrier (A/B builds) */
-#endif
-
 struct SkSeg { int tile, n0, c0, c1, cls, nparts, part, slab0; };      // 32 bytes; host layout = int32[8]
 
 struct WinoSkArgs {
@@ -309,10 +305,6 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
         for (int gw = 0; gw < GW; ++gw) nsoff[gw] = csoff[gw] + (unsigned)(cc + 1) * 32u;
         nuoff = (unsigned)(cc + 1) * u_chunkB + (unsigned)seg.n0 * 64u;
       }
-#if SQD_SK_U_FIRST
-#pragma unroll
-      for (int it = 0; it < U_IT; ++it) dma_u_one(it, nuoff, ubuf ^ 1);
-#endif
       const float* const uR = uR0 + ubuf * USLOTS * 4;
       const bool first = cc == seg.c0;
 
@@ -373,7 +365,7 @@ __device__ __forceinline__ void wino_sk_body(const WinoSkArgs& a, int sidx, cons
 #pragma unroll
           for (int step = 0; step < NSTEP; ++step) {
             if (step < RAW_IT) dma_raw_one(gw, step < RAW_IT ? step : 0, nsoff[gw]);
-            else if (!SQD_SK_U_FIRST && step - RAW_IT < U_PH) dma_u_one(gw * U_PH + (step - RAW_IT < U_PH ? step - RAW_IT : 0), nuoff, ubuf ^ 1);
+            else if (step - RAW_IT < U_PH) dma_u_one(gw * U_PH + (step - RAW_IT < U_PH ? step - RAW_IT : 0), nuoff, ubuf ^ 1);
             if (step & 1) {
               mfma_pos(step, af1, 0);
               __builtin_amdgcn_sched_barrier(0);

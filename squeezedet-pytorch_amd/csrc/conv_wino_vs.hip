@@ -29,9 +29,7 @@
 #define SQD_VS_DIAG 0             /* ablation builds only (scratch/diag/vs_diag.sh; never in libsqdhip.so): bit 0 = no input transform,
                                      1 = no patch DMA inside the chunk loop, 2 = no stage barrier, 3 = U operands not loaded in the loop */
 #endif
-#ifndef SQD_VS_PRIO
-#define SQD_VS_PRIO 0             /* raise the duty wave's priority behind its transform: measured slower (186 vs 174 us) */
-#endif
+/* (s_setprio for the duty wave behind its transform measured slower, 186 vs 174 us, and is gone.) */
 #ifndef SQD_VS_ENTRY
 #define SQD_VS_ENTRY sqd_conv_wino_vs_fwd
 #endif
@@ -184,19 +182,14 @@ __global__ __launch_bounds__(VS_WV * 64, 3) void conv_wino_vs_kernel(WinoVsArgs 
     f32x4 vq[3];
     vq[0] = *(const f32x4*)vR;
     vq[1] = *(const f32x4*)(vR + 256);
-    bool was_duty = false;
     if (has1 && duty == rank) {
       // this wave's patch of chunk cc + 1 was requested nw intervals ago, before everything but the (at most eight) U loads that
       // are still in flight: vector memory operations retire in order
       // (interval 0: a wave that transforms EVERY chunk requested chunk 1's patch behind the prologue's U loads -- wait for all)
       if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       transform(buf ^ 1, cc + 1 + nw < nchunks ? cc + 1 + nw : -1);
-      was_duty = true;
     }
     if (has1) duty = duty + 1 == nw ? 0 : duty + 1;
-#if SQD_VS_PRIO
-    if (was_duty) __builtin_amdgcn_s_setprio(2);             // catch up with the two waves that had the matrix pipe meanwhile
-#endif
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {
       const f32x4 vc = vq[pp % 3];
@@ -214,9 +207,6 @@ __global__ __launch_bounds__(VS_WV * 64, 3) void conv_wino_vs_kernel(WinoVsArgs 
       if (!(SQD_VS_DIAG & 8)) uq[pp] = load_u(nc, pp);
       __builtin_amdgcn_sched_barrier(0);
     }
-#if SQD_VS_PRIO
-    if (was_duty) __builtin_amdgcn_s_setprio(0);
-#endif
     // V(cc + 1) written (duty wave) and V(cc) read (everyone) before the barrier publishes one and frees the other; the U loads and
     // patch requests in flight stay in flight (a raw s_barrier: __syncthreads() would drain the vector memory queue)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
