@@ -139,6 +139,41 @@ while time.time() - ts < max(2.0, 0.1 * budget):
             print('POOL RELU-CODES MISMATCH', dict(B=B, H=H, W=W, C=C)); sys.exit(1)
         n_ok += 1
 print(f'  .. {nsq} fused squeeze-backward cases ok', flush=True)
+# Grouped Winograd weight gradient (sqd_conv_wgrad_wino_group: several 3x3 layers of one pixel grid in one launch, same splits for all):
+# random groups of 1..6 layers of one tile form, channel windows inside wider buffers, ragged grids; every member's slab sum against autograd
+tg = time.time()
+ngrp = 0
+while time.time() - tg < max(2.0, 0.08 * budget):
+    B = int(rs.randint(1, 4)); H = int(rs.choice([1, 3, 4, 5, 8, 13, 24, 31])); W = int(rs.choice([1, 3, 15, 16, 17, 33, 47, 78]))
+    tc = int(rs.choice([1, 2]))
+    nl = int(rs.randint(1, 7))
+    ngroups = B * -(-H // 4) * -(-W // 16)
+    S = int(rs.randint(1, min(ngroups, 9) + 1))
+    items, refs = [], []
+    for _ in range(nl):
+        C = int(rs.choice([4, 16, 20, 48, 80]) if tc == 1 else rs.choice([32, 36, 64, 96, 128]))
+        N = int(rs.choice([64, 128, 192]))
+        assert ops._wino_wgrad_tc(N, C) == tc
+        xin = torch.randn(B, C, H, W)
+        w = (torch.randn(N, C, 3, 3) * (1.0 / (9 * C)) ** 0.5).requires_grad_(True); b = (torch.randn(N) * 0.1).requires_grad_(True)
+        dy = torch.randn(B, N, H, W)
+        F.conv2d(xin, w, b, padding=1).backward(dy)
+        dyp = N + 4 * int(rs.randint(0, 3)); dyo = 4 * int(rs.randint(0, (dyp - N) // 4 + 1))
+        xp = C + 4 * int(rs.randint(0, 3)); xo = 4 * int(rs.randint(0, (xp - C) // 4 + 1))
+        dyb = torch.randn(B, H, W, dyp); dyb[..., dyo:dyo + N] = nhwc(dy)
+        xb = torch.randn(B, H, W, xp); xb[..., xo:xo + C] = nhwc(xin)
+        slab = torch.full((S * (N * 9 * C + N),), float('nan')).cuda()
+        items.append((dyb.cuda(), dyo, N, xb.cuda(), xo, C, slab)); refs.append((w.grad, b.grad))
+    ops.conv_wgrad_wino_group(items, S, tc)
+    for (dyb, dyo, N, xb, xo, C, slab), (gw, gb) in zip(items, refs):
+        red = slab.view(S, N * 9 * C + N).double().sum(0).cpu()
+        dw = red[:N * 9 * C].view(N, 3, 3, C).permute(0, 3, 1, 2)
+        e1 = (dw - gw.double()).abs().max().item(); e2 = (red[N * 9 * C:] - gb.double()).abs().max().item()
+        if not (e1 <= 1e-4 * max(1.0, gw.abs().max().item()) and e2 <= 1e-4 * max(1.0, gb.abs().max().item())):
+            print('WGRAD GROUP MISMATCH', dict(B=B, H=H, W=W, C=C, N=N, S=S, tc=tc, nl=nl, e1=e1, e2=e2)); sys.exit(1)
+        worst = max(worst, e1 / (1e-4 * max(1.0, gw.abs().max().item())))
+    n_ok += 1; ngrp += 1
+print(f'  .. {ngrp} grouped weight-gradient launches ok', flush=True)
 # Fire bridges (one launch for expand pair + next squeeze, optionally through the max pool): random small-C Fire shapes
 tb = time.time()
 nb = 0
