@@ -1,4 +1,6 @@
 #!/bin/bash
+# the tables scratch/tuning_gw_<v>.json = the shipped tuning.json + one row 'GW:<tc>:<blocks>:<npix>': {'cfg': S} each (a: GW:2:52:37440=19, b: GW:1:18:37440=14,
+# c: =56, d: GW:2:4:149760=64, e: =256, f: GW:1:2:599040=128, g: =512, h: GW:2:52:37440=4); results in DESIGN.md section 3
 O=gpurun_out/r05t; mkdir -p $O
 run() {
   timeout -k 10 200 python bench.py --mode train --steps 40 --warmup 10 --no-cpu-baseline --layers > $O/train_$1.json 2> $O/train_$1.err
