@@ -184,6 +184,7 @@ class DetectStream:
             raise ValueError('DetectStream: lanes must be >= 1')
         self.graph = bool(graph)
         self.max_ragged_graphs_per_lane = 1    # captured shapes per lane besides the full batch size
+        self.max_graphs_per_lane = 8           # captured steps a lane keeps (distinct input tensors of submit_device count separately)
         self.degraded = False
         self.captures = 0
         self.eager_batches = 0
@@ -420,13 +421,22 @@ class DetectStream:
         lane.seen[key] = seen + 1
         g = lane.graphs.get(key)
         if g is None and self.graph and seen >= 1:
-            # every captured shape keeps a memory pool of its own (~0.6-1 GB of activations at bs=20): the full batch size is always
-            # captured, of other (ragged) shapes only the first one a lane sees twice -- a stream of many different ragged batch sizes
-            # stays on eager launches
+            # the full batch size is always captured, of other (ragged) sizes only the first one a lane sees twice: a stream of many
+            # different ragged batch sizes stays on eager launches instead of capturing (a device-wide synchronisation each) for ever.
+            # A lane's graphs share one memory pool; their number is bounded as well (a caller of submit_device that keeps handing in
+            # new tensors would otherwise collect one graph per tensor): the oldest one goes
             others = sum(1 for k2, v in lane.graphs.items() if v != 'eager' and k2[1] != self.cap)
             if key[1] == self.cap or others < self.max_ragged_graphs_per_lane:
+                captured = [k2 for k2, v in lane.graphs.items() if v != 'eager']
+                if len(captured) >= self.max_graphs_per_lane:
+                    torch.cuda.synchronize(self.device)           # (nothing may still be replaying the graph that is dropped)
+                    del lane.graphs[captured[0]]
+                    lane.seen.pop(captured[0], None)
                 g = self._capture(lane, compute)
                 lane.graphs[key] = g
+        if len(lane.seen) > 4096:                                 # (keys of tensors seen once and never again)
+            lane.seen = {k2: v for k2, v in lane.seen.items() if k2 in lane.graphs}
+            lane.seen[key] = seen + 1
         with torch.cuda.stream(lane.comp):
             if g is not None and g != 'eager':
                 g.replay()

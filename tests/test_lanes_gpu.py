@@ -92,6 +92,33 @@ def test_stream_device_path_equals_detect_device():
     assert int(sum(w[0].sum() for w in want)) > 10
 
 
+def test_stream_keeps_a_bounded_number_of_graphs_per_lane():
+    """A caller that keeps handing ``submit_device`` new tensors: every tensor seen twice on a lane is captured, but a lane keeps at
+    most ``max_graphs_per_lane`` captured steps (the oldest is dropped) -- and the results stay those of ``detect_device``."""
+    from squeezedet_pytorch_amd import synthetic
+    det, cfg = _detector(batch_size=2)
+    ex = det.stream(lanes=1)
+    ex.max_graphs_per_lane = 3
+    xs = [synthetic.make_images(2, cfg.input_size, seed=10 + s).cuda() for s in range(5)]
+    want = [tuple(t.cpu().numpy() for t in det.detect_device(x)) for x in xs]
+    order = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 0, 0, 4]
+
+    def check(r):
+        cnt, _cls, sc, bx, idx = want[r.tag]
+        assert np.array_equal(r.count, cnt)
+        for b in range(2):                                           # (rows >= count are padding)
+            n = int(cnt[b])
+            assert np.array_equal(r.anchor_idx[b, :n], idx[b, :n]) and np.array_equal(r.boxes[b, :n], bx[b, :n]) and np.array_equal(r.scores[b, :n], sc[b, :n])
+    for i in order:
+        ex.submit_device(xs[i], tag=i)
+        if ex.pending() > 1:
+            check(ex.fetch()[1])
+    for _t, r in ex.drain():
+        check(r)
+    lane = ex._lanes[0]
+    assert sum(1 for v in lane.graphs.values() if v != 'eager') <= 3 and ex.captures >= 5 and not ex.degraded
+
+
 def test_stream_slots_grow_for_larger_images_and_three_lanes():
     det, cfg = _detector(batch_size=2)
     small = _images(4, [(375, 1242)], seed=5)
