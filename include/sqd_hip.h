@@ -82,6 +82,12 @@ int sqd_conv_wgrad_wino(const float* dy, const float* x, float* slab, float* dw,
  * layer needs N % 64 == 0 and must select tile form tc (tc = 1: C < 32 or C % 32 == 16; tc = 2 otherwise); SQD_ERR_UNSUPPORTED otherwise.
  * Bitwise the slabs of n sqd_conv_wgrad_wino(dw = NULL) calls with the same S and tc. */
 int sqd_conv_wgrad_wino_group(const long long* layers, int n, int B, int H, int W, int S, int tc, void* stream);
+/* The same for 1x1 layers (the expand1x1 convolutions of a stage whose width rules out the fused squeeze backward, Fire.expand1x1,
+ * src/model/squeezedet.py:13,20): records as above, slab i holds S * (N_i*C_i + N_i) floats.  Every layer must select the same tile form
+ * sqd_conv_wgrad would give it (N >= 64 and not 64 < N <= 96; in-channel tile 16 * ceil(C / 16) up to 64, 128 from C = 256) and
+ * S <= the number of its pixel blocks; SQD_ERR_UNSUPPORTED otherwise.  Bitwise the slabs of n sqd_conv_wgrad(dw = NULL, taps = 1) calls
+ * with the same S. */
+int sqd_conv_wgrad_group(const long long* layers, int n, int B, int H, int W, int S, void* stream);
 
 /* dw == NULL in sqd_conv_wgrad: write the S partial slabs only; the caller then reduces many layers with ONE launch:
  * descs_dev = device array of n records of 9 int64 {slab offset, dw offset, db offset (floats from slab_base / grad_base;

@@ -36,6 +36,7 @@ _SIGNATURES = {
     'sqd_grad_scale': [c_p, ctypes.c_longlong, c_f, c_p, c_p, c_f, c_p],
     'sqd_conv_wgrad_wino': [c_p] * 5 + [c_i] * 11 + [c_p],
     'sqd_conv_wgrad_wino_group': [c_p] + [c_i] * 6 + [c_p],
+    'sqd_conv_wgrad_group': [c_p] + [c_i] * 5 + [c_p],
     'sqd_squeeze_bwd': [c_p] * 5 + [c_i] * 13 + [c_p],
     'sqd_stem_wgrad': [c_p] * 5 + [c_i] * 6 + [c_p],
     'sqd_stem_wgrad_pooled': [c_p] * 7 + [c_i] * 6 + [c_p],

@@ -28,10 +28,15 @@ def _wgrad_layout(base, saved, B, H, W):
     e3s = [(f'features.{i}.expand3x3', layers[i][4], layers[i][2]) + tuple(saved[f'fire{i}'][2].shape[:3])
            for i in range(len(layers) - 1, 1, -1) if layers[i][0] == 'fire']
     groups = ops.wino_wgrad_groups(e3s, enabled=getattr(base, 'group_wgrad', None))
+    # ... and the expand1x1 weight gradients that are too wide for the fused squeeze backward (their own direct-form launch otherwise)
+    fsb = bool(getattr(base, 'fuse_squeeze_bwd', False))
+    e1s = [(f'features.{i}.expand1x1', layers[i][3], layers[i][2]) + tuple(saved[f'fire{i}'][2].shape[:3])
+           for i in range(len(layers) - 1, 1, -1) if layers[i][0] == 'fire' and not (fsb and ops.squeeze_bwd_ok(layers[i][3], layers[i][2]))]
+    groups.update(ops.wgrad1x1_groups(e1s, enabled=getattr(base, 'group_wgrad', None)))
 
     def add(pre, N, C, taps, shp, fused=False):
         entries.append((pre, N, C, taps, shp[0], shp[1], shp[2], slots[pre + '.weight'][0], slots[pre + '.bias'][0], fused,
-                        groups.get(pre) if taps == 9 else None))
+                        None if fused else groups.get(pre)))
     add('convdet', base.convdet.out_channels, base.convdet.in_channels, 9, (B, H, W))
     for i in range(len(layers) - 1, 1, -1):
         if layers[i][0] != 'fire':
@@ -121,18 +126,24 @@ def run_backbone_backward(base, saved, dpred):
         pre = f'features.{i}.'
         fused_e1 = bool(wb.fused.get(pre + 'expand1x1'))
 
-        if not fused_e1:
-            ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
-        grp = wb.group_of.get(pre + 'expand3x3')
-        if grp is None:
-            ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
-        else:
-            # runs with the other expand3x3 layers of this stage, as soon as the last of them has its gradient (dA stays alive until then)
+        def grouped(key, item, run_group):
+            # a member of a launch group runs with the other members, as soon as the last of them has its gradient (dA stays alive until
+            # then); returns False for a layer that has its own launch
+            grp = wb.group_of.get(key)
+            if grp is None:
+                return False
             lst = pending.setdefault(grp[0], [])
-            lst.append((dA, e1, e3, sq, 0, s, wb.slab(pre + 'expand3x3')))
+            lst.append(item)
             if len(lst) == len(grp[3]):
-                ops.conv_wgrad_wino_group(lst, grp[1], grp[2])
+                run_group(lst, grp)
                 del pending[grp[0]]
+            return True
+        if not fused_e1 and not grouped(pre + 'expand1x1', (dA, 0, e1, sq, 0, s, wb.slab(pre + 'expand1x1')),
+                                        lambda lst, grp: ops.conv_wgrad_group(lst, grp[1])):
+            ops.conv_wgrad(dA, 0, e1, sq, 0, s, 1, slab=wb.slab(pre + 'expand1x1'))
+        if not grouped(pre + 'expand3x3', (dA, e1, e3, sq, 0, s, wb.slab(pre + 'expand3x3')),
+                       lambda lst, grp: ops.conv_wgrad_wino_group(lst, grp[1], grp[2])):
+            ops.conv_wgrad(dA, e1, e3, sq, 0, s, 9, slab=wb.slab(pre + 'expand3x3'))
         dSq = torch.empty_like(sq)
         if fused_e1:
             # narrow expand1x1 (N <= 128: the first four Fires): weight-gradient slabs and the data gradient from ONE pass over the

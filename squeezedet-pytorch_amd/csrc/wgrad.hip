@@ -51,8 +51,10 @@ typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
 // rows = in-channel, columns = pixel, k = out-channel with the k-slice permuted as in the Fire bridges (MFMA r of a 16-channel
 // block takes n = 16 j + 4 g + r from lane group g): one ds_read_b128 of a dy row piece / of a transposed-weight row piece feeds
 // four MFMAs, and a lane ends with four consecutive in-channels of one pixel = one 16-byte store.
+// The body serves the one-layer launch (conv_wgrad_kernel: grid = (splits, channel-tile groups)) and the grouped one below.
+// ``split`` / ``nsplit``: which pixel blocks (split, split + nsplit, ...) and which slab; ``by``: the (out, in)-channel tile group.
 template <int TAPS, int TN, int TC, int TH, bool DG = false>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void wg_body(const WgradArgs& a, const int split, const int nsplit, const int by) {
   static_assert(!DG || TAPS == 1, "the fused data gradient exists for 1x1 layers");
   constexpr int PB = TH * 16;                                 // pixels per block
   constexpr int RN = TN * 4, RC = TC * 4;                     // 16-byte slots per row
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, kq = lane >> 4;
-  const int ng = blockIdx.y % a.n_groups, cg = blockIdx.y / a.n_groups;
+  const int ng = by % a.n_groups, cg = by / a.n_groups;
   const int n0 = ng * TN * 16, c0 = cg * TC * 16;
   const bool do_bias = (cg == 0);
 
@@ -236,10 +238,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       dg_v[it] = (c0 + c < a.C) ? (px * a.dx_pitch + c) * 4 : (int)0x80000000;
     }
   }
-  int pb = blockIdx.x, buf = 0;
+  int pb = split, buf = 0;
   bool first_block = true;
   if (pb < a.nblocks) dma_block(pb, 0);
-  for (; pb < a.nblocks; pb += (int)gridDim.x) {
+  for (; pb < a.nblocks; pb += nsplit) {
     if (DG) {
       if (first_block) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DG_ST) : "memory");
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // explicit: every wave's share of the block's LDS-DMA has landed ...
       __syncthreads();                   // ... before the barrier publishes it; previous compute finished
     }
-    const int nxt = pb + (int)gridDim.x;
+    const int nxt = pb + nsplit;
     if (nxt < a.nblocks) dma_block(nxt, buf ^ 1);
     const float* dyT = dyB + buf * DSLOTS * 4;
     const float* xT = xB + buf * XSLOTS * 4;
@@ -351,8 +353,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     buf ^= 1;
   }
 
-  // one slab per blockIdx.x; layout [n][tap][c] then [N] bias sums
-  float* slab = a.slab + (long long)blockIdx.x * a.slab_stride;
+  // one slab per split; layout [n][tap][c] then [N] bias sums
+  float* slab = a.slab + (long long)split * a.slab_stride;
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
     int nt, ct, tap;
@@ -384,6 +386,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
   }
+}
+
+template <int TAPS, int TN, int TC, int TH, bool DG = false>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  wg_body<TAPS, TN, TC, TH, DG>(a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+// Several 1x1 layers of one pixel grid (the expand1x1 layers of a backward stage that are too wide for the fused squeeze backward) in
+// ONE launch, every layer cut into the same S splits: as wino_wgrad_group_kernel (wino_wgrad.hip) -- a layer alone needs 42-170 splits to
+// fill the chip and then walks only 7-28 pixel blocks per workgroup.  Records by value in the kernel arguments; a layer's workgroups
+// are a contiguous run, split-major inside it.
+#define WG_MAX_GROUP 6
+struct WgGroupArgs { WgradArgs l[WG_MAX_GROUP]; int wg0[WG_MAX_GROUP + 1]; int S, n; };
+
+template <int TN, int TC, int TH>
+__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(WgGroupArgs ga) {
+  const int pos = (int)blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < WG_MAX_GROUP; ++k) i = (k < ga.n && pos >= ga.wg0[k]) ? k : i;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const WgradArgs a = ga.l[i];
+  const int local = pos - ga.wg0[i];
+  wg_body<1, TN, TC, TH, false>(a, local % ga.S, ga.S, local / ga.S);
 }
 
 // dw (OIHW: [N][C][TAPS]) and db ([N]) = fixed-order sum of S slabs.  A block reduces 32 consecutive
@@ -502,6 +528,69 @@ extern "C" int sqd_conv_wgrad(const float* dy, const float* x, float* slab, floa
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs + WGR_OUT - 1) / WGR_OUT)), dim3(WGR_OUT * WGR_PARTS), 0, s, slab, dw, db, S,
                      a.slab_stride, N, C, taps);
   return sqd_launch_status();
+}
+
+template <int TN, int TC, int TH>
+static int launch_wgrad_group(WgGroupArgs& ga, hipStream_t stream) {
+  constexpr int PB = TH * 16;
+  constexpr int DSLOTS = (PB * TN * 4 + 255) & ~255, XSLOTS = (PB * TC * 4 + 255) & ~255;
+  constexpr size_t lds = (size_t)(2 * DSLOTS + 2 * XSLOTS) * 16;
+  static_assert(lds <= 160 * 1024, "wgrad LDS budget");
+  auto kern = conv_wgrad_group_kernel<TN, TC, TH>;
+  static SqdDevOnce once;
+  if (lds > 64 * 1024 && sqd_max_lds_once(once, (const void*)kern, (int)lds) != SQD_OK) return SQD_ERR_LAUNCH;
+  int wg = 0;
+  for (int i = 0; i < ga.n; ++i) {
+    WgradArgs& a = ga.l[i];
+    a.tiles_x = a.tiles_y = 0;
+    a.nblocks = (int)((a.total_px + PB - 1) / PB);
+    if (ga.S > a.nblocks) return SQD_ERR_UNSUPPORTED;
+    a.n_groups = sqd_cdiv(a.N, TN * 16);
+    ga.wg0[i] = wg;
+    wg += ga.S * a.n_groups * sqd_cdiv(a.C, TC * 16);
+  }
+  for (int i = ga.n; i <= WG_MAX_GROUP; ++i) ga.wg0[i] = wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wg), dim3(256), lds, stream, ga);
+  return sqd_launch_status();
+}
+
+// The weight-gradient slabs of up to WG_MAX_GROUP 1x1 layers that share B, H, W in ONE launch, every layer cut into the same S splits
+// (see conv_wgrad_group_kernel).  ``layers``: n records of 9 64-bit words {dy, x, slab, N, dy_pitch, dy_coff, C, x_pitch, x_coff} (host
+// memory).  All layers must select the same tile form as sqd_conv_wgrad would (N >= 64 and not in (64, 96]: 64 out-channels; in-channel
+// tile 16 * ceil(C / 16) up to 64, 128 from C = 256); SQD_ERR_UNSUPPORTED otherwise.  Slabs only.
+extern "C" int sqd_conv_wgrad_group(const long long* layers, int n, int B, int H, int W, int S, void* stream) {
+  SQD_CHECK_ARG(layers && n >= 1 && n <= WG_MAX_GROUP && B > 0 && H > 0 && W > 0 && S > 0 && S <= 65535);
+  WgGroupArgs ga;
+  ga.n = n; ga.S = S;
+  int tc0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const long long* r = layers + 9 * i;
+    WgradArgs& a = ga.l[i];
+    a.dy = (const float*)(uintptr_t)r[0]; a.x = (const float*)(uintptr_t)r[1]; a.slab = (float*)(uintptr_t)r[2];
+    a.N = (int)r[3]; a.dy_pitch = (int)r[4]; a.dy_coff = (int)r[5]; a.C = (int)r[6]; a.x_pitch = (int)r[7]; a.x_coff = (int)r[8];
+    a.B = B; a.H = H; a.W = W;
+    SQD_CHECK_ARG(a.dy && a.x && a.slab && a.N > 0 && a.C > 0);
+    SQD_CHECK_ARG((a.N & 3) == 0 && (a.C & 3) == 0 && (a.dy_pitch & 3) == 0 && (a.dy_coff & 3) == 0 && (a.x_pitch & 3) == 0 && (a.x_coff & 3) == 0);
+    SQD_CHECK_ARG(a.dy_coff + a.N <= a.dy_pitch && a.x_coff + a.C <= a.x_pitch);
+    SQD_CHECK_ARG(((uintptr_t)a.dy & 15) == 0 && ((uintptr_t)a.x & 15) == 0);
+    a.total_px = (long long)B * H * W;
+    a.slab_stride = (long long)a.N * a.C + a.N;
+    a.w = nullptr; a.dx = nullptr; a.dx_pitch = a.dx_coff = a.dx_mask = 0;
+    if (a.N < 64 || (a.N > 64 && a.N <= 96)) return SQD_ERR_UNSUPPORTED;          // (those layers run other tile forms: their own launch)
+    const int tc = a.C >= 256 ? 8 : (a.C >= 64 ? 4 : sqd_cdiv(a.C, 16));
+    if (i == 0) tc0 = tc;
+    if (tc != tc0) return SQD_ERR_UNSUPPORTED;
+  }
+  for (int i = n; i < WG_MAX_GROUP; ++i) ga.l[i] = ga.l[0];
+  hipStream_t s = (hipStream_t)stream;
+  switch (tc0) {
+    case 1: return launch_wgrad_group<4, 1, 4>(ga, s);
+    case 2: return launch_wgrad_group<4, 2, 2>(ga, s);
+    case 3: return launch_wgrad_group<4, 3, 2>(ga, s);
+    case 4: return launch_wgrad_group<4, 4, 2>(ga, s);
+    case 8: return launch_wgrad_group<4, 8, 2>(ga, s);
+  }
+  return SQD_ERR_UNSUPPORTED;
 }
 
 // A Fire squeeze's backward in ONE launch (reference: autograd of Fire.squeeze + squeeze_activation, src/model/squeezedet.py:12,19,

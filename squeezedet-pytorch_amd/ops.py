@@ -744,6 +744,33 @@ def conv_wgrad_wino_group(items, S, tc):
         br.done()
 
 
+def conv_wgrad_group(items, S):
+    """The direct 1x1 weight-gradient slabs of several layers of one pixel grid in ONE launch (``tiles.wgrad1x1_groups`` decides which).
+    ``items`` as ``conv_wgrad_wino_group``; ``slab`` = the layer's ``WgradBatch`` view of S * (N*C + N) floats."""
+    if not 1 <= len(items) <= WINO_WGRAD_GROUP_MAX:
+        raise ValueError('grouped weight gradient: 1..%d layers' % WINO_WGRAD_GROUP_MAX)
+    B, H, W = items[0][0].shape[:3]
+    rows, flops, byts, tag = [], 0.0, 0.0, []
+    for dy, dy_coff, N, x, x_coff, C, slab in items:
+        _check_nhwc(dy, 'dy'); _check_nhwc(x, 'x')
+        if tuple(dy.shape[:3]) != (B, H, W) or tuple(x.shape[:3]) != (B, H, W):
+            raise ValueError('grouped weight gradient: the layers of a group share B,H,W')
+        if dy_coff + N > dy.shape[3] or x_coff + C > x.shape[3] or N % 4 or C % 4:
+            raise ValueError('grouped weight gradient: channel window out of range')
+        if slab.numel() != S * (N * C + N) or not slab.is_contiguous() or slab.dtype != torch.float32:
+            raise ValueError('grouped weight gradient: slab workspace does not match the layer')
+        rows += [dy.data_ptr(), x.data_ptr(), slab.data_ptr(), N, dy.shape[3], dy_coff, C, x.shape[3], x_coff]
+        flops += 2.0 * B * H * W * N * C
+        byts += 4.0 * (B * H * W * (C + N) + 2 * S * (N * C + N))
+        tag.append(f'C{C} N{N}')
+    table = (ctypes.c_longlong * len(rows))(*rows)
+    br = _Bracket('conv_wgrad_group<1>', f'wgrad 1tap {" + ".join(tag)} {H}x{W}', flops, byts) if timing._timer is not None else None
+    rc = nat.lib().sqd_conv_wgrad_group(ctypes.cast(table, ctypes.c_void_p), len(items), B, H, W, int(S), nat.stream_handle(items[0][0].device))
+    nat.check(rc, 'sqd_conv_wgrad_group')
+    if br is not None:
+        br.done()
+
+
 def squeeze_bwd_ok(N, C):
     """Whether ``squeeze_bwd`` can run a (C -> N) 1x1 layer: all N out-channels in one group."""
     return N % 4 == 0 and C % 4 == 0 and N <= 128

@@ -213,6 +213,9 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
     # expand3x3 weight gradients that share a launch (``group_wgrad`` = ``SqueezeDetBase.group_wgrad``): issued when the last member is reached
     groups = ops.wino_wgrad_groups([(i, layers[i][4], layers[i][2], batch, geo[i][0], geo[i][1]) for i in range(last, 1, -1)
                                     if layers[i][0] == 'fire'], enabled=group_wgrad)
+    fire_idx = [i for i in range(last, 1, -1) if layers[i][0] == 'fire']
+    groups.update(ops.wgrad1x1_groups([(('e1', i), layers[i][3], layers[i][2], batch, geo[i][0], geo[i][1]) for i in fire_idx
+                                       if not (fuse_squeeze_bwd and ops.squeeze_bwd_ok(layers[i][3], layers[i][2]))], enabled=group_wgrad))
     pending = {}
     for i in range(last, 1, -1):
         l = layers[i]
@@ -228,7 +231,13 @@ def training_launch_plan(arch='squeezedet', batch=20, input_size=(384, 1248), an
         _, cin, s, e1, e3 = l
         fused_e1 = fuse_squeeze_bwd and ops.squeeze_bwd_ok(e1, s)
         if not fused_e1:
-            plan.append(_wgrad(batch, Hi, Wi, e1, s, 1))
+            if ('e1', i) in groups:
+                gid, _S, _tc, members = groups[('e1', i)]
+                pending.setdefault(gid, []).append(f'C{s} N{e1}')
+                if len(pending[gid]) == len(members):
+                    plan.append(('conv_wgrad_group<1>', f'wgrad 1tap {" + ".join(pending.pop(gid))} {Hi}x{Wi}'))
+            else:
+                plan.append(_wgrad(batch, Hi, Wi, e1, s, 1))
         if i in groups:
             gid, _S, _tc, members = groups[i]
             pending.setdefault(gid, []).append(f'C{s} N{e3}')

@@ -375,6 +375,42 @@ def wino_wgrad_groups(layers, wino=None, enabled=None):
     return out
 
 
+def _wgrad1x1_tc(C):
+    """In-channel tiles of 16 per workgroup of the direct 1x1 weight-gradient kernel for N >= 64 layers (csrc/wgrad.hip sqd_conv_wgrad)."""
+    return 8 if C >= 256 else (4 if C >= 64 else -(-C // 16))
+
+
+def wgrad1x1_groups(layers, enabled=None):
+    """Which 1x1 weight gradients that do NOT run in the fused squeeze backward share a launch (``ops.conv_wgrad_group``).  ``layers``:
+    [(key, N, C, B, H, W)] in launch (backward) order.  Returns {key: (group id, S, tc, member keys)}: same pixel grid, 64-out-channel
+    tile form (N >= 64, not 64 < N <= 96), same in-channel tile, at least two members (at most WINO_WGRAD_GROUP_MAX per launch).
+    S = the splits every member is cut into: one resident round of workgroups over the whole group ('G1:tc:groups:npix' overrides)."""
+    if not (WINO_WGRAD_GROUP if enabled is None else enabled):
+        return {}
+    buckets = {}
+    for key, N, C, B, H, W in layers:
+        if N >= 64 and not (64 < N <= 96) and N % 4 == 0 and C % 4 == 0:
+            buckets.setdefault((B, H, W, _wgrad1x1_tc(C)), []).append((key, N, C))
+    out, gid = {}, 1000
+    for (B, H, W, tc), members in buckets.items():
+        for lo in range(0, len(members), WINO_WGRAD_GROUP_MAX):
+            part = members[lo:lo + WINO_WGRAD_GROUP_MAX]
+            if len(part) < 2:
+                continue
+            groups = sum(-(-N // 64) * -(-C // (16 * tc)) for _k, N, C in part)
+            pb = 64 if tc == 1 else 32                     # pixels per block of the tile form (TH * 16)
+            nblocks = -(-(B * H * W) // pb)
+            S = max(1, min(nblocks, _TARGET_WGS_1X1 // groups if groups <= _TARGET_WGS_1X1 else 1))
+            tuned = _tuning().get(f'G1:{tc}:{groups}:{B * H * W}')
+            if tuned is not None and tuned >= 1:
+                S = max(1, min(nblocks, int(tuned)))
+            keys = tuple(k for k, _n, _c in part)
+            for k in keys:
+                out[k] = (gid, S, tc, keys)
+            gid += 1
+    return out
+
+
 def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False, group_S=None):
     """(S, slab stride): number of split-K partial slabs the weight-gradient kernel writes for this layer, floats per slab.
     ``group_S``: the layer runs inside a grouped launch (``wino_wgrad_groups``) with that many splits.
@@ -383,8 +419,8 @@ def wgrad_split(N, C, taps, B, H, W, wino=None, fused_dgrad=False, group_S=None)
     train: the split of each layer tried inside the training step)."""
     tuned = _tuning().get(f'G:{taps}:{N}:{C}:{B * H * W}')
     if group_S is not None:
-        if not wgrad_uses_wino(N, C, taps, B, H, W, wino):
-            raise ValueError('grouped weight gradient: Winograd 3x3 layers only')
+        if fused_dgrad or not (taps == 1 or wgrad_uses_wino(N, C, taps, B, H, W, wino)):
+            raise ValueError('grouped weight gradient: Winograd 3x3 layers or plain 1x1 layers only')
         return int(group_S), N * taps * C + N
     if wgrad_uses_wino(N, C, taps, B, H, W, wino):
         ngroups = B * -(-H // 4) * -(-W // 16)                    # 4x16-pixel groups = the K axis of the 16 position GEMMs

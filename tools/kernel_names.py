@@ -33,6 +33,7 @@ def short_name(k):
     m = re.match(r"wino_wgrad_kernel<", short)
     if m: return "conv_wgrad_wino"
     if short.startswith("wino_wgrad_group_kernel<"): return "conv_wgrad_wino_group"     # several layers of a backward stage in one launch (round 5)
+    if short.startswith("conv_wgrad_group_kernel<"): return "conv_wgrad_group<1>"       # ... and the wide expand1x1 layers of a stage
     m = re.match(r"conv_wgrad_kernel<(\d+), \d+, \d+, \d+(, (true|false))?>", short)
     if m: return "squeeze_bwd" if m.group(3) == "true" else f"conv_wgrad<{m.group(1)}>"
     m = re.match(r"stem_wave_kernel<\d+, \d+, (true|false), (\d+)>", short)           # the wave-autonomous 3x3 stem (round 3): same bench name as the
