@@ -254,6 +254,15 @@ def roofline_of(summ, ms_per_step, nprof, mode='infer'):
         # Winograd F(2x2,3x3): `achieved` counts the multiply-adds the MFMA pipe executes; the same launch expressed in
         # direct-form 3x3 flops (what the implicit-GEMM kernel would have to execute) is 2.25x that
         roof['direct_form_equivalent_tflops'] = round(ach * 2.25, 2)
+    # the same figure per launch shape of the dominant kernel: the aggregate above averages shapes whose grids fill the chip differently
+    # (e.g. C96 -> N384 runs 3.5 rounds of workgroups, C48 -> N192 1.76) -- [launches per step, us per launch, fraction of the same peak]
+    per_shape = {}
+    for tag, (n_l, ms_l, fl_l, by_l) in sorted(d['tags'].items(), key=lambda kv: -kv[1][1]):
+        if n_l <= 0 or ms_l <= 0:
+            continue
+        frac_l = (fl_l / (ms_l / 1e3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if roof['bound'] == 'mfma' else (by_l / (ms_l / 1e3) / 1e9 / PEAK_HBM_GBS)
+        per_shape[tag] = {'launches_per_step': round(n_l, 2), 'avg_launch_us': round(ms_l / n_l * 1e3, 2), 'frac': round(frac_l, 4)}
+    roof['per_shape'] = per_shape
     roof.update({'kernel': dominant, 'launches_per_step': int(round(d['launches'])),
                  'avg_launch_us': round(avg_s * 1e6, 2),
                  'algorithmic_per_launch': {'gflop': round(flops_per_launch / 1e9, 3), 'mbytes': round(bytes_per_launch / 1e6, 3)},
