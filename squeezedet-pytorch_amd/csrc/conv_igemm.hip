@@ -857,10 +857,9 @@ static int launch_conv(ConvArgs a, hipStream_t stream) {
   constexpr int MINW = LDSW < REGW ? (LDSW < 1 ? 1 : LDSW) : REGW;
   auto kern = conv_igemm_kernel<TAPS, KC, MT, NT, MINW>;
   static int wgs_per_cu = 0;                 // occupancy of this instantiation (immutable once computed)
+  static SqdDevOnce lds_once;                // (the LDS attribute is per device)
+  if (lds > 64 * 1024 && sqd_max_lds_once(lds_once, (const void*)kern, (int)lds) != SQD_OK) return SQD_ERR_LAUNCH;
   if (wgs_per_cu == 0) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
     wgs_per_cu = nb > 4 ? 4 : nb;
@@ -906,10 +905,9 @@ static int launch_conv_dma(ConvArgs a, hipStream_t stream) {
   constexpr int MINW = (MINW0 < WM / 4) ? WM / 4 : MINW0;
   auto kern = stationary ? conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW, FUSE, true> : conv_dma_kernel<TAPS, KC, MT, NT, WM, MINW, FUSE, false>;
   static int wgs_per_cu[2] = {0, 0};
+  static SqdDevOnce lds_once[2];
+  if (lds_max > 64 * 1024 && sqd_max_lds_once(lds_once[stationary], (const void*)kern, (int)lds_max) != SQD_OK) return SQD_ERR_LAUNCH;
   if (wgs_per_cu[stationary] == 0) {
-    if (lds_max > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
-      return SQD_ERR_LAUNCH;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
     wgs_per_cu[stationary] = nb > 6 ? 6 : nb;

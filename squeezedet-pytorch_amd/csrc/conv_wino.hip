@@ -891,10 +891,9 @@ static int launch_wino(WinoArgs a, hipStream_t stream) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv_wino_kernel<NT, WV>;
   static int wgs_per_cu = 0;
+  static SqdDevOnce lds_once;
+  if (lds > 64 * 1024 && sqd_max_lds_once(lds_once, (const void*)kern, (int)lds) != SQD_OK) return SQD_ERR_LAUNCH;
   if (wgs_per_cu == 0) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
     wgs_per_cu = nb > 4 ? 4 : nb;

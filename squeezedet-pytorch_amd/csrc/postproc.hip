@@ -427,12 +427,8 @@ static int launch_detect(DetArgs a, hipStream_t stream) {
   if (a.K < 1 || a.K > DET_K) return SQD_ERR_UNSUPPORTED;                 // one wave holds the NMS bit matrix
   const size_t lds = (size_t)((a.A + 3) & ~3) * 4 + (size_t)a.A * 2 + 16;  // keys + uint16 candidate indices
   if (a.A > 65535 || lds > 150 * 1024) return SQD_ERR_UNSUPPORTED;        // A <= 25600 anchors per image
-  static size_t lds_enabled = 48 * 1024;                                   // raise the dynamic-LDS cap once per size class
-  if (lds > lds_enabled) {
-    if (hipFuncSetAttribute((const void*)detect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-      return SQD_ERR_LAUNCH;
-    lds_enabled = 150 * 1024;
-  }
+  static SqdDevOnce lds_once;                                              // raise the dynamic-LDS cap once per device
+  if (lds > 48 * 1024 && sqd_max_lds_once(lds_once, (const void*)detect_kernel, 150 * 1024) != SQD_OK) return SQD_ERR_LAUNCH;
   // pred mode with a workspace: eight workgroups score an image, its last arriver selects and suppresses (the workspace holds B x
   // ceil4(A) keys + B counters that are zero between launches)
   a.S = (a.pred && a.keys) ? DET_SPLIT : 1;

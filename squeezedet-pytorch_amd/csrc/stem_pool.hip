@@ -493,10 +493,9 @@ static int launch_stem_pool_t(StemPoolArgs a, hipStream_t s) {
   a.tiles_y_m = a.tiles_y > 1 ? (unsigned)(((1ull << 32) + a.tiles_y - 1) / a.tiles_y) : 0u;
   auto kern = stem_pool_kernel<KS, PAD, NT, ARGMAX, WM>;
   static int wgs_per_cu = 0;
+  static SqdDevOnce lds_once;
+  if (lds > 64 * 1024 && sqd_max_lds_once(lds_once, (const void*)kern, (int)lds) != SQD_OK) return SQD_ERR_LAUNCH;
   if (wgs_per_cu == 0) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SQD_ERR_LAUNCH;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
     wgs_per_cu = nb > 4 ? 4 : nb;

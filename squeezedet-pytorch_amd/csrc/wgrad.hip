@@ -454,9 +454,8 @@ static int launch_wgrad(WgradArgs a, int S, hipStream_t stream) {
   constexpr size_t lds = (size_t)(2 * DSLOTS + 2 * XSLOTS) * 16 + (DG ? (size_t)TC * 16 * WP * 4 : 0);
   static_assert(lds <= 160 * 1024, "wgrad LDS budget");
   auto kern = conv_wgrad_kernel<TAPS, TN, TC, TH, DG>;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return SQD_ERR_LAUNCH;
+  static SqdDevOnce lds_once;
+  if (lds > 64 * 1024 && sqd_max_lds_once(lds_once, (const void*)kern, (int)lds) != SQD_OK) return SQD_ERR_LAUNCH;
   if (TAPS == 9) {
     a.tiles_x = sqd_cdiv(a.W, 16); a.tiles_y = sqd_cdiv(a.H, TH);
     a.nblocks = a.B * a.tiles_x * a.tiles_y;
